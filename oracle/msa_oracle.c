@@ -1,0 +1,855 @@
+/*
+ * oracle/msa_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-thread CPU restatement of the trimAl 2.0-RC algorithms that sit
+ * behind pytrimal's `*Trimmer.trim()`:  the per-column / pairwise MSA statistics
+ * (statistics::Gaps, statistics::Similarity incl. its identity-weight matrix,
+ * Cleaner::calculateSeqIdentity, Cleaner::calculateSpuriousVector) and the host
+ * selection logic (Cleaner::clean*, selectMethod, getClustering ...) that turns
+ * the statistic vectors into kept-column / kept-sequence masks.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this file's shared object.  The product (pytrimal_amd + libmsastat_hip.so) never
+ * links, imports or calls it.
+ *
+ * PROVENANCE.  The arithmetic of this path lives in an un-vendored git submodule of
+ * the reference: module github.com/inab/trimal, branch 2.0_RC, >= d89ffc3 + PRs
+ * #117/#118 (reference .gitmodules:1-3, CHANGELOG.md:47,65).  `vendor/trimal` is
+ * empty in /root/reference, so nothing can be compiled from it; each function below
+ * restates trimAl's published algorithm and cites the in-tree declaration / call
+ * site it follows (paths relative to /root/reference).
+ *
+ * PINNING.  tests/test_oracle_golden.py checks this file against every surviving
+ * fixture of the reference's own test-suite (pins P1..P9):
+ * cons60.gt90 / cons40.gt40 column masks, seq80.res80 / seq40.res60 overlap,
+ * maxidentity75 / id70 / id50 clustering, noduplicateseqs, example.001 automated1 /
+ * strictplus / gt90.w3 outputs, the 4-sequence OverlapTrimmer docstring example and
+ * the error cases.  NOT pinned by any surviving fixture (dangling symlinks in the
+ * reference checkout): strict / strictplus / gappyout / automated1 at realistic
+ * size, automated2, clusters=K.  Those paths are "parity unpinned" beyond the 6x46
+ * example and are marked [R] (recalled upstream behaviour) below.
+ *
+ * All `float` is IEEE binary32; build with -ffp-contract=off (see Makefile) so a
+ * multiply followed by an add is never fused.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_E_WINDOW_TOO_BIG 1   /* report_system.pxd: WindowTooBig */
+#define ORC_E_INCORRECT_SYMBOL 2 /* reportsystem.cpp:46-49 -> ValueError */
+#define ORC_E_UNDEFINED_SYMBOL 3
+#define ORC_E_NOT_IMPLEMENTED 4
+#define ORC_E_NOMEM 5
+
+#define ORC_GAPPYOUT 1
+#define ORC_STRICT 2
+
+static int round_int(double x) { return (int)(x + 0.5); } /* trimAl utils::roundInt */
+
+/* ------------------------------------------------------------------------------------------
+ * a1  statistics::Gaps::CalculateVectors   (include/trimal/statistics.pxd:18-21,
+ *     docs/guide/statistics.rst:24-44).  gaps[c] = #rows with '-' in column c; hist[g] =
+ *     #columns with g gaps (m+2 entries so the 2nd-slope scan terminates).
+ * ---------------------------------------------------------------------------------------- */
+void orc_gaps(const uint8_t *a, int m, int n, int ld, int32_t *gaps, int32_t *hist,
+              int32_t *max_gaps, int64_t *total_gaps) {
+    int mx = 0;
+    int64_t tot = 0;
+    if (hist) memset(hist, 0, sizeof(int32_t) * (size_t)(m + 2));
+    for (int c = 0; c < n; c++) {
+        int g = 0;
+        for (int i = 0; i < m; i++) g += (a[(size_t)i * ld + c] == '-');
+        gaps[c] = g;
+        if (hist) hist[g]++;
+        if (g > mx) mx = g;
+        tot += g;
+    }
+    if (max_gaps) *max_gaps = mx;
+    if (total_gaps) *total_gaps = tot;
+}
+
+/* Gaps::applyWindow [R; exercised by tests/data/example.001.gt90.w3.clw,
+ * tests/test_manual_trimmer.py:37-52].  Mirror borders, integer result. */
+int orc_gaps_window(const int32_t *g, int n, int hw, int32_t *gw) {
+    if (hw > n / 4) return ORC_E_WINDOW_TOO_BIG;
+    if (hw <= 0) {
+        memcpy(gw, g, sizeof(int32_t) * (size_t)n);
+        return ORC_OK;
+    }
+    int win = 2 * hw + 1;
+    for (int i = 0; i < n; i++) {
+        int s = 0;
+        for (int j = i - hw; j <= i + hw; j++) {
+            if (j < 0) s += g[-j];
+            else if (j >= n) s += g[(2 * n - j) - 2];
+            else s += g[j];
+        }
+        gw[i] = round_int((double)s / win);
+    }
+    return ORC_OK;
+}
+
+/* Gaps::calcCutPoint(minInputAlignment, gapThreshold)  [pinned by cons60.gt90/cons40.gt40].
+ * gapThreshold is the maximum gap FRACTION (= 1 - gap_threshold kwarg, _trimal.pyx:1589). */
+double orc_gaps_cutpoint(const int32_t *hist, int m, int n, float base_line, float gap_threshold) {
+    double cut_gap = (double)m * gap_threshold;
+    double need = round_int(((double)(n * base_line) / 100.0));
+    if (need > n) need = n;
+    int i, acc = 0;
+    for (i = 0; i < m; i++) {
+        acc += hist[i];
+        if (acc >= need) break;
+    }
+    double cut_cons;
+    if (i < m + 1 && hist[i]) cut_cons = (double)(i - ((float)(acc - need) / hist[i]));
+    else cut_cons = 0;
+    return cut_cons > cut_gap ? cut_cons : cut_gap;
+}
+
+/* Gaps::calcCutPoint2ndSlope [R; on example.001 -> 1].  `row` is an int in upstream
+ * (ratios are truncated into it), kept here. */
+int orc_gaps_cutpoint_2nd_slope(const int32_t *hist, int m, int n, int max_gaps) {
+    int max_iter = max_gaps + 1, act = 0, best = 0, prev, pprev, row = 1;
+    float *s2 = (float *)malloc(sizeof(float) * (size_t)(max_gaps + 2));
+    for (int i = 0; i < max_gaps + 2; i++) s2[i] = -1.0f;
+    while (act < max_iter) {
+        while (hist[act] == 0) act++;
+        pprev = act;
+        if (act + 1 >= max_iter) break;
+        do { act++; } while (hist[act] == 0);
+        prev = act;
+        if (act + 1 >= max_iter) break;
+        do { act++; } while (hist[act] == 0);
+        if (act >= max_iter) break;
+        s2[act] = ((float)(act - pprev) / m);
+        s2[act] /= ((float)(hist[act] + hist[prev]) / n);
+        if (s2[pprev] != -1.0f) {
+            if ((s2[act] / s2[pprev]) > row) {
+                row = (int)(s2[act] / s2[pprev]);
+                best = pprev;
+            }
+        } else if (s2[prev] != -1.0f) {
+            if ((s2[act] / s2[prev]) > row) {
+                row = (int)(s2[act] / s2[prev]);
+                best = pprev;
+            }
+        }
+        act = prev;
+    }
+    free(s2);
+    return best;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2/a5  pair counts.  Cleaner::calculateSeqIdentity (include/trimal/cleaner.pxd:42) and
+ *        Similarity::calculateMatrixIdentity (statistics.pxd:56) share the integers
+ *        dst = #{c : valid(a_ic) or valid(a_jc)}, hit = #{c counted : a_ic == a_jc} on RAW bytes
+ *        (docs/guide/statistics.rst:64-84).  valid(x) = x != '-' and x != indet.
+ *        Full symmetric m*m output, diagonal 0.
+ * ---------------------------------------------------------------------------------------- */
+void orc_pair_counts(const uint8_t *a, int m, int n, int ld, uint8_t indet, uint32_t *hit,
+                     uint32_t *dst) {
+    uint8_t *valid = (uint8_t *)malloc((size_t)m * n);
+    for (int i = 0; i < m; i++)
+        for (int c = 0; c < n; c++) {
+            uint8_t x = a[(size_t)i * ld + c];
+            valid[(size_t)i * n + c] = (x != '-' && x != indet);
+        }
+    for (int i = 0; i < m; i++) {
+        const uint8_t *ri = a + (size_t)i * ld, *vi = valid + (size_t)i * n;
+        hit[(size_t)i * m + i] = 0;
+        dst[(size_t)i * m + i] = 0;
+        for (int j = i + 1; j < m; j++) {
+            const uint8_t *rj = a + (size_t)j * ld, *vj = valid + (size_t)j * n;
+            uint32_t h = 0, d = 0;
+            for (int c = 0; c < n; c++) {
+                uint32_t cnt = vi[c] | vj[c];
+                d += cnt;
+                h += cnt & (uint32_t)(ri[c] == rj[c]);
+            }
+            hit[(size_t)i * m + j] = hit[(size_t)j * m + i] = h;
+            dst[(size_t)i * m + j] = dst[(size_t)j * m + i] = d;
+        }
+    }
+    free(valid);
+}
+
+/* identities[i][j] = (float)hit/dst, diagonal 0  (alignment.pxd:27).  dst == 0 -> 0 [R]. */
+void orc_identities(const uint32_t *hit, const uint32_t *dst, int m, float *ident) {
+    for (size_t k = 0; k < (size_t)m * m; k++) ident[k] = dst[k] ? (float)hit[k] / (float)dst[k] : 0.0f;
+    for (int i = 0; i < m; i++) ident[(size_t)i * m + i] = 0.0f;
+}
+
+/* matrixIdentity[i][j] = 1.0F - (float)sum/length  (statistics.pxd:49).  The diagonal is never
+ * written nor read upstream; 0 here. */
+void orc_weights(const uint32_t *hit, const uint32_t *dst, int m, float *w) {
+    for (size_t k = 0; k < (size_t)m * m; k++)
+        w[k] = dst[k] ? 1.0f - ((float)hit[k] / (float)dst[k]) : 1.0f - 0.0f;
+    for (int i = 0; i < m; i++) w[(size_t)i * m + i] = 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7  similarityMatrix::distMat, exactly as src/pytrimal/_trimal.pyx:1987-1997
+ *     (float accumulator, C sqrt(double) narrowed to float).
+ * ---------------------------------------------------------------------------------------- */
+void orc_distmat(const float *sim, int npos, float *dist) {
+    for (int j = 0; j < npos; j++) {
+        dist[j * npos + j] = 0.0f;
+        for (int i = j + 1; i < npos; i++) {
+            float total = 0;
+            for (int k = 0; k < npos; k++)
+                total += ((sim[k * npos + j] - sim[k * npos + i]) * (sim[k * npos + j] - sim[k * npos + i]));
+            dist[i * npos + j] = dist[j * npos + i] = (float)sqrt((double)total);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a3  Similarity::calculateVectors(cutByGap=true)  (statistics.pxd:55; statistics.rst:86-106).
+ *     Sequential float32 accumulation over valid pairs j<k in lexicographic order.
+ *     q_out (optional) receives num/den before the exp.
+ *     err[0..2] = {row, col, byte} of the first offending residue on error.
+ * ---------------------------------------------------------------------------------------- */
+int orc_similarity(const uint8_t *a, int m, int n, int ld, uint8_t indet, const float *w,
+                   const int32_t *gaps_w, const int32_t *vhash, const float *dist, int npos,
+                   float *mdk, float *q_out, int32_t *err) {
+    int32_t *code = (int32_t *)malloc(sizeof(int32_t) * (size_t)m);
+    for (int c = 0; c < n; c++) {
+        if (q_out) q_out[c] = 0.0f;
+        if (gaps_w && ((float)gaps_w[c] / m) >= 0.8f) {
+            mdk[c] = 0.0f;
+            continue;
+        }
+        /* residue -> matrix index; -1 = skipped (gap / indetermination) */
+        for (int j = 0; j < m; j++) {
+            uint8_t x = a[(size_t)j * ld + c];
+            if (x == '-' || x == indet) { code[j] = -1; continue; }
+            int up = (x >= 'a' && x <= 'z') ? x - 32 : x;
+            if (up < 'A' || up > 'Z') {
+                if (err) { err[0] = j; err[1] = c; err[2] = x; }
+                free(code);
+                return ORC_E_INCORRECT_SYMBOL;
+            }
+            int h = vhash[up - 'A'];
+            if (h == -1) {
+                if (err) { err[0] = j; err[1] = c; err[2] = x; }
+                free(code);
+                return ORC_E_UNDEFINED_SYMBOL;
+            }
+            code[j] = h;
+        }
+        float num = 0, den = 0;
+        for (int j = 0; j < m; j++) {
+            if (code[j] < 0) continue;
+            const float *wj = w + (size_t)j * m;
+            const float *dj = dist + (size_t)code[j] * npos;
+            for (int k = j + 1; k < m; k++) {
+                if (code[k] < 0) continue;
+                num += wj[k] * dj[code[k]];
+                den += wj[k];
+            }
+        }
+        if (den == 0) mdk[c] = 0.0f;
+        else {
+            float q = num / den;
+            if (q_out) q_out[c] = q;
+            float v = (float)exp(-(double)q);
+            mdk[c] = v > 1.0f ? 1.0f : v;
+        }
+    }
+    free(code);
+    return ORC_OK;
+}
+
+/* Similarity::applyWindow [R]: float mean over 2w+1 with mirrored borders. */
+int orc_window_f32(const float *v, int n, int hw, float *out) {
+    if (hw > n / 4) return ORC_E_WINDOW_TOO_BIG;
+    if (hw <= 0) {
+        memcpy(out, v, sizeof(float) * (size_t)n);
+        return ORC_OK;
+    }
+    int win = 2 * hw + 1;
+    for (int i = 0; i < n; i++) {
+        float s = 0.0f;
+        for (int j = i - hw; j <= i + hw; j++) {
+            if (j < 0) s += v[-j];
+            else if (j >= n) s += v[(2 * n - j) - 2];
+            else s += v[j];
+        }
+        out[i] = s / (float)win;
+    }
+    return ORC_OK;
+}
+
+static int cmp_f32(const void *x, const void *y) {
+    float a = *(const float *)x, b = *(const float *)y;
+    return (a > b) - (a < b);
+}
+static int cmp_i32(const void *x, const void *y) {
+    int a = *(const int32_t *)x, b = *(const int32_t *)y;
+    return (a > b) - (a < b);
+}
+
+/* Similarity::calcCutPoint(baseLine, conservationPct) (statistics.pxd:61) [R; unpinned].
+ * Upstream indexes the sorted vector at (int)((n-1)*(100-baseLine)/100), which is past the end
+ * when baseLine is unset (-1, _trimal.pyx:1656); clamped here (undefined upstream). */
+double orc_sim_cutpoint(const float *mdkw, int n, float base_line, float sim_threshold) {
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+    memcpy(tmp, mdkw, sizeof(float) * (size_t)n);
+    qsort(tmp, (size_t)n, sizeof(float), cmp_f32);
+    int pos = (int)((double)(n - 1) * (100.0 - base_line) / 100.0);
+    if (pos > n - 1) pos = n - 1;
+    if (pos < 0) pos = 0;
+    double c = tmp[pos];
+    free(tmp);
+    return c < sim_threshold ? c : sim_threshold;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6  Cleaner::calculateSpuriousVector(overlap, out)  (cleaner.pxd:27; statistics.rst:128-156).
+ * ---------------------------------------------------------------------------------------- */
+void orc_overlap(const uint8_t *a, int m, int n, int ld, uint8_t indet, float overlap, float *out) {
+    float fo = overlap * (float)(m - 1);
+    int need = (int)ceilf(fo);
+    uint8_t *col = (uint8_t *)malloc((size_t)m);
+    int32_t *good = (int32_t *)calloc((size_t)m, sizeof(int32_t));
+    for (int c = 0; c < n; c++) {
+        for (int i = 0; i < m; i++) col[i] = a[(size_t)i * ld + c];
+        for (int i = 0; i < m; i++) {
+            uint8_t x = col[i];
+            int vx = (x != '-' && x != indet), hit = 0;
+            for (int k = 0; k < m; k++) {
+                if (k == i) continue;
+                uint8_t y = col[k];
+                if (x == y) hit++;
+                else if (vx && y != '-' && y != indet) hit++;
+            }
+            if (hit >= need) good[i]++;
+        }
+    }
+    for (int i = 0; i < m; i++) out[i] = (float)good[i] / n;
+    free(col);
+    free(good);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a10  Cleaner::selectMethod (cleaner.pxd:16) [decision pinned on example.001 only].
+ * ---------------------------------------------------------------------------------------- */
+int orc_select_method(const float *ident, int m, float *avg_out, float *max_out) {
+    float max_seq = 0, avg_seq = 0;
+    for (int i = 0; i < m; i++) {
+        float mx = 0, avg = 0;
+        for (int j = 0; j < m; j++) {
+            if (i == j) continue;
+            float v = ident[(size_t)i * m + j];
+            mx = mx < v ? v : mx;
+            avg += v;
+        }
+        avg_seq += avg / (m - 1);
+        max_seq += mx;
+    }
+    avg_seq = avg_seq / m;
+    max_seq = max_seq / m;
+    if (avg_out) *avg_out = avg_seq;
+    if (max_out) *max_out = max_seq;
+    if (avg_seq >= 0.55) return ORC_GAPPYOUT;
+    else if (avg_seq <= 0.38) return ORC_STRICT;
+    else {
+        if (m <= 20) return ORC_GAPPYOUT;
+        else {
+            if ((max_seq >= 0.5) && (max_seq <= 0.65)) return ORC_GAPPYOUT;
+            else return ORC_STRICT;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9  column selection.  save[c] = c if kept, -1 if dropped (alignment.pxd:29).
+ * ---------------------------------------------------------------------------------------- */
+
+/* shared recovery walk of the three cleanByCutValue* functions (cleaner.pxd:17-19)
+ * [pinned for the gaps flavour by cons60.gt90].  ok(c) says whether a dropped column may be
+ * re-added. */
+typedef struct {
+    const int32_t *gw; double cut_g; int use_g;
+    const float *vw; float cut_v; int use_v;
+} recover_rule;
+static int rule_ok(const recover_rule *r, int c) {
+    if (r->use_g && r->use_v) return (r->vw[c] >= r->cut_v) || (r->gw[c] <= r->cut_g);
+    if (r->use_g) return r->gw[c] <= r->cut_g;
+    return r->vw[c] >= r->cut_v;
+}
+static void recover_columns(int32_t *save, int n, int oth, const recover_rule *r) {
+    for (int k = round_int(0.005 * n); (k >= 0) && (oth > 0); k--) {
+        int i, j, jn;
+        for (i = (n / 2), j = (i + 1); (((i > 0) || (j < (n - 1))) && (oth > 0)); i--, j++) {
+            for (jn = i; (jn >= 0) && (save[jn] != -1) && (oth > 0); jn--) ;
+            if ((i - jn) >= k)
+                for (; (jn >= 0) && (save[jn] == -1) && (oth > 0); jn--) {
+                    if (rule_ok(r, jn)) { save[jn] = jn; oth--; }
+                    else break;
+                }
+            i = jn;
+            for (jn = j; (jn < n) && (save[jn] != -1) && (oth > 0); jn++) ;
+            if ((jn - j) >= k)
+                for (; (jn < n) && (save[jn] == -1) && (oth > 0); jn++) {
+                    if (rule_ok(r, jn)) { save[jn] = jn; oth--; }
+                    else break;
+                }
+            j = jn;
+        }
+    }
+}
+
+/* Cleaner::cleanByCutValueOverpass(cut, baseLine, gInCol)  -- keep iff gw <= cut. */
+void orc_clean_overpass(const int32_t *gw, int n, double cut, float base_line, int32_t *save) {
+    int kept = 0;
+    for (int c = 0; c < n; c++) {
+        if (gw[c] <= cut) { save[c] = c; kept++; }
+        else save[c] = -1;
+    }
+    int oth = round_int((((base_line / 100.0) - (float)kept / n)) * n);
+    if (oth > 0) {
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+        memcpy(tmp, gw, sizeof(int32_t) * (size_t)n);
+        qsort(tmp, (size_t)n, sizeof(int32_t), cmp_i32);
+        recover_rule r = {gw, (double)tmp[(int)((float)(n - 1) * (base_line) / 100.0)], 1, NULL, 0, 0};
+        free(tmp);
+        recover_columns(save, n, oth, &r);
+    }
+}
+
+/* Cleaner::cleanByCutValueFallBehind(cut, baseLine, ValueVect) -- keep iff value > cut [R]. */
+void orc_clean_fallbehind(const float *vw, int n, float cut, float base_line, int32_t *save) {
+    int kept = 0;
+    for (int c = 0; c < n; c++) {
+        if (vw[c] > cut) { save[c] = c; kept++; }
+        else save[c] = -1;
+    }
+    int oth = round_int((((base_line / 100.0) - (float)kept / n)) * n);
+    if (oth > 0) {
+        float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+        memcpy(tmp, vw, sizeof(float) * (size_t)n);
+        qsort(tmp, (size_t)n, sizeof(float), cmp_f32);
+        recover_rule r = {NULL, 0, 0, vw, tmp[(int)((float)(n - 1) * (100.0 - base_line) / 100.0)], 1};
+        free(tmp);
+        recover_columns(save, n, oth, &r);
+    }
+}
+
+/* Cleaner::cleanByCutValueOverpassOrEquals(cutGaps, gInCol, baseLine, cutCons, MDK_Win) [R]. */
+void orc_clean_both(const int32_t *gw, const float *vw, int n, double cut_g, float cut_v,
+                    float base_line, int32_t *save) {
+    int kept = 0;
+    for (int c = 0; c < n; c++) {
+        if ((vw[c] > cut_v) && (gw[c] <= cut_g)) { save[c] = c; kept++; }
+        else save[c] = -1;
+    }
+    int oth = round_int((((base_line / 100.0) - (float)kept / n)) * n);
+    if (oth > 0) {
+        float *tf = (float *)malloc(sizeof(float) * (size_t)n);
+        int32_t *ti = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+        memcpy(tf, vw, sizeof(float) * (size_t)n);
+        memcpy(ti, gw, sizeof(int32_t) * (size_t)n);
+        qsort(tf, (size_t)n, sizeof(float), cmp_f32);
+        qsort(ti, (size_t)n, sizeof(int32_t), cmp_i32);
+        recover_rule r = {gw, (double)ti[(int)((float)(n - 1) * (base_line) / 100.0)], 1,
+                          vw, tf[(int)((float)(n - 1) * (100.0 - base_line) / 100.0)], 1};
+        free(tf);
+        free(ti);
+        recover_columns(save, n, oth, &r);
+    }
+}
+
+/* simCut of Cleaner::cleanCombMethods (cleaner.pxd:30) [pinned on example.001 via P5]. */
+float orc_comb_simcut(const int32_t *gw, const float *mdkw, int n, int gap_cut) {
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int acm = 0;
+    for (int c = 0; c < n; c++)
+        if (gw[c] <= gap_cut) tmp[acm++] = mdkw[c];
+    qsort(tmp, (size_t)acm, sizeof(float), cmp_f32);
+    float first20 = 0, last80 = 0;
+    for (int i = acm - 1, j = 1; i >= 0; i--, j++) {
+        if ((((float)j / acm) * 100.0) <= 20.0) first20 = tmp[i];
+        if ((((float)j / acm) * 100.0) <= 80.0) last80 = tmp[i];
+    }
+    free(tmp);
+    double inic = log10((double)first20), fin = log10((double)last80);
+    double vlr = ((inic - fin) / 10) + fin;
+    return (float)pow(10, vlr);
+}
+
+/* Cleaner::cleanStrict(gapCut, gInCol, simCut, MDK_W, complementary, variable) (cleaner.pxd:20)
+ * [P5: snapshot rescue discriminated; edge columns and trailing-block handling are R]. */
+void orc_clean_strict(const int32_t *gw, const float *mdkw, int n, int gap_cut, float sim_cut,
+                      int variable, int32_t *save) {
+    uint8_t *rej = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    for (int c = 0; c < n; c++) {
+        rej[c] = (gw[c] > gap_cut || mdkw[c] < sim_cut);
+        save[c] = rej[c] ? -1 : c;
+    }
+    /* rescue against the snapshot `rej` */
+    if (n > 2 && rej[0]) save[0] = (rej[1] + rej[2]) > 0 ? -1 : 0;
+    if (n > 3 && rej[1]) save[1] = (rej[0] + rej[2] + rej[3]) > 0 ? -1 : 1;
+    if (n >= 5) {
+        for (int c = 2; c < n - 2; c++)
+            if (rej[c]) save[c] = (rej[c - 2] + rej[c - 1] + rej[c + 1] + rej[c + 2]) > 1 ? -1 : c;
+        if (rej[n - 2]) save[n - 2] = (rej[n - 4] + rej[n - 3] + rej[n - 1]) > 0 ? -1 : n - 2;
+        if (rej[n - 1]) save[n - 1] = (rej[n - 3] + rej[n - 2]) > 0 ? -1 : n - 1;
+    }
+    free(rej);
+    int len_block;
+    if (!variable) len_block = 5;
+    else {
+        len_block = round_int(n * 0.01F);
+        len_block = len_block > 3 ? (len_block < 12 ? len_block : 12) : 3;
+    }
+    /* drop kept runs shorter than len_block; as upstream, a run touching the last column is
+     * only examined when a dropped column follows it, i.e. never [R]. */
+    int pos = 0, counter = 0;
+    for (int c = 0; c < n; c++) {
+        if (save[c] != -1) { pos = c; counter++; continue; }
+        if (counter < len_block)
+            while (counter > 0) { save[pos--] = -1; counter--; }
+        counter = 0;
+    }
+}
+
+/* Cleaner::removeAllGapsSeqsAndCols (cleaner.pxd:40; _trimal.pyx:1692-1694). */
+void orc_remove_all_gaps(const uint8_t *a, int m, int n, int ld, int32_t *save_seq, int32_t *save_res) {
+    for (int i = 0; i < m; i++) {
+        if (save_seq[i] == -1) continue;
+        int valid = 0;
+        for (int c = 0; c < n && !valid; c++)
+            if (save_res[c] != -1 && a[(size_t)i * ld + c] != '-') valid = 1;
+        if (!valid) save_seq[i] = -1;
+    }
+    for (int c = 0; c < n; c++) {
+        if (save_res[c] == -1) continue;
+        int valid = 0;
+        for (int i = 0; i < m && !valid; i++)
+            if (save_seq[i] != -1 && a[(size_t)i * ld + c] != '-') valid = 1;
+        if (!valid) save_res[c] = -1;
+    }
+}
+
+/* Cleaner::removeDuplicates as patched by patches/Cleaner.cpp.patch:1-14: the EARLIER of two
+ * identical rows is dropped [pinned by ENOG411BWBU.noduplicateseqs.fasta]. */
+void orc_remove_duplicates(const uint8_t *a, int m, int n, int ld, int32_t *save_seq) {
+    for (int i = 0; i < m; i++)
+        for (int x = i + 1; x < m; x++)
+            if (memcmp(a + (size_t)i * ld, a + (size_t)x * ld, (size_t)n) == 0) {
+                save_seq[i] = -1;
+                break;
+            }
+}
+
+/* trimAl utils::quicksort(int **, ini, fin): Sedgewick partition on the last element, keyed on
+ * [0] only.  Not stable; the tie order is observable in calculateRepresentativeSeq and is pinned
+ * by maxidentity75 / id70 [R for the routine itself]. */
+static void ts_swap(int32_t *x, int32_t *y) {
+    int32_t t0 = x[0], t1 = x[1];
+    x[0] = y[0]; x[1] = y[1];
+    y[0] = t0; y[1] = t1;
+}
+static void ts_quicksort(int32_t *v /* pairs */, int ini, int fin) {
+    if ((ini >= fin) || (fin < 0)) return;
+    int32_t div = v[2 * fin];
+    int i = ini - 1, j = fin;
+    while (1) {
+        while (v[2 * (++i)] < div) if (i == fin) break;
+        while (v[2 * (--j)] > div) if (j == 0) break;
+        if (i < j) ts_swap(&v[2 * i], &v[2 * j]);
+        else break;
+    }
+    ts_swap(&v[2 * i], &v[2 * fin]);
+    ts_quicksort(v, ini, i - 1);
+    ts_quicksort(v, i + 1, fin);
+}
+
+static int32_t *sorted_by_length(const uint8_t *a, int m, int n, int ld, int stable) {
+    int32_t *seqs = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)m);
+    for (int i = 0; i < m; i++) {
+        int len = 0;
+        for (int c = 0; c < n; c++) len += (a[(size_t)i * ld + c] != '-');
+        seqs[2 * i] = len;
+        seqs[2 * i + 1] = i;
+    }
+    if (stable) { /* insertion sort: stable ascending */
+        for (int i = 1; i < m; i++) {
+            int32_t k0 = seqs[2 * i], k1 = seqs[2 * i + 1];
+            int j = i - 1;
+            while (j >= 0 && seqs[2 * j] > k0) { seqs[2 * j + 2] = seqs[2 * j]; seqs[2 * j + 3] = seqs[2 * j + 1]; j--; }
+            seqs[2 * j + 2] = k0; seqs[2 * j + 3] = k1;
+        }
+    } else ts_quicksort(seqs, 0, m - 1);
+    return seqs;
+}
+
+/* Cleaner::calculateRepresentativeSeq(maximumIdent) (cleaner.pxd:44) [pinned P3].
+ * Returns the number of clusters; keeps representatives in save_seq.  sort_mode 0 = trimAl
+ * quicksort, 1 = stable ascending. */
+int orc_representatives(const uint8_t *a, int m, int n, int ld, const float *ident, float max_ident,
+                        int sort_mode, int32_t *save_seq) {
+    int32_t *seqs = sorted_by_length(a, m, n, ld, sort_mode);
+    int32_t *cluster = (int32_t *)malloc(sizeof(int32_t) * (size_t)m);
+    int nc = 1;
+    cluster[0] = seqs[2 * (m - 1) + 1];
+    for (int i = m - 2; i >= 0; i--) {
+        int s = seqs[2 * i + 1], pos = -1, j;
+        float mx = 0;
+        for (j = 0; j < nc; j++) {
+            float v = ident[(size_t)s * m + cluster[j]];
+            if (v > max_ident && v > mx) { mx = v; pos = j; }
+        }
+        if (pos == -1) cluster[nc++] = s;
+    }
+    for (int i = 0; i < m; i++) save_seq[i] = -1;
+    for (int j = 0; j < nc; j++) save_seq[cluster[j]] = cluster[j];
+    free(seqs);
+    free(cluster);
+    return nc;
+}
+
+/* Cleaner::getCutPointClusters(clusterNumber) (cleaner.pxd:35) [R; PARITY UNPINNED: the
+ * reference's clusters5/clusters10 fixtures are stale]. */
+float orc_cutpoint_clusters(const uint8_t *a, int m, int n, int ld, const float *ident, int k,
+                            int sort_mode) {
+    if (k == m) return 1;
+    if (k == 1) return 0;
+    float gmax = 0, gmin = 1, start = 0, prev = 0, iter = 0;
+    for (int i = 0; i < m; i++) {
+        float mx = 0, mn = 1, avg = 0;
+        for (int j = 0; j < m; j++) {
+            if (j == i) continue;
+            float v = ident[(size_t)i * m + j];
+            if (mx < v) mx = v;
+            if (mn > v) mn = v;
+            avg += v;
+        }
+        start += avg / (m - 1);
+        if (mx > gmax) gmax = mx;
+        if (mn < gmin) gmin = mn;
+    }
+    start /= m;
+    int32_t *seqs = sorted_by_length(a, m, n, ld, sort_mode);
+    int32_t *cluster = (int32_t *)malloc(sizeof(int32_t) * (size_t)m);
+    cluster[0] = seqs[2 * (m - 1) + 1];
+    while (1) {
+        int nc = 1;
+        for (int i = m - 2; i >= 0; i--) {
+            int j;
+            for (j = 0; j < nc; j++)
+                if (ident[(size_t)seqs[2 * i + 1] * m + cluster[j]] > start) break;
+            if (j == nc) cluster[nc++] = seqs[2 * i + 1];
+        }
+        if ((nc == k) || (iter > 10)) break;
+        if (nc > k) { gmax = start; start = (gmax + gmin) / 2; }
+        else { gmin = start; start = (gmax + gmin) / 2; }
+        if (prev != nc) { iter = 0; prev = (float)nc; }
+        else iter++;
+    }
+    free(seqs);
+    free(cluster);
+    return start;
+}
+
+/* trimAl utils::checkAlignmentType [R] -> 'X' for amino-acid alignments else 'N'
+ * (_trimal.pyx:759-763,868-898).  Returns SequenceTypes bits: 1 DNA, 2 RNA, 4 AA, 8 DEG
+ * (include/trimal/__init__.pxd:5-10 order NotDefined, DNA, RNA, AA, DEG as bit flags). */
+int orc_alignment_type(const uint8_t *a, int m, int n, int ld) {
+    static const char dna[] = "AGCTN", rna[] = "AGCUN", deg[] = "RYKMSWBDHV";
+    int g_dna = 0, g_rna = 0, ext_dna = 0, ext_rna = 0;
+    for (int i = 0; i < m; i++) {
+        int k = 0, hd = 0, hr = 0, dg = 0;
+        for (int j = 0; j < n && k < 100; j++) {
+            uint8_t x = a[(size_t)i * ld + j];
+            if (x == '-' || x == '.' || x == '?') continue;
+            k++;
+            int up = (x >= 'a' && x <= 'z') ? x - 32 : x;
+            if (up && strchr(dna, up)) hd++;
+            if (up && strchr(rna, up)) hr++;
+            if (up && strchr(deg, up)) dg++;
+        }
+        if (k == 0) continue;
+        if ((((float)(hd + dg) / k) < 0.7) && (((float)(hr + dg) / k) < 0.7)) return 4;
+        else if (hr > hd && dg == 0) g_rna++;
+        else if (hr < hd && dg == 0) g_dna++;
+        else if (hr > hd && dg != 0) ext_rna++;
+        else if (hr < hd && dg != 0) ext_dna++;
+    }
+    if (ext_dna != 0 && ext_dna > ext_rna) return 1 | 8;
+    else if (ext_rna != 0 && ext_dna < ext_rna) return 2 | 8;
+    else if (g_rna > g_dna) return 2;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * trimAlManager::clean_alignment (include/trimal/manager.pxd:88) as driven by
+ * BaseTrimmer.trim (_trimal.pyx:1291-1365) and the four _configure_manager methods
+ * (_trimal.pyx:1479-1497, 1651-1659, 1766-1769, 1859-1862).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t method;  /* 0 none, 1 strict, 2 strictplus, 3 gappyout, 4 nogaps, 5 noallgaps,
+                        6 automated1, 7 automated2, 8 noduplicateseqs */
+    float gap_threshold;           /* max gap fraction (1 - kwarg) or -1 */
+    int32_t gap_absolute_threshold; /* or -1 */
+    float similarity_threshold;    /* or -1 */
+    float conservation_percentage; /* or -1 */
+    int32_t window, gap_window, similarity_window; /* or -1 */
+    float residue_overlap, sequence_overlap;       /* or -1 */
+    int32_t clusters;                              /* or -1 */
+    float max_identity;                            /* or -1 */
+    uint8_t indet;                                 /* 'X' or 'N' */
+    int32_t sort_mode;
+} orc_params;
+
+typedef struct {
+    int32_t selected;  /* automated1: ORC_GAPPYOUT / ORC_STRICT, else 0 */
+    float avg_seq, max_seq;
+    int32_t gap_cut;
+    float sim_cut;
+    int32_t err[3];
+} orc_info;
+
+int orc_trim(const uint8_t *a, int m, int n, int ld, const orc_params *p, const int32_t *vhash,
+             const float *dist, int npos, int32_t *save_res, int32_t *save_seq, orc_info *info) {
+    int rc = ORC_OK;
+    orc_info dummy;
+    if (!info) info = &dummy;
+    memset(info, 0, sizeof(*info));
+    for (int c = 0; c < n; c++) save_res[c] = c;
+    for (int i = 0; i < m; i++) save_seq[i] = i;
+    if (m == 0 || n == 0) return ORC_OK;
+
+    /* set_window_size (manager.pxd:90) */
+    int gw_h = p->gap_window, sw_h = p->similarity_window;
+    if (p->window != -1) gw_h = sw_h = p->window;
+    if (gw_h == -1) gw_h = 0;
+    if (sw_h == -1) sw_h = 0;
+
+    int32_t *gaps = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *gw = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *hist = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m + 2));
+    float *mdk = NULL, *mdkw = NULL, *ident = NULL, *w = NULL;
+    uint32_t *hit = NULL, *dst = NULL;
+    int32_t max_gaps = 0;
+    int have_gaps = 0;
+
+#define NEED_GAPS()                                                                 \
+    do {                                                                            \
+        if (!have_gaps) {                                                           \
+            orc_gaps(a, m, n, ld, gaps, hist, &max_gaps, NULL);                     \
+            rc = orc_gaps_window(gaps, n, gw_h, gw);                                \
+            if (rc) goto done;                                                      \
+            have_gaps = 1;                                                          \
+        }                                                                           \
+    } while (0)
+#define NEED_PAIRS()                                                                \
+    do {                                                                            \
+        if (!hit) {                                                                 \
+            hit = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)m * m);             \
+            dst = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)m * m);             \
+            orc_pair_counts(a, m, n, ld, p->indet, hit, dst);                       \
+        }                                                                           \
+    } while (0)
+#define NEED_IDENT()                                                                \
+    do {                                                                            \
+        NEED_PAIRS();                                                               \
+        if (!ident) {                                                               \
+            ident = (float *)malloc(sizeof(float) * (size_t)m * m);                 \
+            orc_identities(hit, dst, m, ident);                                     \
+        }                                                                           \
+    } while (0)
+#define NEED_SIM()                                                                  \
+    do {                                                                            \
+        NEED_GAPS();                                                                \
+        if (!mdk) {                                                                 \
+            NEED_PAIRS();                                                           \
+            w = (float *)malloc(sizeof(float) * (size_t)m * m);                     \
+            orc_weights(hit, dst, m, w);                                            \
+            mdk = (float *)malloc(sizeof(float) * (size_t)n);                       \
+            mdkw = (float *)malloc(sizeof(float) * (size_t)n);                      \
+            if (sw_h > n / 4) { rc = ORC_E_WINDOW_TOO_BIG; goto done; } /* applyWindow runs first */ \
+            rc = orc_similarity(a, m, n, ld, p->indet, w, gw, vhash, dist, npos, mdk, NULL, info->err); \
+            if (rc) goto done;                                                      \
+            orc_window_f32(mdk, n, sw_h, mdkw);                                     \
+        }                                                                           \
+    } while (0)
+
+    int method = p->method;
+    if (method == 8) { /* removeDuplicates only */
+        orc_remove_duplicates(a, m, n, ld, save_seq);
+        goto finish;
+    }
+    /* --- CleanSequences --- */
+    if (p->clusters != -1) {
+        NEED_IDENT();
+        float thr = orc_cutpoint_clusters(a, m, n, ld, ident, p->clusters, p->sort_mode);
+        orc_representatives(a, m, n, ld, ident, thr, p->sort_mode, save_seq);
+        goto finish;
+    } else if (p->max_identity != -1) {
+        NEED_IDENT();
+        orc_representatives(a, m, n, ld, ident, p->max_identity, p->sort_mode, save_seq);
+        goto finish;
+    } else if (p->residue_overlap != -1 && p->sequence_overlap != -1) {
+        float *ov = (float *)malloc(sizeof(float) * (size_t)m);
+        orc_overlap(a, m, n, ld, p->indet, p->residue_overlap, ov);
+        float min_ov = p->sequence_overlap / 100.0F;
+        for (int i = 0; i < m; i++)
+            if (ov[i] < min_ov) save_seq[i] = -1;
+        free(ov);
+        goto finish;
+    }
+    /* --- CleanResiduesAuto --- */
+    if (method == 6) { /* automated1 */
+        NEED_IDENT();
+        info->selected = orc_select_method(ident, m, &info->avg_seq, &info->max_seq);
+        method = info->selected == ORC_GAPPYOUT ? 3 : 1;
+    }
+    if (method == 7) { rc = ORC_E_NOT_IMPLEMENTED; goto done; } /* automated2: unpinned, unknown */
+    if (method == 3) { /* gappyout = clean2ndSlope */
+        NEED_GAPS();
+        info->gap_cut = orc_gaps_cutpoint_2nd_slope(hist, m, n, max_gaps);
+        orc_clean_overpass(gw, n, info->gap_cut, 0, save_res);
+    } else if (method == 1 || method == 2) { /* cleanCombMethods */
+        NEED_GAPS();
+        info->gap_cut = orc_gaps_cutpoint_2nd_slope(hist, m, n, max_gaps);
+        NEED_SIM();
+        info->sim_cut = orc_comb_simcut(gw, mdkw, n, info->gap_cut);
+        orc_clean_strict(gw, mdkw, n, info->gap_cut, info->sim_cut, method == 2, save_res);
+    } else if (method == 4) { /* nogaps = cleanGaps(0, 0) */
+        NEED_GAPS();
+        orc_clean_overpass(gw, n, orc_gaps_cutpoint(hist, m, n, 0, 0), 0, save_res);
+    } else if (method == 5) { /* noallgaps */
+        NEED_GAPS();
+        orc_clean_overpass(gw, n, m - 1, 0, save_res);
+    } else {
+        /* --- CleanResiduesNonAuto --- */
+        float gap_thr = p->gap_threshold;
+        if (p->gap_absolute_threshold != -1) gap_thr = (float)p->gap_absolute_threshold / m; /* [R] */
+        int has_g = (gap_thr != -1), has_s = (p->similarity_threshold != -1);
+        float base = p->conservation_percentage;
+        if (has_g && has_s) { /* Cleaner::clean */
+            NEED_SIM();
+            double cg = orc_gaps_cutpoint(hist, m, n, base, gap_thr);
+            float cs = (float)orc_sim_cutpoint(mdkw, n, base, p->similarity_threshold);
+            orc_clean_both(gw, mdkw, n, cg, cs, base, save_res);
+        } else if (has_g) { /* cleanGaps */
+            NEED_GAPS();
+            orc_clean_overpass(gw, n, orc_gaps_cutpoint(hist, m, n, base, gap_thr), base, save_res);
+        } else if (has_s) { /* cleanConservation */
+            NEED_SIM();
+            float cs = (float)orc_sim_cutpoint(mdkw, n, base, p->similarity_threshold);
+            orc_clean_fallbehind(mdkw, n, cs, base, save_res);
+        }
+    }
+finish:
+    orc_remove_all_gaps(a, m, n, ld, save_seq, save_res);
+done:
+    free(gaps); free(gw); free(hist); free(mdk); free(mdkw); free(ident); free(w); free(hit); free(dst);
+    return rc;
+}
