@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MSA statistics path (BASELINE.json metric).
+
+One "step" = one whole `AutomaticTrimmer('automated1')` trim of one synthetic 2 000-sequence x
+10 000-column protein MSA (BASELINE.json configs[2], seed 1003 + rank) whose residue bytes are
+already resident in HBM: bit-plane prep, pair counts (identity + weight matrices), selectMethod
+means, gap counts, similarity (order-preserving float32), host selection logic, masks back in
+host memory.  With N > 1 every rank trims its own alignment (alignments are independent: weak
+scaling, no data-path collective) and rank 0 gathers the kept-column masks over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel, HIP-event timed on the context's own stream) and `cpu_baseline` (the oracle, one host
+core, on a bounded column sample of the same alignment).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (m, n, base seed, trimmer method)
+    "C3": (2000, 10000, 1003, "automated1"),
+    "C2": (500, 2000, 1002, "automated1"),
+    "C5": (1000, 4000, 2000, "automated1"),
+}
+
+
+def algorithmic_bytes(kernel, m, n):
+    """every array touched once."""
+    return {
+        "gaps": m * n + 4 * n,
+        "prep": 2 * m * n,
+        "pairs": m * n + 8 * m * m,
+        "sim": m * n + 4 * m * m + 8 * n,
+        "encode": 2 * m * n,
+        "idstats": 4 * m * m,
+    }[kernel]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cols", type=int, default=4000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+
+    from pytrimal_amd import _lib
+    from pytrimal_amd.matrix import SimilarityMatrix
+    from pytrimal_amd.synth import synth_msa
+
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    m, n, seed, method = WORKLOADS[args.workload]
+    a = synth_msa(m, n, seed + rank)
+    ld = (n + 63) // 64 * 64
+    dev = torch.zeros((m, ld), dtype=torch.uint8, device=f"cuda:{local_rank}")
+    dev[:, :n] = torch.from_numpy(a).to(dev.device)
+    torch.cuda.synchronize()
+
+    ctx = _lib.Context(local_rank)
+    matrix = SimilarityMatrix.aa()
+    vhash = np.ascontiguousarray(matrix._vhash, dtype=np.int32)
+    dmat = np.ascontiguousarray(matrix._dist, dtype=np.float32)
+    params = _lib.TrimParams(_lib.METHOD_CODES[method], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0,
+                             vhash.ctypes.data, dmat.ctypes.data, len(matrix))
+    gathered = [torch.empty(n, dtype=torch.uint8, device=dev.device) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        # attach drops every derived buffer: each step recomputes the whole path from the bytes
+        ctx.attach(dev.data_ptr(), m, n, ld, ord("X"))
+        keep_res, keep_seq, info = ctx.trim(params)
+        if dist is not None:
+            mask = torch.from_numpy(keep_res.view(np.uint8)).to(dev.device)
+            dist.gather(mask, gathered, dst=0)
+        return keep_res, keep_seq, info
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep_res, keep_seq, info = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernels = {}
+    for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "overlap"):
+        ms, launches = ctx.prof_get(name)
+        if launches:
+            kernels[name] = {"ms_avg": ms / launches, "launches": launches}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed  # columns/s over the whole job
+        dom = max(kernels, key=lambda k: kernels[k]["ms_avg"] * kernels[k]["launches"]) if kernels else None
+        roofline = None
+        if dom:
+            alg = algorithmic_bytes(dom, m, n)
+            achieved = alg / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(f"{args.workload}:{dom}")
+            roofline = {
+                "kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "algorithmic_bytes": alg, "ms_avg": round(kernels[dom]["ms_avg"], 4),
+                "note": "order-preserving fp32 accumulation: bound by the dependent-add chain, not HBM (DESIGN.md)",
+            }
+        out = {
+            "metric": "MSA columns/s (gap+similarity+identity)",
+            "value": round(value, 2),
+            "unit": "columns/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"AutomaticTrimmer('{method}') on synthetic {m} seq x {n} col protein MSA "
+                            f"({args.workload}, seed {seed}+rank), one alignment per GPU per step",
+                "m": m, "n": n, "selected_method": {1: "gappyout", 2: "strict"}.get(info.selected_method),
+                "avg_seq": round(float(info.avg_seq), 6), "max_seq": round(float(info.max_seq), 6),
+                "kept_columns": int(info.kept_residues), "parallelism": f"replicas x{world} (alignment per rank)",
+            },
+            "roofline": roofline,
+            "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            import oracle
+
+            ncols = min(args.cpu_sample_cols, n)
+            sample = np.ascontiguousarray(a[:, :ncols])
+            t0 = time.perf_counter()
+            ores, oseq, oinfo = oracle.trim(sample, method=method)
+            cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(ncols / cpu_s, 2), "unit": "columns/s", "cores": 1, "kind": "port",
+                "sample": f"all {m} sequences x first {ncols} columns of the same alignment, oracle.trim('{method}') "
+                          f"single thread, {cpu_s:.1f} s (cost per column equals the full workload's)",
+                "seconds": round(cpu_s, 2),
+            }
+            out["speedup_vs_cpu_port"] = round(value / (ncols / cpu_s), 1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

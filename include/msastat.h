@@ -1,0 +1,179 @@
+/*
+ * msastat.h -- C ABI of libmsastat_hip.so, the MI355X (gfx950) implementation of the MSA
+ * statistics hot path behind pytrimal's Trimmer classes.
+ *
+ * There is no C ABI in the reference: the statistics are C++ virtuals of trimAl's
+ * statistics::Manager selected by `ComputePlatform` (reference include/trimal/statistics.pxd:67-96)
+ * and reached from `BaseTrimmer.trim` (reference src/pytrimal/_trimal.pyx:1334-1359).  Each entry
+ * point below names the reference interface it replaces; INTEGRATION.md shows the binding a
+ * pytrimal maintainer would add (a `HIP` ComputePlatform / a Cython `cdef extern` block).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every matrix is row-major and dense;
+ *   - every call returns MSA_OK (0) or a negative error code; msa_strerror() names it;
+ *   - outputs are caller-allocated HOST buffers unless the name ends in `_dev`;
+ *   - a context owns its device buffers and one HIP stream; contexts are independent, so
+ *     `trim` stays re-entrant across threads exactly as in the reference (_trimal.pyx:1305-1316):
+ *     use one context per thread / per call;
+ *   - nothing here touches Python.  Symbol errors are reported as codes + (row, column, byte)
+ *     and turned into ValueError by the host, mirroring reference
+ *     src/trimal/source/reportsystem.cpp:44-53.
+ */
+#ifndef MSASTAT_H
+#define MSASTAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msa_ctx msa_ctx;
+
+enum {
+    MSA_OK = 0,
+    MSA_E_INVALID = -1,          /* bad argument / call order */
+    MSA_E_NO_DEVICE = -2,        /* no gfx950 device visible */
+    MSA_E_HIP = -3,              /* HIP runtime failure (msa_last_hip_error) */
+    MSA_E_NOMEM = -4,
+    MSA_E_WINDOW_TOO_BIG = -5,   /* half-window > n/4  (trimAl ErrorCode::WindowTooBig) */
+    MSA_E_INCORRECT_SYMBOL = -6, /* residue outside A-Z  -> ValueError (reportsystem.cpp:46-49) */
+    MSA_E_UNDEFINED_SYMBOL = -7, /* residue not in the similarity matrix alphabet -> ValueError */
+    MSA_E_NOT_IMPLEMENTED = -8,  /* automated2: no surviving pin in the reference checkout */
+    MSA_E_NON_ASCII = -9         /* byte >= 0x80 in the alignment */
+};
+
+/* first offending residue of MSA_E_INCORRECT_SYMBOL / MSA_E_UNDEFINED_SYMBOL */
+typedef struct {
+    int32_t row, col, byte;
+} msa_err_detail;
+
+const char *msa_strerror(int code);
+int msa_device_count(void);              /* number of visible HIP devices (0 on a CPU-only host) */
+const char *msa_last_hip_error(const msa_ctx *ctx);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int msa_ctx_create(int device, msa_ctx **out);
+void msa_ctx_destroy(msa_ctx *ctx);
+/* the context's hipStream_t, so that a caller can time / order work on it */
+void *msa_ctx_stream(msa_ctx *ctx);
+int msa_ctx_sync(msa_ctx *ctx);
+
+/* ---- alignment upload: replaces the `std::string *sequences` rows of trimAl's Alignment
+ *      (reference include/trimal/alignment.pxd:22) as the statistics' input ------------------ */
+/* m row pointers of n raw residue bytes each; indet = 'X' (protein) or 'N' (nucleotides),
+ * i.e. what Alignment::getAlignmentType selects (_trimal.pyx:759-763,891). */
+int msa_upload_rows(msa_ctx *ctx, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet);
+/* one packed row-major host buffer, leading dimension ld >= n */
+int msa_upload_packed(msa_ctx *ctx, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet);
+/* residue matrix already resident in device memory (not copied, must outlive its use) */
+int msa_attach_device(msa_ctx *ctx, const void *rowmajor_dev, int32_t m, int32_t n, int64_t ld, uint8_t indet);
+
+/* ---- a1  statistics::Gaps::CalculateVectors (statistics.pxd:18-21) via
+ *          Manager::calculateGapStats (statistics.pxd:90) ------------------------------------ */
+/* gaps_out[n]: '-' count per column (gapsInColumn).  indet_out[n] (nullable): count of the
+ * indetermination symbol per column (used by the overlap pass). */
+int msa_gaps(msa_ctx *ctx, int32_t *gaps_out, int32_t *indet_out);
+
+/* ---- a2/a5  pairwise identity counts: Cleaner::calculateSeqIdentity (cleaner.pxd:42) and
+ *             Similarity::calculateMatrixIdentity (statistics.pxd:56) share them -------------- */
+/* hit[m*m], dst[m*m] (either nullable): symmetric, diagonal 0. */
+int msa_pair_counts(msa_ctx *ctx, uint32_t *hit, uint32_t *dst);
+/* ident[m*m] = (float)hit/dst  -> Alignment::identities (alignment.pxd:27);
+ * w[m*m] = 1 - (float)hit/dst  -> Similarity::matrixIdentity (statistics.pxd:49).
+ * Either may be NULL: the matrix then stays on the device for the later passes. */
+int msa_identities(msa_ctx *ctx, float *ident, float *w);
+/* the two means of Cleaner::selectMethod (cleaner.pxd:16), accumulated in the reference's
+ * order on the device; returns them without moving the m*m matrix to the host. */
+int msa_identity_stats(msa_ctx *ctx, float *avg_seq, float *max_seq);
+
+/* ---- a3  statistics::Similarity::calculateVectors (statistics.pxd:55) ----------------------- */
+/* vhash[26]: 'A'..'Z' -> matrix index or -1; dist[npos*npos]: Euclidean distance matrix
+ * (similarity_matrix.pxd:4-7, built as _trimal.pyx:1987-1997); gaps_windowed[n] (nullable):
+ * the vector used for the ">= 80 % gaps -> 0" cut, default = this context's gap counts.
+ * mdk_out[n]: MDK; q_out[n] (nullable): num/den before the exp.  Bit-exact with the reference's
+ * sequential float32 accumulation order. */
+int msa_similarity(msa_ctx *ctx, const int32_t *vhash, const float *dist, int32_t npos,
+                   const int32_t *gaps_windowed, float *mdk_out, float *q_out, msa_err_detail *detail);
+
+/* ---- a6  Cleaner::calculateSpuriousVector (cleaner.pxd:27) --------------------------------- */
+int msa_overlap(msa_ctx *ctx, float residue_overlap, float *spurious_out);
+
+/* ---- a4/a9/a10  host selection logic (trimAl Cleaner / Gaps / Similarity cut points).
+ *      Pure host functions: usable without a device. ------------------------------------------ */
+int msa_window_i32(const int32_t *v, int32_t n, int32_t half_window, int32_t *out);
+int msa_window_f32(const float *v, int32_t n, int32_t half_window, float *out);
+/* Gaps::calcCutPoint / calcCutPoint2ndSlope */
+double msa_gaps_cutpoint(const int32_t *gaps, int32_t m, int32_t n, float base_line, float gap_threshold);
+int32_t msa_gaps_cutpoint_2nd_slope(const int32_t *gaps, int32_t m, int32_t n);
+/* Similarity::calcCutPoint (statistics.pxd:61) */
+double msa_similarity_cutpoint(const float *mdk_windowed, int32_t n, float base_line, float sim_threshold);
+/* Cleaner::cleanByCutValueOverpass / FallBehind / OverpassOrEquals (cleaner.pxd:17-19);
+ * keep[n]: 1 kept, 0 dropped */
+int msa_clean_gaps(const int32_t *gaps_w, int32_t n, double cut, float base_line, uint8_t *keep);
+int msa_clean_similarity(const float *mdk_w, int32_t n, float cut, float base_line, uint8_t *keep);
+int msa_clean_both(const int32_t *gaps_w, const float *mdk_w, int32_t n, double cut_gaps, float cut_sim,
+                   float base_line, uint8_t *keep);
+/* Cleaner::cleanCombMethods + cleanStrict (cleaner.pxd:20,30); variable = strictplus.
+ * gaps[n] feeds the 2nd-slope histogram, gaps_w[n] / mdk_w[n] are the windowed vectors. */
+int msa_clean_strict(const int32_t *gaps, const int32_t *gaps_w, const float *mdk_w, int32_t m, int32_t n,
+                     int32_t variable, uint8_t *keep, int32_t *gap_cut_out, float *sim_cut_out);
+/* Cleaner::selectMethod decision from the two means: 1 = gappyout, 2 = strict */
+int32_t msa_select_method(float avg_seq, float max_seq, int32_t m);
+/* Cleaner::calculateRepresentativeSeq / getCutPointClusters (cleaner.pxd:35,44);
+ * lengths[m] = ungapped sequence lengths; keep_seq[m] */
+int msa_representatives(const float *ident, const int32_t *lengths, int32_t m, float max_identity,
+                        uint8_t *keep_seq, int32_t *n_clusters);
+float msa_cutpoint_clusters(const float *ident, const int32_t *lengths, int32_t m, int32_t clusters);
+
+/* ---- whole trim: trimAlManager::clean_alignment (manager.pxd:88) as configured by the four
+ *      `_configure_manager` methods (_trimal.pyx:1479-1497,1651-1659,1766-1769,1859-1862) ------ */
+enum {
+    MSA_METHOD_NONE = 0, MSA_METHOD_STRICT = 1, MSA_METHOD_STRICTPLUS = 2, MSA_METHOD_GAPPYOUT = 3,
+    MSA_METHOD_NOGAPS = 4, MSA_METHOD_NOALLGAPS = 5, MSA_METHOD_AUTOMATED1 = 6,
+    MSA_METHOD_AUTOMATED2 = 7, MSA_METHOD_NODUPLICATESEQS = 8
+};
+
+typedef struct {
+    int32_t method;                  /* MSA_METHOD_* (AutomaticTrimmer) */
+    float gap_threshold;             /* trimAlManager::gapThreshold = 1 - kwarg, or -1 */
+    int32_t gap_absolute_threshold;  /* or -1 */
+    float similarity_threshold;      /* or -1 */
+    float conservation_percentage;   /* trimAlManager::conservationThreshold, or -1 */
+    int32_t window, gap_window, similarity_window; /* or -1 */
+    float residue_overlap, sequence_overlap;       /* OverlapTrimmer, or -1 */
+    int32_t clusters;                /* RepresentativeTrimmer, or -1 */
+    float max_identity;              /* RepresentativeTrimmer, or -1 */
+    /* similarity matrix (Manager::setSimilarityMatrix, statistics.pxd:89) */
+    const int32_t *vhash;            /* [26] */
+    const float *dist;               /* [npos*npos] */
+    int32_t npos;
+} msa_trim_params;
+
+typedef struct {
+    int32_t selected_method;  /* automated1: 1 gappyout / 2 strict; else 0 */
+    float avg_seq, max_seq;   /* selectMethod means (automated1) */
+    int32_t gap_cut;          /* calcCutPoint2ndSlope (gappyout/strict/strictplus) */
+    float sim_cut;            /* cleanCombMethods */
+    int32_t kept_residues, kept_sequences;
+    msa_err_detail err;
+    float ms_device;          /* device time of the statistics kernels of this call (HIP events) */
+} msa_trim_info;
+
+/* keep_res[n], keep_seq[m]: the saveResidues / saveSequences masks (alignment.pxd:29-30) as
+ * 0/1 bytes, i.e. TrimmedAlignment.residues_mask / sequences_mask (_trimal.pyx:1085-1121). */
+int msa_trim(msa_ctx *ctx, const msa_trim_params *params, uint8_t *keep_res, uint8_t *keep_seq,
+             msa_trim_info *info);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+/* device time (ms, HIP events on the context stream) and launch count of the named kernel
+ * family since the last msa_prof_reset: "gaps", "prep", "pairs", "idstats", "encode", "sim",
+ * "overlap".  Returns MSA_E_INVALID for an unknown name. */
+int msa_prof_get(msa_ctx *ctx, const char *kernel, float *ms_total, int32_t *launches);
+void msa_prof_reset(msa_ctx *ctx);
+void msa_prof_enable(msa_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSASTAT_H */

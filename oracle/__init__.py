@@ -64,16 +64,17 @@ NT_MATRIX = np.array([
 
 
 def _deg_matrix():
-    """trimAl defaultNTDegeneratedSimMatrix [R]: overlap of the IUPAC base sets, normalised by
-    the larger set (pinned only by nt(True).distance('A','T') ~ 1.5184, _trimal.pyx:2042-2046)."""
-    sets = {"A": "A", "C": "C", "G": "G", "T": "T", "U": "T", "R": "AG", "Y": "CT", "K": "GT",
+    """trimAl defaultNTDegeneratedSimMatrix [R; values not in the reference tree]: identity on the
+    diagonal, otherwise IUPAC base-set overlap / (|x| * |y|) / 2.  This is the reading that
+    reproduces the one pin, nt(True).distance('A','T') ~ 1.5184 (_trimal.pyx:2042-2046)."""
+    sets = {"A": "A", "C": "C", "G": "G", "T": "T", "U": "U", "R": "AG", "Y": "CT", "K": "GT",
             "M": "AC", "S": "CG", "W": "AT", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG"}
     k = len(NT_DEG_ALPHABET)
     out = np.zeros((k, k), dtype=np.float32)
     for i, x in enumerate(NT_DEG_ALPHABET):
         for j, y in enumerate(NT_DEG_ALPHABET):
             sx, sy = set(sets[x]), set(sets[y])
-            out[i, j] = np.float32(len(sx & sy)) / np.float32(len(sx) * len(sy))
+            out[i, j] = 1.0 if x == y else len(sx & sy) / float(len(sx) * len(sy)) / 2.0
     return out
 
 

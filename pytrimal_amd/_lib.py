@@ -1,0 +1,306 @@
+"""ctypes binding of ``libmsastat_hip.so`` (C ABI: ``include/msastat.h``).
+
+This is the only way the package computes anything: there is no CPU fallback.  If the shared
+library is missing or no MI355X device is visible, the trimmers fail loudly with `RuntimeError`
+(the reference does the same for a SIMD platform that is not available,
+``/root/reference/src/pytrimal/_trimal.pyx:1205-1218``).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsastat_hip.so")
+
+OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_WINDOW_TOO_BIG = -1, -2, -3, -4, -5
+E_INCORRECT_SYMBOL, E_UNDEFINED_SYMBOL, E_NOT_IMPLEMENTED, E_NON_ASCII = -6, -7, -8, -9
+
+METHOD_CODES = {
+    None: 0, "strict": 1, "strictplus": 2, "gappyout": 3, "nogaps": 4, "noallgaps": 5,
+    "automated1": 6, "automated2": 7, "noduplicateseqs": 8,
+}
+
+# every symbol include/msastat.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "msa_strerror", "msa_device_count", "msa_last_hip_error", "msa_ctx_create", "msa_ctx_destroy",
+    "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_attach_device",
+    "msa_gaps", "msa_pair_counts", "msa_identities", "msa_identity_stats", "msa_similarity",
+    "msa_overlap", "msa_window_i32", "msa_window_f32", "msa_gaps_cutpoint",
+    "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
+    "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
+    "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_prof_get", "msa_prof_reset",
+    "msa_prof_enable",
+]
+
+
+class ErrDetail(ctypes.Structure):
+    _fields_ = [("row", ctypes.c_int32), ("col", ctypes.c_int32), ("byte", ctypes.c_int32)]
+
+
+class TrimParams(ctypes.Structure):
+    _fields_ = [
+        ("method", ctypes.c_int32),
+        ("gap_threshold", ctypes.c_float),
+        ("gap_absolute_threshold", ctypes.c_int32),
+        ("similarity_threshold", ctypes.c_float),
+        ("conservation_percentage", ctypes.c_float),
+        ("window", ctypes.c_int32),
+        ("gap_window", ctypes.c_int32),
+        ("similarity_window", ctypes.c_int32),
+        ("residue_overlap", ctypes.c_float),
+        ("sequence_overlap", ctypes.c_float),
+        ("clusters", ctypes.c_int32),
+        ("max_identity", ctypes.c_float),
+        ("vhash", ctypes.c_void_p),
+        ("dist", ctypes.c_void_p),
+        ("npos", ctypes.c_int32),
+    ]
+
+
+class TrimInfo(ctypes.Structure):
+    _fields_ = [
+        ("selected_method", ctypes.c_int32),
+        ("avg_seq", ctypes.c_float),
+        ("max_seq", ctypes.c_float),
+        ("gap_cut", ctypes.c_int32),
+        ("sim_cut", ctypes.c_float),
+        ("kept_residues", ctypes.c_int32),
+        ("kept_sequences", ctypes.c_int32),
+        ("err", ErrDetail),
+        ("ms_device", ctypes.c_float),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the HIP library, or raise `RuntimeError` (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pytrimal_amd/csrc` (hipcc --offload-arch=gfx950)"
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, f32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
+        L.msa_strerror.restype = ctypes.c_char_p
+        L.msa_strerror.argtypes = [ctypes.c_int]
+        L.msa_device_count.restype = ctypes.c_int
+        L.msa_last_hip_error.restype = ctypes.c_char_p
+        L.msa_last_hip_error.argtypes = [vp]
+        L.msa_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.msa_ctx_destroy.argtypes = [vp]
+        L.msa_ctx_destroy.restype = None
+        L.msa_ctx_stream.argtypes = [vp]
+        L.msa_ctx_stream.restype = vp
+        L.msa_ctx_sync.argtypes = [vp]
+        L.msa_upload_rows.argtypes = [vp, vp, i32, i32, ctypes.c_uint8]
+        L.msa_upload_packed.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
+        L.msa_attach_device.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
+        L.msa_gaps.argtypes = [vp, vp, vp]
+        L.msa_pair_counts.argtypes = [vp, vp, vp]
+        L.msa_identities.argtypes = [vp, vp, vp]
+        L.msa_identity_stats.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]
+        L.msa_similarity.argtypes = [vp, vp, vp, i32, vp, vp, vp, ctypes.POINTER(ErrDetail)]
+        L.msa_overlap.argtypes = [vp, f32, vp]
+        L.msa_window_i32.argtypes = [vp, i32, i32, vp]
+        L.msa_window_f32.argtypes = [vp, i32, i32, vp]
+        L.msa_gaps_cutpoint.argtypes = [vp, i32, i32, f32, f32]
+        L.msa_gaps_cutpoint.restype = f64
+        L.msa_gaps_cutpoint_2nd_slope.argtypes = [vp, i32, i32]
+        L.msa_gaps_cutpoint_2nd_slope.restype = i32
+        L.msa_similarity_cutpoint.argtypes = [vp, i32, f32, f32]
+        L.msa_similarity_cutpoint.restype = f64
+        L.msa_clean_gaps.argtypes = [vp, i32, f64, f32, vp]
+        L.msa_clean_similarity.argtypes = [vp, i32, f32, f32, vp]
+        L.msa_clean_both.argtypes = [vp, vp, i32, f64, f32, f32, vp]
+        L.msa_clean_strict.argtypes = [vp, vp, vp, i32, i32, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(f32)]
+        L.msa_select_method.argtypes = [f32, f32, i32]
+        L.msa_select_method.restype = i32
+        L.msa_representatives.argtypes = [vp, vp, i32, f32, vp, ctypes.POINTER(i32)]
+        L.msa_cutpoint_clusters.argtypes = [vp, vp, i32, i32]
+        L.msa_cutpoint_clusters.restype = f32
+        L.msa_trim.argtypes = [vp, ctypes.POINTER(TrimParams), vp, vp, ctypes.POINTER(TrimInfo)]
+        L.msa_prof_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(f32), ctypes.POINTER(i32)]
+        L.msa_prof_reset.argtypes = [vp]
+        L.msa_prof_reset.restype = None
+        L.msa_prof_enable.argtypes = [vp, ctypes.c_int]
+        L.msa_prof_enable.restype = None
+        _lib = L
+        return L
+
+
+def device_count():
+    """Number of visible HIP devices; 0 when the library is missing or the host has no GPU."""
+    try:
+        return int(load().msa_device_count())
+    except (RuntimeError, OSError):
+        return 0
+
+
+def ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
+
+
+class MsaError(RuntimeError):
+    def __init__(self, code, message, detail=None):
+        super().__init__(message)
+        self.code, self.detail = code, detail
+
+
+def check(lib, ctx, rc, detail=None):
+    """Turn a C-ABI return code into the exception type the reference raises for it
+    (``/root/reference/src/trimal/source/reportsystem.cpp:44-53``)."""
+    if rc == OK:
+        return
+    msg = lib.msa_strerror(rc).decode()
+    if rc in (E_INCORRECT_SYMBOL, E_UNDEFINED_SYMBOL):
+        ch = chr(detail.byte) if detail is not None else "?"
+        if rc == E_INCORRECT_SYMBOL:
+            raise ValueError(f"the symbol {ch!r} is incorrect")
+        raise ValueError(f"the symbol {ch!r} accesing the matrix is not defined in this object")
+    if rc == E_HIP and ctx:
+        msg += ": " + lib.msa_last_hip_error(ctx).decode()
+    if rc == E_NON_ASCII:
+        raise ValueError(msg)
+    raise MsaError(rc, msg, detail)
+
+
+class Context:
+    """One `msa_ctx`: device buffers + a HIP stream.  Not shared between threads."""
+
+    def __init__(self, device=None):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("PYTRIMAL_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = self.lib.msa_device_count()
+            if n > 0:
+                device %= n
+        h = ctypes.c_void_p()
+        rc = self.lib.msa_ctx_create(int(device), ctypes.byref(h))
+        if rc != OK:
+            raise RuntimeError(
+                f"cannot create a HIP context on device {device}: {self.lib.msa_strerror(rc).decode()} "
+                "(platform='hip' needs a visible gfx950 device; there is no CPU fallback)"
+            )
+        self.h = h
+        self.device = int(device)
+        self.shape = (0, 0)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.msa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- uploads ---
+    def upload(self, matrix, indet):
+        a = np.ascontiguousarray(matrix, dtype=np.uint8)
+        m, n = a.shape
+        check(self.lib, self.h, self.lib.msa_upload_packed(self.h, ptr(a), m, n, n, indet))
+        self.shape = (m, n)
+
+    def attach(self, dev_ptr, m, n, ld, indet):
+        check(self.lib, self.h, self.lib.msa_attach_device(self.h, ctypes.c_void_p(dev_ptr), m, n, ld, indet))
+        self.shape = (m, n)
+
+    # --- statistics ---
+    def gaps(self, with_indet=False):
+        m, n = self.shape
+        g = np.zeros(n, dtype=np.int32)
+        x = np.zeros(n, dtype=np.int32) if with_indet else None
+        check(self.lib, self.h, self.lib.msa_gaps(self.h, ptr(g), ptr(x)))
+        return (g, x) if with_indet else g
+
+    def pair_counts(self):
+        m, _ = self.shape
+        hit = np.zeros((m, m), dtype=np.uint32)
+        dst = np.zeros((m, m), dtype=np.uint32)
+        check(self.lib, self.h, self.lib.msa_pair_counts(self.h, ptr(hit), ptr(dst)))
+        return hit, dst
+
+    def identities(self, want_ident=True, want_w=True):
+        m, _ = self.shape
+        ident = np.zeros((m, m), dtype=np.float32) if want_ident else None
+        w = np.zeros((m, m), dtype=np.float32) if want_w else None
+        check(self.lib, self.h, self.lib.msa_identities(self.h, ptr(ident), ptr(w)))
+        return ident, w
+
+    def identity_stats(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        check(self.lib, self.h, self.lib.msa_identity_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return np.float32(a.value), np.float32(b.value)
+
+    def similarity(self, vhash, dist, gaps_windowed=None):
+        _, n = self.shape
+        vhash = np.ascontiguousarray(vhash, dtype=np.int32)
+        dist = np.ascontiguousarray(dist, dtype=np.float32)
+        gw = None if gaps_windowed is None else np.ascontiguousarray(gaps_windowed, dtype=np.int32)
+        mdk = np.zeros(n, dtype=np.float32)
+        q = np.zeros(n, dtype=np.float32)
+        det = ErrDetail()
+        rc = self.lib.msa_similarity(self.h, ptr(vhash), ptr(dist), dist.shape[0], ptr(gw), ptr(mdk), ptr(q),
+                                     ctypes.byref(det))
+        check(self.lib, self.h, rc, det)
+        return mdk, q
+
+    def overlap(self, residue_overlap):
+        m, _ = self.shape
+        out = np.zeros(m, dtype=np.float32)
+        check(self.lib, self.h, self.lib.msa_overlap(self.h, residue_overlap, ptr(out)))
+        return out
+
+    def trim(self, params):
+        m, n = self.shape
+        keep_res = np.ones(n, dtype=np.uint8)
+        keep_seq = np.ones(m, dtype=np.uint8)
+        info = TrimInfo()
+        rc = self.lib.msa_trim(self.h, ctypes.byref(params), ptr(keep_res), ptr(keep_seq), ctypes.byref(info))
+        check(self.lib, self.h, rc, info.err)
+        return keep_res.astype(bool), keep_seq.astype(bool), info
+
+    # --- instrumentation ---
+    def prof_enable(self, on=True):
+        self.lib.msa_prof_enable(self.h, 1 if on else 0)
+
+    def prof_reset(self):
+        self.lib.msa_prof_reset(self.h)
+
+    def prof_get(self, name):
+        ms, k = ctypes.c_float(0), ctypes.c_int32(0)
+        check(self.lib, self.h, self.lib.msa_prof_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(k)))
+        return ms.value, k.value
+
+    def sync(self):
+        check(self.lib, self.h, self.lib.msa_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.msa_ctx_stream(self.h)
+
+
+_tls = threading.local()
+
+
+def thread_context():
+    """A per-thread context, so that `trim` is re-entrant across threads like the reference
+    (``_trimal.pyx:1305-1316``)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or ctx.h is None:
+        ctx = _tls.ctx = Context()
+    return ctx

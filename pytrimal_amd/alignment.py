@@ -1,0 +1,384 @@
+"""`Alignment` / `TrimmedAlignment`: the host-side containers of the trim path.
+
+API-compatible with ``pytrimal.Alignment`` and ``pytrimal.TrimmedAlignment``
+(``/root/reference/src/pytrimal/_trimal.pyx:416-1165``): same constructors, properties, views,
+error messages and mask semantics.  Residues are held as one packed ``uint8[m, n]`` matrix -- the
+layout the device upload wants -- instead of the reference's per-row ``std::string`` array
+(``include/trimal/alignment.pxd:22``).  Only the FASTA and Clustal formats are read/written here:
+trimAl's ten-format `FormatHandling` layer is I/O, not statistics.
+"""
+import io
+import os
+
+import numpy as np
+
+_GAP = ord("-")
+# characters trimAl's Alignment::fillMatrices accepts besides letters
+_EXTRA_VALID = frozenset(b"-.?*")
+
+SEQUENCE_TYPES = {"protein": 4, "dna": 1, "rna": 2}  # SequenceTypes bits: DNA 1, RNA 2, AA 4, DEG 8
+
+
+def _is_valid_table():
+    t = np.zeros(256, dtype=bool)
+    for c in range(256):
+        ch = bytes([c])
+        t[c] = ch.isalpha() or c in _EXTRA_VALID
+    return t
+
+
+_VALID = _is_valid_table()
+
+
+def detect_alignment_type(matrix):
+    """trimAl ``utils::checkAlignmentType`` (behind ``Alignment::getAlignmentType``,
+    ``_trimal.pyx:891``): look at the first 100 non-gap letters of every sequence; an alignment
+    is amino-acid as soon as one sequence has < 70 % nucleotide letters."""
+    upper = np.where((matrix >= 97) & (matrix <= 122), matrix - 32, matrix)
+    dna = np.isin(upper, np.frombuffer(b"AGCTN", dtype=np.uint8))
+    rna = np.isin(upper, np.frombuffer(b"AGCUN", dtype=np.uint8))
+    deg = np.isin(upper, np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8))
+    letter = ~np.isin(matrix, np.frombuffer(b"-.?", dtype=np.uint8))
+    rank = np.cumsum(letter, axis=1)
+    first100 = letter & (rank <= 100)
+    g_dna = g_rna = ext_dna = ext_rna = 0
+    for i in range(matrix.shape[0]):
+        sel = first100[i]
+        k = int(sel.sum())
+        if k == 0:
+            continue
+        hd, hr, dg = int(dna[i][sel].sum()), int(rna[i][sel].sum()), int(deg[i][sel].sum())
+        if (np.float32(hd + dg) / np.float32(k)) < 0.7 and (np.float32(hr + dg) / np.float32(k)) < 0.7:
+            return 4
+        if hr > hd and dg == 0:
+            g_rna += 1
+        elif hr < hd and dg == 0:
+            g_dna += 1
+        elif hr > hd and dg != 0:
+            ext_rna += 1
+        elif hr < hd and dg != 0:
+            ext_dna += 1
+    if ext_dna != 0 and ext_dna > ext_rna:
+        return 1 | 8
+    if ext_rna != 0 and ext_dna < ext_rna:
+        return 2 | 8
+    if g_rna > g_dna:
+        return 2
+    return 1
+
+
+class _View:
+    """Read-only view with zero-copy slicing (``AlignmentSequences`` / ``AlignmentResidues``)."""
+
+    def __init__(self, owner, indices):
+        self._owner = owner
+        self._indices = indices
+
+    def __len__(self):
+        return len(self._indices)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return type(self)(self._owner, self._indices[index])
+        i = int(index)
+        if i < 0:
+            i += len(self._indices)
+        if i < 0 or i >= len(self._indices):
+            raise IndexError(index)
+        return self._get(int(self._indices[i]))
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+
+class AlignmentSequences(_View):
+    """A read-only view over the sequences of an alignment."""
+
+    def _get(self, row):
+        o = self._owner
+        return o._matrix[row, o._res_idx].tobytes().decode("ascii")
+
+
+class AlignmentResidues(_View):
+    """A read-only view over the residues (columns) of an alignment."""
+
+    def _get(self, col):
+        o = self._owner
+        return o._matrix[o._seq_idx, col].tobytes().decode("ascii")
+
+
+class Alignment:
+    """A multiple sequence alignment."""
+
+    def __init__(self, names, sequences, sequence_type=None):
+        if names is None or sequences is None:
+            raise TypeError("`names` and `sequences` must not be None")
+        if len(names) != len(sequences):
+            raise ValueError(f"`Alignment` given {len(names)!r} names but {len(sequences)!r} sequences")
+        if sequence_type is not None and sequence_type not in SEQUENCE_TYPES:
+            raise ValueError(
+                f"invalid `sequence_type`: {sequence_type!r} (expected one of 'protein', 'rna', 'dna' or None)")
+        validate = not isinstance(sequences, AlignmentSequences)
+        rows, nres = [], 0
+        self._names = []
+        for i, (name, seq) in enumerate(zip(names, sequences)):
+            if not isinstance(name, (bytes, bytearray)):
+                raise TypeError(f"expected bytes, found {type(name).__name__}")
+            raw = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)
+            if not nres:
+                nres = len(raw)
+            if len(raw) != nres:
+                raise ValueError(f"Sequence length mismatch in sequence {i}: {len(raw)} != {nres}")
+            self._names.append(bytes(name))
+            rows.append(raw)
+        m = len(rows)
+        if m == 0:
+            nres = 0
+        self._matrix = (np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(m, nres).copy()
+                        if m and nres else np.zeros((m, nres), dtype=np.uint8))
+        if validate and nres:
+            bad = ~_VALID[self._matrix]
+            if bad.any():
+                r, c = np.argwhere(bad)[0]
+                raise ValueError(
+                    f"The sequence \"{self._names[r].decode('ascii', 'replace')}\" has an unknown "
+                    f"({int(self._matrix[r, c])}) character")
+        self._datatype = SEQUENCE_TYPES.get(sequence_type, 0)
+        self._seq_mask = np.ones(m, dtype=bool)
+        self._res_mask = np.ones(nres, dtype=bool)
+        self._reindex()
+
+    # --- internals ------------------------------------------------------------
+
+    @classmethod
+    def _from_parts(cls, names, matrix, datatype=0, seq_mask=None, res_mask=None):
+        self = cls.__new__(cls)
+        self._names = list(names)
+        self._matrix = matrix
+        self._datatype = datatype
+        m, n = matrix.shape
+        self._seq_mask = np.ones(m, dtype=bool) if seq_mask is None else np.asarray(seq_mask, dtype=bool).copy()
+        self._res_mask = np.ones(n, dtype=bool) if res_mask is None else np.asarray(res_mask, dtype=bool).copy()
+        self._reindex()
+        return self
+
+    def _reindex(self):
+        self._seq_idx = np.flatnonzero(self._seq_mask)
+        self._res_idx = np.flatnonzero(self._res_mask)
+
+    def _dense(self):
+        """The visible (kept) residues as a C-contiguous uint8 matrix."""
+        if self._seq_mask.all() and self._res_mask.all():
+            return self._matrix
+        return np.ascontiguousarray(self._matrix[np.ix_(self._seq_idx, self._res_idx)])
+
+    def _alignment_type(self):
+        if self._datatype:
+            return self._datatype
+        dense = self._dense()
+        if dense.size == 0:
+            return 0
+        return detect_alignment_type(dense)
+
+    # --- parser / loader --------------------------------------------------------
+
+    @classmethod
+    def load(cls, file, format=None):
+        """Load a multiple sequence alignment from a path or a binary file-like object."""
+        if file is None:
+            raise TypeError("`file` must not be None")
+        if isinstance(file, (str, bytes, os.PathLike)):
+            path = os.fspath(file)
+            if os.path.isdir(path):
+                raise IsADirectoryError(file)
+            with open(path, "rb") as f:
+                data = f.read()
+            fmt = format
+        else:
+            ty = type(file).__name__
+            if not hasattr(file, "seek") or not file.seekable():
+                raise TypeError(f"{ty!r} object is not seekable.")
+            if not hasattr(file, "readinto") and not hasattr(file, "read"):
+                raise TypeError(f"{ty!r} object has no attribute 'read'.")
+            if format is None:
+                raise ValueError("Format must be specified when loading from a file-like object")
+            data = file.read()
+            if isinstance(data, str):
+                raise TypeError(f"{ty!r} object is not open in binary mode.")
+            fmt = format
+        if fmt is None:
+            head = data.lstrip()[:7].upper()
+            fmt = "clustal" if head.startswith(b"CLUSTAL") else "fasta"
+        fmt = fmt.lower()
+        if fmt == "fasta":
+            names, seqs = _parse_fasta(data)
+        elif fmt == "clustal":
+            names, seqs = _parse_clustal(data)
+        else:
+            raise ValueError(f"Unknown alignment format: {format!r}")
+        if not names:
+            raise RuntimeError(f"Failed to load alignment from {file!r}.")
+        out = cls.__new__(cls)
+        Alignment.__init__(out, names, seqs)
+        return out
+
+    def dump(self, file, format="fasta"):
+        """Dump the alignment to a path or a binary file-like object."""
+        text = self.dumps(format).encode("ascii")
+        if isinstance(file, (str, bytes, os.PathLike)):
+            with open(os.fspath(file), "wb") as f:
+                f.write(text)
+        else:
+            file.write(text)
+
+    def dumps(self, format="fasta", encoding="utf-8"):
+        fmt = format.lower()
+        names = [n.decode(encoding) for n in self.names]
+        seqs = list(self.sequences)
+        out = io.StringIO()
+        if fmt == "fasta":
+            for name, seq in zip(names, seqs):
+                out.write(f">{name}\n")
+                for k in range(0, len(seq), 60):
+                    out.write(seq[k:k + 60] + "\n")
+        elif fmt == "clustal":
+            out.write("CLUSTAL multiple sequence alignment\n\n")
+            width = max((len(x) for x in names), default=0) + 6
+            n = len(seqs[0]) if seqs else 0
+            for k in range(0, n, 60):
+                for name, seq in zip(names, seqs):
+                    out.write(name.ljust(width) + seq[k:k + 60] + "\n")
+                out.write("\n\n")
+        else:
+            raise ValueError(f"Could not recognize alignment format: {format!r}")
+        return out.getvalue()
+
+    # --- magic ------------------------------------------------------------------
+
+    def __repr__(self):
+        return f"{type(self).__name__}(names={self.names!r}, sequences={list(self.sequences)!r})"
+
+    def __copy__(self):
+        return self.copy()
+
+    def __len__(self):
+        return len(self._seq_idx)
+
+    # --- properties -------------------------------------------------------------
+
+    @property
+    def sequence_type(self):
+        ty = self._alignment_type()
+        if ty & 1:
+            return "dna"
+        if ty & 2:
+            return "rna"
+        if ty & 4:
+            return "protein"
+        return None
+
+    @property
+    def names(self):
+        return [self._names[i] for i in self._seq_idx]
+
+    @property
+    def sequences(self):
+        return AlignmentSequences(self, self._seq_idx)
+
+    @property
+    def residues(self):
+        return AlignmentResidues(self, self._res_idx)
+
+    def copy(self):
+        return type(self)._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask,
+                                      self._res_mask)
+
+
+class TrimmedAlignment(Alignment):
+    """A multiple sequence alignment that has been trimmed (masks over the original)."""
+
+    @classmethod
+    def load(cls, file, format=None):
+        ali = Alignment.load(file, format)
+        return cls._from_parts(ali._names, ali._matrix, ali._datatype)
+
+    def __init__(self, names, sequences, sequences_mask=None, residues_mask=None):
+        super().__init__(names, sequences)
+        m, n = self._matrix.shape
+        if sequences_mask is not None:
+            if len(sequences_mask) != m:
+                raise ValueError("Sequences mask must have the same length as the sequences list")
+            self._seq_mask = np.array([bool(x) for x in sequences_mask], dtype=bool)
+        if residues_mask is not None:
+            if len(residues_mask) != n:
+                raise ValueError("Sequences mask must have the same length as the sequences list")
+            self._res_mask = np.array([bool(x) for x in residues_mask], dtype=bool)
+        self._reindex()
+
+    @property
+    def residues_mask(self):
+        """sequence of `bool`: Which residues are kept in the alignment."""
+        return [bool(x) for x in self._res_mask]
+
+    @property
+    def sequences_mask(self):
+        """sequence of `bool`: Which sequences are kept in the alignment."""
+        return [bool(x) for x in self._seq_mask]
+
+    def original_alignment(self):
+        """Rebuild the original alignment from which this object was obtained."""
+        return Alignment._from_parts(self._names, self._matrix.copy(), self._datatype)
+
+    def terminal_only(self):
+        """Get a trimmed alignment where only the terminal residues are removed
+        (``Cleaner::removeOnlyTerminal``, ``_trimal.pyx:1144-1157``): every column between the
+        first and the last kept column is restored."""
+        res = self._res_mask.copy()
+        kept = np.flatnonzero(res)
+        if kept.size:
+            res[kept[0]:kept[-1] + 1] = True
+        return TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, res)
+
+    def copy(self):
+        return TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask,
+                                            self._res_mask)
+
+
+# --- minimal readers --------------------------------------------------------------------------
+
+def _parse_fasta(data):
+    names, seqs = [], []
+    for line in data.splitlines():
+        line = line.strip()
+        if not line:
+            continue
+        if line.startswith(b">"):
+            fields = line[1:].split()
+            names.append(fields[0] if fields else b"")
+            seqs.append([])
+        elif names:
+            seqs[-1].append(line.replace(b" ", b""))
+    return names, [b"".join(s) for s in seqs]
+
+
+def _parse_clustal(data):
+    names, seqs = [], {}
+    lines = data.splitlines()
+    for line in lines[1:]:
+        if not line.strip() or line[:1] in (b" ", b"\t"):
+            continue
+        parts = line.split()
+        if len(parts) < 2:
+            continue
+        if parts[0] not in seqs:
+            names.append(parts[0])
+            seqs[parts[0]] = []
+        seqs[parts[0]].append(parts[1])
+    return names, [b"".join(seqs[k]) for k in names]

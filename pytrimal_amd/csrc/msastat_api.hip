@@ -1,0 +1,815 @@
+// msastat_api.hip -- the C-ABI shim of include/msastat.h: context, uploads, one entry point per
+// statistic, and msa_trim (the trimAlManager::clean_alignment equivalent that keeps the
+// alignment and the m*m matrices on the device and moves only O(m + n) vectors to the host).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "msastat.h"
+#include "msastat_host.h"
+#include "msastat_kernels.h"
+
+namespace {
+
+template <typename T>
+struct DevBuf {  // grow-only device allocation, reused across uploads
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t count) {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) cap = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {  // pinned host staging
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t count) {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ProfEntry {
+    double ms = 0;
+    int launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+}  // namespace
+
+struct msa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char hip_err[256] = {0};
+
+    // alignment
+    int m = 0, n = 0;
+    int64_t ld = 0;
+    uint8_t indet = 'X';
+    const uint8_t *raw = nullptr;  // device
+    DevBuf<uint8_t> raw_own;
+
+    // derived device data + validity flags
+    int nchunk = 0, m_pad = 0, ldw = 0;
+    DevBuf<uint32_t> planes;
+    bool have_planes = false;
+    DevBuf<int32_t> gaps, indets;
+    bool have_gaps = false;
+    DevBuf<float> ident, wmat;
+    bool have_ident = false, have_w = false;
+    DevBuf<uint32_t> hit, dst;
+    DevBuf<float> row_avg, row_max, stats2;
+    DevBuf<uint32_t> codes4;
+    DevBuf<uint8_t> lut;
+    DevBuf<float> tab;
+    DevBuf<int32_t> gaps_w;
+    DevBuf<float> q, mdk;
+    DevBuf<unsigned long long> errkey;
+    DevBuf<int> errflag;
+    DevBuf<uint32_t> col_ok;
+    DevBuf<int32_t> good, row_cnt, col_cnt, lengths, pairs, equal;
+    DevBuf<uint8_t> keep_res_d, keep_seq_d;
+    DevBuf<unsigned long long> hashes;
+
+    // pinned staging
+    PinBuf<int32_t> h_i32;
+    PinBuf<float> h_f32;
+    PinBuf<unsigned long long> h_u64;
+    PinBuf<uint8_t> h_u8;
+
+    // host copies valid for the current alignment
+    std::vector<int32_t> h_gaps, h_indets;
+
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
+    std::snprintf(c->hip_err, sizeof(c->hip_err), "%s: %s", what, hipGetErrorString(e));
+    return MSA_E_HIP;
+}
+#define HIPCHK(ctx, expr)                                    \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
+    } while (0)
+
+struct ProfScope {  // records an event pair around a launch sequence when profiling is on
+    msa_ctx *c;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(msa_ctx *ctx, const char *nm) : c(ctx), name(nm) {
+        if (!c->prof_on) return;
+        a = take();
+        b = take();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!c->prof_on) return;
+        (void)hipEventRecord(b, c->stream);
+        ProfEntry &e = c->prof[name];
+        e.pending.emplace_back(a, b);
+        e.launches++;
+    }
+    hipEvent_t take() {
+        if (!c->event_pool.empty()) {
+            hipEvent_t ev = c->event_pool.back();
+            c->event_pool.pop_back();
+            return ev;
+        }
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        return ev;
+    }
+};
+
+void prof_collect(msa_ctx *c) {
+    for (auto &kv : c->prof) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+                kv.second.ms += ms;
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+void invalidate(msa_ctx *c) {
+    c->have_planes = c->have_gaps = c->have_ident = c->have_w = false;
+    c->h_gaps.clear();
+    c->h_indets.clear();
+}
+
+int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
+    if (m < 0 || n < 0) return MSA_E_INVALID;
+    c->m = m;
+    c->n = n;
+    c->indet = indet;
+    c->nchunk = (n + 31) / 32;
+    c->m_pad = round_up(std::max(m, 1), 64 * msak::PAIR_TJ);
+    c->ldw = round_up(std::max(m, 1), 64);
+    invalidate(c);
+    return MSA_OK;
+}
+
+int ensure_planes(msa_ctx *c) {
+    if (c->have_planes) return MSA_OK;
+    HIPCHK(c, c->planes.reserve((size_t)8 * c->nchunk * c->m_pad + 64));
+    HIPCHK(c, c->errflag.reserve(1));
+    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
+    {
+        ProfScope ps(c, "prep");
+        msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad,
+                                 c->errflag.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_i32.reserve(4));
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_i32.p[0]) return MSA_E_NON_ASCII;
+    c->have_planes = true;
+    return MSA_OK;
+}
+
+int ensure_gaps(msa_ctx *c, bool to_host) {
+    if (!c->have_gaps) {
+        HIPCHK(c, c->gaps.reserve((size_t)c->n + 64));
+        HIPCHK(c, c->indets.reserve((size_t)c->n + 64));
+        HIPCHK(c, hipMemsetAsync(c->gaps.p, 0, sizeof(int32_t) * c->n, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->indets.p, 0, sizeof(int32_t) * c->n, c->stream));
+        {
+            ProfScope ps(c, "gaps");
+            msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p);
+        }
+        HIPCHK(c, hipGetLastError());
+        c->have_gaps = true;
+    }
+    if (to_host && c->h_gaps.empty() && c->n > 0) {
+        HIPCHK(c, c->h_i32.reserve((size_t)2 * c->n));
+        HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_i32.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->h_gaps.assign(c->h_i32.p, c->h_i32.p + c->n);
+        c->h_indets.assign(c->h_i32.p + c->n, c->h_i32.p + 2 * c->n);
+    }
+    return MSA_OK;
+}
+
+// pair pass; want_* select which float matrices / integer matrices are produced
+int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
+    int rc = ensure_planes(c);
+    if (rc) return rc;
+    const bool need_ident = want_ident && !c->have_ident, need_w = want_w && !c->have_w;
+    if (!need_ident && !need_w && !want_counts) return MSA_OK;
+    const size_t fsz = (size_t)c->m * c->ldw + 64;
+    if (need_ident) {
+        HIPCHK(c, c->ident.reserve(fsz));
+        HIPCHK(c, hipMemsetAsync(c->ident.p, 0, fsz * sizeof(float), c->stream));
+    }
+    if (need_w) {
+        HIPCHK(c, c->wmat.reserve(fsz));
+        HIPCHK(c, hipMemsetAsync(c->wmat.p, 0, fsz * sizeof(float), c->stream));
+    }
+    if (want_counts) {
+        HIPCHK(c, c->hit.reserve((size_t)c->m * c->m + 1));
+        HIPCHK(c, c->dst.reserve((size_t)c->m * c->m + 1));
+        HIPCHK(c, hipMemsetAsync(c->hit.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->dst.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
+    }
+    {
+        ProfScope ps(c, "pairs");
+        msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
+                                 want_counts ? c->hit.p : nullptr, want_counts ? c->dst.p : nullptr,
+                                 need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (need_ident) c->have_ident = true;
+    if (need_w) c->have_w = true;
+    return MSA_OK;
+}
+
+int identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
+    int rc = run_pairs(c, true, false, false);
+    if (rc) return rc;
+    HIPCHK(c, c->row_avg.reserve(c->m + 64));
+    HIPCHK(c, c->row_max.reserve(c->m + 64));
+    HIPCHK(c, c->stats2.reserve(2));
+    {
+        ProfScope ps(c, "idstats");
+        msak::launch_identity_stats(c->stream, c->ident.p, c->m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_f32.reserve(2));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->stats2.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *avg_seq = c->h_f32.p[0];
+    *max_seq = c->h_f32.p[1];
+    return MSA_OK;
+}
+
+// byte -> table offset LUT and {distance, both-valid} table (see msastat_kernels.hip)
+void build_tables(const int32_t *vhash, const float *dist, int npos, uint8_t indet, uint8_t lut[256], float *tab) {
+    for (int b = 0; b < 256; ++b) {
+        uint8_t code;
+        if (b == '-' || b == indet) code = 224;
+        else {
+            const int up = (b >= 'a' && b <= 'z') ? b - 32 : b;
+            if (up < 'A' || up > 'Z') code = 0xFE;
+            else if (vhash[up - 'A'] < 0 || vhash[up - 'A'] >= npos) code = 0xFF;
+            else code = static_cast<uint8_t>(vhash[up - 'A'] * 8);
+        }
+        lut[b] = code;
+    }
+    std::memset(tab, 0, sizeof(float) * 2 * 29 * 32);
+    for (int a = 0; a < npos; ++a)
+        for (int b = 0; b < npos; ++b) {
+            tab[(a * 32 + b) * 2 + 0] = dist[a * npos + b];
+            tab[(a * 32 + b) * 2 + 1] = 1.0f;
+        }
+}
+
+int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed,
+               float *mdk_out, float *q_out, msa_err_detail *detail) {
+    if (npos < 1 || npos > 28) return MSA_E_INVALID;
+    int rc = run_pairs(c, false, true, false);
+    if (rc) return rc;
+    rc = ensure_gaps(c, false);
+    if (rc) return rc;
+    const int m = c->m, n = c->n;
+    const int G = (m + 3) / 4;
+    // tables
+    uint8_t lut[256];
+    std::vector<float> tab(2 * 29 * 32);
+    build_tables(vhash, dist, npos, c->indet, lut, tab.data());
+    HIPCHK(c, c->lut.reserve(256));
+    HIPCHK(c, c->tab.reserve(tab.size()));
+    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, n)));
+    HIPCHK(c, c->h_f32.reserve(std::max<size_t>(tab.size(), (size_t)2 * n + 64)));
+    std::memcpy(c->h_u8.p, lut, 256);
+    std::memcpy(c->h_f32.p, tab.data(), tab.size() * sizeof(float));
+    HIPCHK(c, hipMemcpyAsync(c->lut.p, c->h_u8.p, 256, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tab.p, c->h_f32.p, tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // the vector used for the ">= 80 % gaps" cut
+    const int32_t *gw_dev = c->gaps.p;
+    if (gaps_windowed) {
+        HIPCHK(c, c->gaps_w.reserve((size_t)n + 64));
+        HIPCHK(c, c->h_i32.reserve((size_t)2 * n + 4));
+        std::memcpy(c->h_i32.p, gaps_windowed, sizeof(int32_t) * n);
+        HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+        gw_dev = c->gaps_w.p;
+    }
+    HIPCHK(c, c->codes4.reserve((size_t)G * c->ld + 64));
+    HIPCHK(c, c->errkey.reserve(1));
+    HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
+    {
+        ProfScope ps(c, "encode");
+        msak::launch_sim_encode(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codes4.p, c->errkey.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->q.reserve((size_t)n + 64));
+    HIPCHK(c, c->mdk.reserve((size_t)n + 64));
+    {
+        ProfScope ps(c, "sim");
+        int e = msak::launch_similarity(c->stream, c->codes4.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, gw_dev,
+                                        c->q.p, c->mdk.p);
+        if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_u64.reserve(1));
+    HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned long long key = c->h_u64.p[0];
+    if (key != ~0ull) {
+        if (detail) {
+            detail->col = static_cast<int32_t>(key >> 40);
+            detail->row = static_cast<int32_t>((key >> 16) & 0xFFFFFFull);
+            detail->byte = static_cast<int32_t>(key & 0xFF);
+        }
+        return ((key >> 8) & 1ull) ? MSA_E_UNDEFINED_SYMBOL : MSA_E_INCORRECT_SYMBOL;
+    }
+    std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
+    if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
+    return MSA_OK;
+}
+
+int overlap(msa_ctx *c, float residue_overlap, float *out) {
+    int rc = ensure_gaps(c, false);
+    if (rc) return rc;
+    const int m = c->m, n = c->n;
+    const float fo = residue_overlap * static_cast<float>(m - 1);
+    const int need = static_cast<int>(std::ceil(fo));
+    HIPCHK(c, c->col_ok.reserve((size_t)3 * c->nchunk + 64));
+    HIPCHK(c, c->good.reserve((size_t)m + 64));
+    {
+        ProfScope ps(c, "overlap");
+        msak::launch_overlap(c->stream, c->raw, m, n, c->ld, c->indet, c->gaps.p, c->indets.p, need, c->col_ok.p,
+                             c->nchunk, c->good.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->good.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < m; ++i) out[i] = static_cast<float>(c->h_i32.p[i]) / n;
+    return MSA_OK;
+}
+
+// Cleaner::removeAllGapsSeqsAndCols: first sequences (over kept columns), then columns (over
+// the updated sequences).
+int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
+    const int m = c->m, n = c->n;
+    HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
+    HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
+    HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
+    HIPCHK(c, c->col_cnt.reserve((size_t)n + 64));
+    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, n)));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
+    std::memcpy(c->h_u8.p, keep_res, n);
+    HIPCHK(c, hipMemcpyAsync(c->keep_res_d.p, c->h_u8.p, n, hipMemcpyHostToDevice, c->stream));
+    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < m; ++i)
+        if (keep_seq[i] && c->h_i32.p[i] == 0) keep_seq[i] = 0;
+    std::memcpy(c->h_u8.p, keep_seq, m);
+    HIPCHK(c, hipMemcpyAsync(c->keep_seq_d.p, c->h_u8.p, m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
+    msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int j = 0; j < n; ++j)
+        if (keep_res[j] && c->h_i32.p[j] == 0) keep_res[j] = 0;
+    return MSA_OK;
+}
+
+int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned long long> *hashes) {
+    const int m = c->m;
+    HIPCHK(c, c->lengths.reserve((size_t)m + 64));
+    HIPCHK(c, c->hashes.reserve((size_t)2 * m + 64));
+    msak::launch_row_digest(c->stream, c->raw, m, c->n, c->ld, c->lengths.p, c->hashes.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    HIPCHK(c, c->h_u64.reserve((size_t)2 * m + 1));
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->lengths.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->hashes.p, sizeof(unsigned long long) * 2 * m, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    lengths.assign(c->h_i32.p, c->h_i32.p + m);
+    if (hashes) hashes->assign(c->h_u64.p, c->h_u64.p + 2 * m);
+    return MSA_OK;
+}
+
+// Cleaner::removeDuplicates (as patched by the reference): the earlier of two identical rows goes.
+int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
+    const int m = c->m;
+    std::vector<int32_t> lengths;
+    std::vector<unsigned long long> hashes;
+    int rc = row_digest(c, lengths, &hashes);
+    if (rc) return rc;
+    // candidate pairs: for each row i, the first later row x with equal digest
+    struct Key {
+        unsigned long long a, b;
+        bool operator==(const Key &o) const { return a == o.a && b == o.b; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key &k) const { return static_cast<size_t>(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); }
+    };
+    std::unordered_map<Key, std::vector<int>, KeyHash> groups;
+    for (int i = 0; i < m; ++i) groups[Key{hashes[2 * i], hashes[2 * i + 1]}].push_back(i);
+    std::vector<int32_t> pairs;
+    for (auto &kv : groups) {
+        const std::vector<int> &g = kv.second;
+        for (size_t a = 0; a < g.size(); ++a)
+            for (size_t b = a + 1; b < g.size(); ++b) {
+                pairs.push_back(g[a]);
+                pairs.push_back(g[b]);
+            }
+    }
+    const int npairs = static_cast<int>(pairs.size() / 2);
+    if (npairs == 0) return MSA_OK;
+    HIPCHK(c, c->pairs.reserve(pairs.size()));
+    HIPCHK(c, c->equal.reserve(npairs));
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    msak::launch_rows_equal(c->stream, c->raw, c->n, c->ld, c->pairs.p, npairs, c->equal.p);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int32_t> equal(npairs);
+    HIPCHK(c, hipMemcpyAsync(equal.data(), c->equal.p, npairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int p = 0; p < npairs; ++p)
+        if (equal[p]) keep_seq[std::min(pairs[2 * p], pairs[2 * p + 1])] = 0;  // a later identical row exists
+    return MSA_OK;
+}
+
+int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of the identity matrix
+    int rc = run_pairs(c, true, false, false);
+    if (rc) return rc;
+    host.resize((size_t)c->m * c->m);
+    HIPCHK(c, hipMemcpy2DAsync(host.data(), (size_t)c->m * sizeof(float), c->ident.p, (size_t)c->ldw * sizeof(float),
+                               (size_t)c->m * sizeof(float), c->m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *msa_strerror(int code) {
+    switch (code) {
+        case MSA_OK: return "ok";
+        case MSA_E_INVALID: return "invalid argument or call order";
+        case MSA_E_NO_DEVICE: return "no HIP device available";
+        case MSA_E_HIP: return "HIP runtime error";
+        case MSA_E_NOMEM: return "out of memory";
+        case MSA_E_WINDOW_TOO_BIG: return "window size is too big for this alignment";
+        case MSA_E_INCORRECT_SYMBOL: return "incorrect symbol in the alignment";
+        case MSA_E_UNDEFINED_SYMBOL: return "symbol not defined in the similarity matrix";
+        case MSA_E_NOT_IMPLEMENTED: return "method not implemented";
+        case MSA_E_NON_ASCII: return "non-ASCII byte in the alignment";
+        default: return "unknown error";
+    }
+}
+
+int msa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *msa_last_hip_error(const msa_ctx *ctx) { return ctx ? ctx->hip_err : ""; }
+
+int msa_ctx_create(int device, msa_ctx **out) {
+    if (!out) return MSA_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MSA_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MSA_E_NO_DEVICE;
+    msa_ctx *c = new (std::nothrow) msa_ctx();
+    if (!c) return MSA_E_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return MSA_E_HIP;
+    }
+    *out = c;
+    return MSA_OK;
+}
+
+void msa_ctx_destroy(msa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+    c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
+    c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release();
+    c->stats2.release(); c->codes4.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
+    c->q.release(); c->mdk.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
+    c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
+    c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
+    c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *msa_ctx_stream(msa_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+int msa_ctx_sync(msa_ctx *c) {
+    if (!c) return MSA_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSA_OK;
+}
+
+int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
+    if (!c || (!rowmajor && m > 0 && n > 0) || ld < n) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_shape(c, m, n, indet);
+    if (rc) return rc;
+    c->ld = round_up(std::max(n, 1), 64);
+    HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
+    c->raw = c->raw_own.p;
+    if (m > 0 && n > 0)
+        HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor, (size_t)ld, (size_t)n, (size_t)m,
+                                   hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `rowmajor` on return
+    return MSA_OK;
+}
+
+int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet) {
+    if (!c || (!rows && m > 0)) return MSA_E_INVALID;
+    std::vector<uint8_t> packed((size_t)std::max(m, 0) * std::max(n, 0));
+    for (int i = 0; i < m; ++i) std::memcpy(packed.data() + (size_t)i * n, rows[i], (size_t)n);
+    return msa_upload_packed(c, packed.data(), m, n, n, indet);
+}
+
+int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
+    if (!c || !rowmajor_dev || ld < n) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_shape(c, m, n, indet);
+    if (rc) return rc;
+    const bool usable = (ld % 64 == 0) && (ld >= round_up(std::max(n, 1), 64)) &&
+                        (reinterpret_cast<uintptr_t>(rowmajor_dev) % 16 == 0);
+    if (usable) {
+        c->raw = static_cast<const uint8_t *>(rowmajor_dev);
+        c->ld = ld;
+    } else {  // re-pitch into an owned buffer (device-to-device)
+        c->ld = round_up(std::max(n, 1), 64);
+        HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
+        HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor_dev, (size_t)ld, (size_t)n, (size_t)m,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        c->raw = c->raw_own.p;
+    }
+    return MSA_OK;
+}
+
+int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
+    if (!c || !c->raw) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_gaps(c, true);
+    if (rc) return rc;
+    if (gaps_out) std::copy(c->h_gaps.begin(), c->h_gaps.end(), gaps_out);
+    if (indet_out) std::copy(c->h_indets.begin(), c->h_indets.end(), indet_out);
+    return MSA_OK;
+}
+
+int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
+    if (!c || !c->raw) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = run_pairs(c, false, false, true);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->m * c->m * sizeof(uint32_t);
+    if (hit) HIPCHK(c, hipMemcpyAsync(hit, c->hit.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (dst) HIPCHK(c, hipMemcpyAsync(dst, c->dst.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSA_OK;
+}
+
+int msa_identities(msa_ctx *c, float *ident, float *w) {
+    if (!c || !c->raw) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = run_pairs(c, true, true, false);
+    if (rc) return rc;
+    const size_t row = (size_t)c->m * sizeof(float);
+    if (ident)
+        HIPCHK(c, hipMemcpy2DAsync(ident, row, c->ident.p, (size_t)c->ldw * sizeof(float), row, c->m,
+                                   hipMemcpyDeviceToHost, c->stream));
+    if (w)
+        HIPCHK(c, hipMemcpy2DAsync(w, row, c->wmat.p, (size_t)c->ldw * sizeof(float), row, c->m, hipMemcpyDeviceToHost,
+                                   c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSA_OK;
+}
+
+int msa_identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
+    if (!c || !c->raw || !avg_seq || !max_seq) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return identity_stats(c, avg_seq, max_seq);
+}
+
+int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t npos, const int32_t *gaps_windowed,
+                   float *mdk_out, float *q_out, msa_err_detail *detail) {
+    if (!c || !c->raw || !vhash || !dist || !mdk_out) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return similarity(c, vhash, dist, npos, gaps_windowed, mdk_out, q_out, detail);
+}
+
+int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
+    if (!c || !c->raw || !spurious_out) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    return overlap(c, residue_overlap, spurious_out);
+}
+
+int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
+    if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    msa_trim_info local;
+    if (!info) info = &local;
+    std::memset(info, 0, sizeof(*info));
+    const int m = c->m, n = c->n;
+    std::fill(keep_res, keep_res + n, 1);
+    std::fill(keep_seq, keep_seq + m, 1);
+    if (m == 0 || n == 0) return MSA_OK;
+    int rc = MSA_OK;
+
+    // trimAlManager::set_window_size
+    int gap_hw = p->gap_window, sim_hw = p->similarity_window;
+    if (p->window != -1) gap_hw = sim_hw = p->window;
+    if (gap_hw == -1) gap_hw = 0;
+    if (sim_hw == -1) sim_hw = 0;
+
+    std::vector<int32_t> gaps_w;
+    std::vector<float> mdk, mdk_w;
+    auto need_gaps = [&]() -> int {
+        if (!gaps_w.empty()) return MSA_OK;
+        int r = ensure_gaps(c, true);
+        if (r) return r;
+        gaps_w.resize(n);
+        return msah::window_i32(c->h_gaps.data(), n, gap_hw, gaps_w.data());
+    };
+    auto need_sim = [&]() -> int {
+        if (!mdk.empty()) return MSA_OK;
+        int r = need_gaps();
+        if (r) return r;
+        if (sim_hw > n / 4) return MSA_E_WINDOW_TOO_BIG;
+        if (!p->vhash || !p->dist) return MSA_E_INVALID;
+        mdk.resize(n);
+        r = similarity(c, p->vhash, p->dist, p->npos, gap_hw > 0 ? gaps_w.data() : nullptr, mdk.data(), nullptr,
+                       &info->err);
+        if (r) return r;
+        mdk_w.resize(n);
+        return msah::window_f32(mdk.data(), n, sim_hw, mdk_w.data());
+    };
+
+    int method = p->method;
+    bool seq_mode = false;
+    if (method == MSA_METHOD_NODUPLICATESEQS) {
+        rc = remove_duplicates(c, keep_seq);
+        if (rc) return rc;
+        seq_mode = true;
+    } else if (p->clusters != -1 || p->max_identity != -1) {
+        // RepresentativeTrimmer: the m*m identities come to the host for the greedy clustering
+        std::vector<float> ident;
+        rc = fetch_ident(c, ident);
+        if (rc) return rc;
+        std::vector<int32_t> lengths;
+        rc = row_digest(c, lengths, nullptr);
+        if (rc) return rc;
+        float thr = p->max_identity;
+        if (p->clusters != -1) thr = msah::cutpoint_clusters(ident.data(), m, lengths.data(), m, p->clusters);
+        msah::representatives(ident.data(), m, lengths.data(), m, thr, keep_seq);
+        seq_mode = true;
+    } else if (p->residue_overlap != -1 && p->sequence_overlap != -1) {
+        std::vector<float> ov(m);
+        rc = overlap(c, p->residue_overlap, ov.data());
+        if (rc) return rc;
+        const float min_ov = p->sequence_overlap / 100.0F;
+        for (int i = 0; i < m; ++i)
+            if (ov[i] < min_ov) keep_seq[i] = 0;
+        seq_mode = true;
+    }
+
+    if (!seq_mode) {
+        if (method == MSA_METHOD_AUTOMATED1) {
+            // one pair pass produces both float matrices when strict is likely to follow
+            rc = run_pairs(c, true, true, false);
+            if (rc) return rc;
+            rc = identity_stats(c, &info->avg_seq, &info->max_seq);
+            if (rc) return rc;
+            info->selected_method = msah::select_method(info->avg_seq, info->max_seq, m);
+            method = info->selected_method == 1 ? MSA_METHOD_GAPPYOUT : MSA_METHOD_STRICT;
+        }
+        if (method == MSA_METHOD_AUTOMATED2) return MSA_E_NOT_IMPLEMENTED;
+        if (method == MSA_METHOD_GAPPYOUT) {
+            if ((rc = need_gaps())) return rc;
+            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            msah::clean_gaps(gaps_w.data(), n, info->gap_cut, 0, keep_res);
+        } else if (method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS) {
+            if ((rc = need_gaps())) return rc;
+            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            if ((rc = need_sim())) return rc;
+            info->sim_cut = msah::comb_similarity_cut(gaps_w.data(), mdk_w.data(), n, info->gap_cut);
+            msah::clean_strict(gaps_w.data(), mdk_w.data(), n, info->gap_cut, info->sim_cut,
+                               method == MSA_METHOD_STRICTPLUS, keep_res);
+        } else if (method == MSA_METHOD_NOGAPS) {
+            if ((rc = need_gaps())) return rc;
+            msah::clean_gaps(gaps_w.data(), n, msah::GapHistogram(c->h_gaps.data(), m, n).cut_point(0, 0), 0, keep_res);
+        } else if (method == MSA_METHOD_NOALLGAPS) {
+            if ((rc = need_gaps())) return rc;
+            msah::clean_gaps(gaps_w.data(), n, m - 1, 0, keep_res);
+        } else if (method == MSA_METHOD_NONE) {
+            float gap_thr = p->gap_threshold;
+            if (p->gap_absolute_threshold != -1) gap_thr = static_cast<float>(p->gap_absolute_threshold) / m;
+            const bool has_g = gap_thr != -1, has_s = p->similarity_threshold != -1;
+            const float base = p->conservation_percentage;
+            if (has_g && has_s) {
+                if ((rc = need_sim())) return rc;
+                const double cg = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point(base, gap_thr);
+                const float cs = static_cast<float>(msah::similarity_cut_point(mdk_w.data(), n, base, p->similarity_threshold));
+                msah::clean_both(gaps_w.data(), mdk_w.data(), n, cg, cs, base, keep_res);
+            } else if (has_g) {
+                if ((rc = need_gaps())) return rc;
+                msah::clean_gaps(gaps_w.data(), n, msah::GapHistogram(c->h_gaps.data(), m, n).cut_point(base, gap_thr), base,
+                                 keep_res);
+            } else if (has_s) {
+                if ((rc = need_sim())) return rc;
+                const float cs = static_cast<float>(msah::similarity_cut_point(mdk_w.data(), n, base, p->similarity_threshold));
+                msah::clean_similarity(mdk_w.data(), n, cs, base, keep_res);
+            }
+        } else {
+            return MSA_E_INVALID;
+        }
+    }
+    rc = remove_all_gaps(c, keep_res, keep_seq);
+    if (rc) return rc;
+    info->kept_residues = static_cast<int32_t>(std::count(keep_res, keep_res + n, 1));
+    info->kept_sequences = static_cast<int32_t>(std::count(keep_seq, keep_seq + m, 1));
+    return MSA_OK;
+}
+
+int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
+    if (!c || !kernel) return MSA_E_INVALID;
+    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap"};
+    bool known = false;
+    for (const char *nm : names) known |= (std::strcmp(nm, kernel) == 0);
+    if (!known) return MSA_E_INVALID;
+    (void)hipSetDevice(c->device);
+    prof_collect(c);
+    auto it = c->prof.find(kernel);
+    if (ms_total) *ms_total = it == c->prof.end() ? 0.0f : static_cast<float>(it->second.ms);
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    return MSA_OK;
+}
+
+void msa_prof_reset(msa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    prof_collect(c);
+    c->prof.clear();
+}
+
+void msa_prof_enable(msa_ctx *c, int enable) {
+    if (c) c->prof_on = enable != 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Launch wrappers of msastat_kernels.hip (internal; the public surface is include/msastat.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msak {
+
+constexpr int PAIR_TI = 8;   // rows "i" per wave in pair_counts (wave-uniform, SGPR operands)
+constexpr int PAIR_TJ = 2;   // rows "j" per lane; m_pad must be a multiple of 64 * PAIR_TJ
+
+void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
+                        int nchunk, int m_pad, int *err_flag);
+void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
+                       int32_t *indets);
+void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
+                        uint32_t *dst, float *ident, float *wmat);
+void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
+                           float *out2);
+void launch_sim_encode(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
+                       const int32_t *gaps_w, uint32_t *codes4, unsigned long long *err_key);
+size_t similarity_lds_bytes(int m);
+int launch_similarity(hipStream_t s, const uint32_t *codes4, int m, int n, int64_t ld, const float *wmat, int ldw,
+                      const void *tab, const int32_t *gaps_w, float *q_out, float *mdk_out);
+void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
+                    const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good);
+void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,
+                       int32_t *row_nongap);
+void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,
+                       int32_t *col_nongap);
+void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, int32_t *lengths,
+                       unsigned long long *hashes);
+void launch_rows_equal(hipStream_t s, const uint8_t *raw, int n, int64_t ld, const int32_t *pairs, int npairs,
+                       int32_t *equal);
+
+}  // namespace msak

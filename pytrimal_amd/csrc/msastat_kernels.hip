@@ -1,0 +1,581 @@
+// msastat_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the MSA statistics path.
+//
+// Data layout in HBM (all produced on the device from the row-major residue bytes):
+//   raw     [m][ld]              u8   residues as given (ld % 64 == 0, columns >= n undefined)
+//   planes  [8][nchunk][m_pad]   u32  bit-sliced rows: plane p<7 = bit p of the ASCII byte,
+//                                      plane 7 = validity (not '-' and not indet); bit b of word
+//                                      (chunk c, row r) is column 32c+b.  Row index is fastest, so a
+//                                      wave whose lanes own 64 consecutive rows loads 256 B per plane.
+//   gaps / indet [n]             i32  per-column '-' / indetermination counts
+//   ident, w [m][ldw]            f32  pairwise identity and 1-identity (ldw % 64 == 0, pad = 0)
+//   codes4  [ceil(m/4)][ld]      u32  per column, 4 consecutive rows' similarity-table offsets
+//   tab     [29][32]             f32x2 {distance, both-valid} indexed by (row code, column code)
+//
+// No MFMA anywhere: this is integer / lookup / ordered-fp32 work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msastat_kernels.h"
+
+namespace msak {
+
+// ------------------------------------------------------------------------------------------
+// prep_planes: raw bytes -> bit-sliced planes.  One thread = one row x 64 columns (a full 64-B
+// line of that row); lanes of a wave own consecutive rows so the plane stores coalesce.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gather_bit4(uint32_t x, int b) {
+    // bit b of each of the 4 bytes of x -> 4 adjacent bits (byte 0 -> bit 0)
+    return ((((x >> b) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
+    // 0x80 in every byte of v that is zero (exact, bytes < 0x80 or not)
+    uint32_t t = (v & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | v | 0x7f7f7f7fu);
+}
+
+__global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restrict__ raw, int m, int n,
+                                                          int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
+                                                          int nchunk, int m_pad, int *__restrict__ err_flag) {
+    const int row = blockIdx.x * 256 + threadIdx.x;  // < m_pad
+    const int cpair = blockIdx.y;                    // 64-column group
+    if (row >= m_pad) return;
+    uint32_t out[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) out[h][p] = 0;
+    if (row < m) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld + (size_t)cpair * 64);
+        uint32_t bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v4 = src[q];
+            uint32_t w[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = cpair * 64 + q * 16 + e * 4;  // first column of this dword
+                uint32_t x = w[e];
+                // mask columns >= n (undefined bytes) to '-' so they are invalid everywhere
+                uint32_t keep = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) keep |= (col + k < n) ? (0xFFu << (8 * k)) : 0u;
+                x = (x & keep) | (0x2d2d2d2du & ~keep);
+                bad |= x & 0x80808080u;
+                uint32_t inval = zero_bytes(x ^ 0x2d2d2d2du) | zero_bytes(x ^ indet4);  // 0x80 flags
+                uint32_t vbits = gather_bit4(~inval, 7);
+                const int h = q >> 1, sh = ((q & 1) * 4 + e) * 4;
+#pragma unroll
+                for (int p = 0; p < 7; ++p) out[h][p] |= gather_bit4(x, p) << sh;
+                out[h][7] |= vbits << sh;
+            }
+        }
+        if (bad) atomicOr(err_flag, 1);
+    }
+    const size_t pstride = (size_t)nchunk * m_pad;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int chunk = cpair * 2 + h;
+        if (chunk < nchunk) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) planes[p * pstride + (size_t)chunk * m_pad + row] = out[h][p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gap_counts: per-column '-' and indetermination counts (statistics::Gaps::CalculateVectors).
+// One thread = 4 adjacent columns (one dword per row, a wave reads 256 contiguous bytes per
+// row), SWAR byte counters over a slab of <= 128 rows, then one integer atomic per column.
+// HBM-bound: reads m*n bytes once.
+// ------------------------------------------------------------------------------------------
+constexpr int GAP_SLAB = 64;
+
+__global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         uint32_t indet4, int32_t *__restrict__ gaps,
+                                                         int32_t *__restrict__ indets) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x;  // dword column
+    if ((int64_t)c4 * 4 >= ld) return;
+    const int r0 = blockIdx.y * GAP_SLAB;
+    const int r1 = min(m, r0 + GAP_SLAB);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)r0 * ld) + c4;
+    const size_t stride = (size_t)(ld >> 2);
+    uint32_t accg = 0, acci = 0;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+        uint32_t x = *p;
+        p += stride;
+        accg += zero_bytes(x ^ 0x2d2d2d2du) >> 7;
+        acci += zero_bytes(x ^ indet4) >> 7;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        if (c < n) {
+            uint32_t g = (accg >> (8 * k)) & 0xFFu, x = (acci >> (8 * k)) & 0xFFu;
+            if (g) atomicAdd(&gaps[c], (int)g);
+            if (x) atomicAdd(&indets[c], (int)x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pair_counts: hit/dst of every sequence pair (Cleaner::calculateSeqIdentity ==
+// Similarity::calculateMatrixIdentity integers).  One wave = TI rows "i" (wave-uniform, read
+// through the scalar cache) x 64 rows "j" (one per lane); per 32 columns and pair:
+// 7 xor + 3 or3 (difference mask) + bfi + 2 bcnt + or.  Integer work, any order is exact.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                         int m, int ldw, uint32_t *__restrict__ hit_out,
+                                                         uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                         float *__restrict__ wmat) {
+    const int lane = threadIdx.x;
+    const int i0 = blockIdx.x * TI;  // uniform
+    const int j0 = blockIdx.y * (64 * TJ);
+    if (j0 + 64 * TJ - 1 <= i0) return;  // tile holds no pair with j > i: its mirror tile writes both halves
+    uint32_t hit[TJ][TI], dst[TJ][TI];
+#pragma unroll
+    for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int t = 0; t < TI; ++t) hit[u][t] = dst[u][t] = 0;
+    const size_t ps = (size_t)nchunk * m_pad;
+    const uint32_t *pj = planes + j0 + lane;
+    const uint32_t *pi = planes + i0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int c = 0; c < nchunk; ++c) {
+        const size_t off = (size_t)c * m_pad;
+        uint32_t b[TJ][8];
+#pragma unroll
+        for (int u = 0; u < TJ; ++u)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) b[u][p] = pj[off + p * ps + 64 * u];
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const uint32_t *q = pi + off + t;  // wave-uniform address -> scalar loads
+            const uint32_t a0 = q[0], a1 = q[ps], a2 = q[2 * ps], a3 = q[3 * ps], a4 = q[4 * ps], a5 = q[5 * ps],
+                           a6 = q[6 * ps], vi = q[7 * ps];
+#pragma unroll
+            for (int u = 0; u < TJ; ++u) {
+                uint32_t d = a0 ^ b[u][0];
+                d |= a1 ^ b[u][1];
+                d |= a2 ^ b[u][2];
+                d |= a3 ^ b[u][3];
+                d |= a4 ^ b[u][4];
+                d |= a5 ^ b[u][5];
+                d |= a6 ^ b[u][6];
+                hit[u][t] += __builtin_popcount(~d & vi);
+                dst[u][t] += __builtin_popcount(vi | b[u][7]);
+            }
+        }
+    }
+    // epilogue: row-wise (coalesced along j) and mirrored (TI contiguous values per lane)
+#pragma unroll
+    for (int u = 0; u < TJ; ++u) {
+        const int j = j0 + 64 * u + lane;
+        if (j >= m) continue;
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const int i = i0 + t;
+            if (i >= m) break;
+            const bool diag = (i == j);
+            const uint32_t h = diag ? 0u : hit[u][t], d = diag ? 0u : dst[u][t];
+            if (hit_out) {
+                hit_out[(size_t)i * m + j] = h;
+                hit_out[(size_t)j * m + i] = h;
+            }
+            if (dst_out) {
+                dst_out[(size_t)i * m + j] = d;
+                dst_out[(size_t)j * m + i] = d;
+            }
+            if (ident || wmat) {
+                const float r = d ? (float)h / (float)d : 0.0f;
+                if (ident) {
+                    const float v = diag ? 0.0f : r;
+                    ident[(size_t)i * ldw + j] = v;
+                    ident[(size_t)j * ldw + i] = v;
+                }
+                if (wmat) {
+                    const float v = diag ? 0.0f : 1.0f - r;
+                    wmat[(size_t)i * ldw + j] = v;
+                    wmat[(size_t)j * ldw + i] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// identity_stats: the per-row max / mean of Cleaner::selectMethod, then the two means over
+// rows, every sum in the reference's order (ascending index, float32).  Lane = row i; the
+// symmetric matrix is read column-wise so that loads coalesce.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+                                                           float *__restrict__ row_avg, float *__restrict__ row_max) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= m) return;
+    float mx = 0.0f, avg = 0.0f;
+    const float *p = ident + i;
+#pragma unroll 8
+    for (int j = 0; j < m; ++j) {
+        const float v = p[(size_t)j * ldw];  // ident[j][i] == ident[i][j]
+        if (j != i) {
+            mx = mx < v ? v : mx;
+            avg += v;
+        }
+    }
+    row_avg[i] = avg / (float)(m - 1);
+    row_max[i] = mx;
+}
+
+__global__ void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max, int m,
+                                      float *__restrict__ out2) {
+    if (threadIdx.x || blockIdx.x) return;
+    float a = 0.0f, x = 0.0f;
+    for (int i = 0; i < m; ++i) {
+        a += row_avg[i];
+        x += row_max[i];
+    }
+    out2[0] = a / (float)m;
+    out2[1] = x / (float)m;
+}
+
+// ------------------------------------------------------------------------------------------
+// sim_encode: residues -> similarity-table offsets, 4 rows packed per dword per column, and the
+// first offending residue (reference order: lowest non-skipped column, then lowest row).
+// lut[256]: byte -> code*8 (0..216), 224 = skipped (gap / indetermination),
+//           0xFE = incorrect symbol, 0xFF = symbol not in the matrix alphabet.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sim_encode_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         const uint8_t *__restrict__ lut_g,
+                                                         const int32_t *__restrict__ gaps_w,
+                                                         uint32_t *__restrict__ codes4,
+                                                         unsigned long long *__restrict__ err_key) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)c4 * 4 >= ld) return;
+    const int g = blockIdx.y;  // row group
+    uint32_t x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = g * 4 + r;
+        x[r] = (row < m) ? *(reinterpret_cast<const uint32_t *>(raw + (size_t)row * ld) + c4) : 0x2d2d2d2du;
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        uint32_t o = 0;
+        bool skipcol = true;
+        if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t byte = (x[r] >> (8 * k)) & 0xFFu;
+            uint32_t code = (c < n) ? lut[byte] : 224u;
+            if (code >= 0xFEu) {
+                if (!skipcol) {
+                    const unsigned long long key = ((unsigned long long)c << 40) |
+                                                   ((unsigned long long)(g * 4 + r) << 16) |
+                                                   ((unsigned long long)(code & 1u) << 8) | byte;
+                    atomicMin(err_key, key);
+                }
+                code = 224u;
+            }
+            o |= code << (8 * r);
+        }
+        out[k] = o;
+    }
+    *reinterpret_cast<uint4 *>(codes4 + (size_t)g * ld + (size_t)c4 * 4) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity_mdk (order-preserving): statistics::Similarity::calculateVectors.
+// One lane = one column; a wave walks the pairs (j,k), j<k, in the reference's lexicographic
+// order, so W[j][k] is wave-uniform and each lane carries its own {num, den} float32 chain:
+//     num = fl(num + fl(W*D));  den = fl(den + W)       (no FMA contraction)
+// Skipped rows contribute W*0 / +0, which leaves both sums bit-identical to skipping them.
+// The column tile (m x 64 codes) and the {D, valid} table live in LDS.
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool TILE_IN_LDS>
+__global__ __launch_bounds__(64) void similarity_kernel(const uint32_t *__restrict__ codes4, int m, int n, int64_t ld,
+                                                        const float *__restrict__ wmat, int ldw,
+                                                        const f32x2 *__restrict__ tab_g,
+                                                        const int32_t *__restrict__ gaps_w, float *__restrict__ q_out,
+                                                        float *__restrict__ mdk_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x2 *tab = reinterpret_cast<f32x2 *>(smem);                 // [29][32] -> 7424 B
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem + 7424);   // [G][64]
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const int G = (m + 3) >> 2;
+    for (int t = lane; t < 29 * 32; t += 64) tab[t] = tab_g[t];
+    const uint32_t *col = codes4 + c;  // c < ld always (ld % 64 == 0)
+    if (TILE_IN_LDS) {
+        for (int g = 0; g < G; ++g) tile[g * 64 + lane] = col[(size_t)g * ld];
+    }
+    __syncthreads();
+    const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
+
+    f32x2 acc = {0.0f, 0.0f};  // {num, den}
+    for (int j = 0; j + 1 < m; ++j) {
+        const uint32_t wj = TILE_IN_LDS ? tile[(j >> 2) * 64 + lane] : col[(size_t)(j >> 2) * ld];
+        const uint32_t cj8 = (wj >> ((j & 3) * 8)) & 0xFFu;
+        const unsigned char *trow = tabb + cj8 * 32u;  // row stride 32 entries * 8 B
+        const float *wrow = wmat + (size_t)j * ldw;    // wave-uniform
+        int g = (j + 1) >> 2;
+        {   // first group: rows k <= j are masked with W = 0
+            const uint32_t cw = TILE_IN_LDS ? tile[g * 64 + lane] : col[(size_t)g * ld];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 4 * g + s;
+                const float w = (k > j) ? wrow[k] : 0.0f;
+                const f32x2 t = *reinterpret_cast<const f32x2 *>(trow + ((cw >> (8 * s)) & 0xFFu));
+                const f32x2 ww = {w, w};
+                acc += t * ww;
+            }
+        }
+        for (++g; g < G; ++g) {
+            const uint32_t cw = TILE_IN_LDS ? tile[g * 64 + lane] : col[(size_t)g * ld];
+            const float4 w4 = *reinterpret_cast<const float4 *>(wrow + 4 * g);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x2 t = *reinterpret_cast<const f32x2 *>(trow + ((cw >> (8 * s)) & 0xFFu));
+                const f32x2 ww = {wv[s], wv[s]};
+                acc += t * ww;
+            }
+        }
+    }
+    if (c < n) {
+        const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+        float q = 0.0f, v = 0.0f;
+        if (!skip && acc.y != 0.0f) {
+            q = acc.x / acc.y;
+            v = (float)exp(-(double)q);
+            v = v > 1.0f ? 1.0f : v;
+        }
+        if (q_out) q_out[c] = q;
+        mdk_out[c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// overlap: Cleaner::calculateSpuriousVector.  For residue x of row i in column c the hit count
+// over the other rows is   valid(x) ? nvalid_c - 1 : (count of x in c) - 1,   so the O(n m^2)
+// loop collapses to per-column counts (gap_counts) + one masked popcount pass over the planes.
+// col_ok[3][nchunk] bit masks: column is "good" for a valid / gap / indetermination residue.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overlap_colmask_kernel(const int32_t *__restrict__ gaps,
+                                                              const int32_t *__restrict__ indets, int m, int n,
+                                                              int need, uint32_t *__restrict__ col_ok, int nchunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    bool okv = false, okg = false, oki = false;
+    if (c < n) {
+        const int g = gaps[c], x = indets[c], v = m - g - x;
+        okv = (v - 1) >= need;
+        okg = (g - 1) >= need;
+        oki = (x - 1) >= need;
+    }
+    // one 64-bit ballot per wave -> two chunk words
+    const unsigned long long bv = __ballot(okv), bg = __ballot(okg), bi = __ballot(oki);
+    const int lane = threadIdx.x & 63;
+    const int chunk0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) >> 5;
+    if (lane < 2 && chunk0 + lane < nchunk) {
+        col_ok[chunk0 + lane] = (uint32_t)(bv >> (32 * lane));
+        col_ok[nchunk + chunk0 + lane] = (uint32_t)(bg >> (32 * lane));
+        col_ok[2 * nchunk + chunk0 + lane] = (uint32_t)(bi >> (32 * lane));
+    }
+}
+
+__global__ __launch_bounds__(256) void overlap_rows_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                           uint32_t indet4, const uint32_t *__restrict__ col_ok,
+                                                           int nchunk, int32_t *__restrict__ good) {
+    // one wave per row, lanes sweep the row 4 bytes at a time; shuffle-reduce the count
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)row * ld);
+    int cnt = 0;
+    for (int c4 = lane; c4 * 4 < n; c4 += 64) {
+        const uint32_t x = p[c4];
+        const uint32_t isg = zero_bytes(x ^ 0x2d2d2d2du), isi = zero_bytes(x ^ indet4);
+        const int chunk = c4 >> 3, sh = (c4 & 7) * 4;
+        const uint32_t okv = (col_ok[chunk] >> sh) & 0xFu, okg = (col_ok[nchunk + chunk] >> sh) & 0xFu,
+                       oki = (col_ok[2 * nchunk + chunk] >> sh) & 0xFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c4 * 4 + k < n) {
+                const bool g = (isg >> (8 * k + 7)) & 1u, i = (isi >> (8 * k + 7)) & 1u;
+                const uint32_t ok = g ? okg : (i ? oki : okv);
+                cnt += (ok >> k) & 1u;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) good[row] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// masked non-gap counts for Cleaner::removeAllGapsSeqsAndCols
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         const uint8_t *__restrict__ keep_res,
+                                                         int32_t *__restrict__ row_nongap) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const uint8_t *p = raw + (size_t)row * ld;
+    int cnt = 0;
+    for (int c = lane; c < n; c += 64) cnt += (keep_res[c] && p[c] != '-') ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) row_nongap[row] = cnt;
+}
+
+__global__ __launch_bounds__(256) void col_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         const uint8_t *__restrict__ keep_seq,
+                                                         int32_t *__restrict__ col_nongap) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * 64, r1 = min(m, r0 + 64);
+    if (c >= n) return;
+    int cnt = 0;
+    for (int r = r0; r < r1; ++r) cnt += (keep_seq[r] && raw[(size_t)r * ld + c] != '-') ? 1 : 0;
+    if (cnt) atomicAdd(&col_nongap[c], cnt);
+}
+
+// per-row ungapped length + 2x64-bit row hash (duplicate detection, representative ordering)
+__global__ __launch_bounds__(256) void row_digest_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         int32_t *__restrict__ lengths,
+                                                         unsigned long long *__restrict__ hashes) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    const uint8_t *p = raw + (size_t)row * ld;
+    int cnt = 0;
+    unsigned long long h1 = 0, h2 = 0;
+    for (int c = lane; c < n; c += 64) {
+        const unsigned long long x = p[c];
+        cnt += (x != '-') ? 1 : 0;
+        // position-keyed mixing (splitmix-style), summed => order independent across lanes
+        unsigned long long z = (x + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)c * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 31; z *= 0x94D049BB133111EBull; z ^= z >> 29;
+        h1 += z;
+        unsigned long long y = (x + 7) * 0xD6E8FEB86659FD93ull ^ ((unsigned long long)c + 1) * 0xCA5A826395121157ull;
+        y ^= y >> 32; y *= 0xFF51AFD7ED558CCDull; y ^= y >> 33;
+        h2 += y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        h1 += __shfl_down(h1, off, 64);
+        h2 += __shfl_down(h2, off, 64);
+    }
+    if (lane == 0) {
+        lengths[row] = cnt;
+        hashes[2 * row] = h1;
+        hashes[2 * row + 1] = h2;
+    }
+}
+
+// exact row equality for candidate pairs (hash-equal rows)
+__global__ __launch_bounds__(64) void rows_equal_kernel(const uint8_t *__restrict__ raw, int n, int64_t ld,
+                                                        const int32_t *__restrict__ pairs, int npairs,
+                                                        int32_t *__restrict__ equal) {
+    const int pidx = blockIdx.x;
+    if (pidx >= npairs) return;
+    const uint8_t *a = raw + (size_t)pairs[2 * pidx] * ld, *b = raw + (size_t)pairs[2 * pidx + 1] * ld;
+    int diff = 0;
+    for (int c = threadIdx.x; c < n; c += 64) diff |= (a[c] != b[c]);
+    const unsigned long long any = __ballot(diff);
+    if (threadIdx.x == 0) equal[pidx] = any ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline uint32_t rep4(uint8_t b) { return 0x01010101u * b; }
+
+void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
+                        int nchunk, int m_pad, int *err_flag) {
+    dim3 grid((m_pad + 255) / 256, (nchunk + 1) / 2);
+    prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag);
+}
+
+void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
+                       int32_t *indets) {
+    dim3 grid((unsigned)((ld / 4 + 255) / 256), (m + GAP_SLAB - 1) / GAP_SLAB);
+    gap_counts_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), gaps, indets);
+}
+
+void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
+                        uint32_t *dst, float *ident, float *wmat) {
+    constexpr int TI = PAIR_TI, TJ = PAIR_TJ;
+    dim3 grid((m + TI - 1) / TI, m_pad / (64 * TJ));
+    pair_counts_kernel<TI, TJ><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+}
+
+void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
+                           float *out2) {
+    identity_rows_kernel<<<(m + 63) / 64, 64, 0, s>>>(ident, m, ldw, row_avg, row_max);
+    identity_final_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
+}
+
+void launch_sim_encode(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
+                       const int32_t *gaps_w, uint32_t *codes4, unsigned long long *err_key) {
+    dim3 grid((unsigned)((ld / 4 + 255) / 256), (m + 3) / 4);
+    sim_encode_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codes4, err_key);
+}
+
+size_t similarity_lds_bytes(int m) { return 7424 + (size_t)((m + 3) / 4) * 256; }
+
+int launch_similarity(hipStream_t s, const uint32_t *codes4, int m, int n, int64_t ld, const float *wmat, int ldw,
+                      const void *tab, const int32_t *gaps_w, float *q_out, float *mdk_out) {
+    const int blocks = (n + 63) / 64;
+    const size_t lds = similarity_lds_bytes(m);
+    if (lds <= 160 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        similarity_kernel<true><<<blocks, 64, lds, s>>>(codes4, m, n, ld, wmat, ldw,
+                                                        reinterpret_cast<const f32x2 *>(tab), gaps_w, q_out, mdk_out);
+    } else {
+        similarity_kernel<false><<<blocks, 64, 7424, s>>>(codes4, m, n, ld, wmat, ldw,
+                                                          reinterpret_cast<const f32x2 *>(tab), gaps_w, q_out, mdk_out);
+    }
+    return 0;
+}
+
+void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
+                    const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good) {
+    overlap_colmask_kernel<<<(nchunk * 32 + 255) / 256, 256, 0, s>>>(gaps, indets, m, n, need, col_ok, nchunk);
+    overlap_rows_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, rep4(indet), col_ok, nchunk, good);
+}
+
+void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,
+                       int32_t *row_nongap) {
+    row_nongap_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, keep_res, row_nongap);
+}
+
+void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,
+                       int32_t *col_nongap) {
+    dim3 grid((n + 255) / 256, (m + 63) / 64);
+    col_nongap_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, keep_seq, col_nongap);
+}
+
+void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, int32_t *lengths,
+                       unsigned long long *hashes) {
+    row_digest_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, lengths, hashes);
+}
+
+void launch_rows_equal(hipStream_t s, const uint8_t *raw, int n, int64_t ld, const int32_t *pairs, int npairs,
+                       int32_t *equal) {
+    if (npairs > 0) rows_equal_kernel<<<npairs, 64, 0, s>>>(raw, n, ld, pairs, npairs, equal);
+}
+
+}  // namespace msak

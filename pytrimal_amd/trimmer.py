@@ -1,0 +1,310 @@
+"""Trimmer classes: the callers of the statistics path.
+
+Mirror of ``pytrimal.BaseTrimmer`` and its four subclasses
+(``/root/reference/src/pytrimal/_trimal.pyx:1170-1862``): same constructors, keyword validation,
+``repr``, pickle state and ``trim(alignment, matrix=None)`` contract.  What the reference hands to
+``trimAlManager::clean_alignment`` (``_trimal.pyx:1355``) goes to ``msa_trim`` of the HIP library
+instead; the only compute platform of this package is ``"hip"``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .alignment import Alignment, TrimmedAlignment
+from .matrix import SimilarityMatrix
+
+_HIP_RUNTIME_SUPPORT = _lib.device_count() > 0
+_BEST_PLATFORM = "hip" if _HIP_RUNTIME_SUPPORT else None
+
+
+def _check_range(value, name, lo, hi, cast=float):
+    try:
+        v = cast(value)
+    except (TypeError, ValueError):
+        raise TypeError(f"Invalid type for `{name}`: {type(value).__name__}") from None
+    if v < lo or v > hi or v != v:
+        raise ValueError(f"Invalid value for `{name}`: {v!r}")
+    return v
+
+
+def _check_positive(value, name, cast=int):
+    try:
+        v = cast(value)
+    except (TypeError, ValueError):
+        raise TypeError(f"Invalid type for `{name}`: {type(value).__name__}") from None
+    if v <= 0:
+        raise ValueError(f"Invalid value for `{name}`: {v!r}")
+    return v
+
+
+class BaseTrimmer:
+    """A sequence alignment trimmer.  Subclasses are configured through their constructor and
+    all provide the same `trim` method."""
+
+    def __init__(self, *, platform="detect"):
+        if platform == "detect":
+            self._platform = _BEST_PLATFORM
+        elif platform == "hip":
+            if not _lib.device_count():
+                raise RuntimeError("Cannot run HIP kernels on this machine (no gfx950 device or library missing)")
+            self._platform = "hip"
+        elif platform is None:
+            self._platform = None
+        elif isinstance(platform, str):
+            raise ValueError(f"Unsupported platform on this architecture: {platform!r}")
+        else:
+            raise TypeError(f"expected str or None, found {type(platform).__name__}")
+
+    def __repr__(self):
+        arg = f"platform={self.platform!r}" if self._platform != _BEST_PLATFORM else ""
+        return f"{type(self).__name__}({arg})"
+
+    def __getstate__(self):
+        return {"platform": self.platform}
+
+    def __setstate__(self, state):
+        try:
+            BaseTrimmer.__init__(self, platform=state["platform"])
+        except (ValueError, RuntimeError):
+            BaseTrimmer.__init__(self, platform="detect")
+
+    @property
+    def platform(self):
+        """`str` or `None`: The compute platform for this trimmer."""
+        return self._platform
+
+    # subclasses fill the C parameter block (the trimAlManager fields of `_configure_manager`)
+    def _configure(self, params):
+        pass
+
+    def trim(self, alignment, matrix=None):
+        """Trim the provided alignment and return a `TrimmedAlignment`.
+
+        Re-entrant: each thread works on its own device context and stream.
+        """
+        if not isinstance(alignment, Alignment):
+            raise TypeError(f"expected Alignment, found {type(alignment).__name__}")
+        if matrix is not None and not isinstance(matrix, SimilarityMatrix):
+            raise TypeError(f"expected SimilarityMatrix, found {type(matrix).__name__}")
+        if self._platform != "hip":
+            raise RuntimeError(
+                "this build computes the alignment statistics on an MI355X only: no CPU platform exists "
+                "(platform=None / no visible device); construct the trimmer with platform='hip' on a GPU host")
+        # a TrimmedAlignment is first materialised to its kept sequences / residues (_trimal.pyx:1324-1327)
+        dense = alignment._dense()
+        names = alignment.names
+        m, n = dense.shape
+        ty = alignment._alignment_type()
+        indet = ord("X") if (ty & 4) else ord("N")
+        if matrix is None:
+            # create_or_use_similarity_matrix; an undetected type falls back to the AA matrix (:1342-1352)
+            if ty & 4 or ty == 0:
+                matrix = SimilarityMatrix.aa()
+            else:
+                matrix = SimilarityMatrix.nt(degenerated=bool(ty & 8))
+
+        params = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
+        self._configure(params)
+        vhash = np.ascontiguousarray(matrix._vhash, dtype=np.int32)
+        dist = np.ascontiguousarray(matrix._dist, dtype=np.float32)
+        params.vhash = vhash.ctypes.data_as(ctypes.c_void_p)
+        params.dist = dist.ctypes.data_as(ctypes.c_void_p)
+        params.npos = len(matrix)
+
+        if m == 0 or n == 0:
+            keep_res, keep_seq = np.ones(n, dtype=bool), np.ones(m, dtype=bool)
+        else:
+            ctx = _lib.thread_context()
+            ctx.upload(dense, indet)
+            keep_res, keep_seq, _info = ctx.trim(params)
+        return TrimmedAlignment._from_parts(names, dense, alignment._datatype, keep_seq, keep_res)
+
+
+class AutomaticTrimmer(BaseTrimmer):
+    """A sequence alignment trimmer with automatic parameter detection."""
+
+    METHODS = frozenset({
+        "strict", "strictplus", "gappyout", "nogaps", "noallgaps", "automated1", "automated2",
+        "noduplicateseqs",
+    })
+
+    def __init__(self, method="strict", *, platform="detect"):
+        super().__init__(platform=platform)
+        if not isinstance(method, str):
+            raise TypeError(f"expected str, found {type(method).__name__}")
+        if method not in self.METHODS:
+            raise ValueError(f"Invalid value for `method`: {method!r}")
+        self.method = method
+
+    def __repr__(self):
+        args = [repr(self.method)]
+        if self._platform != _BEST_PLATFORM:
+            args.append(f"platform={self.platform!r}")
+        return f"{type(self).__name__}({', '.join(args)})"
+
+    def __getstate__(self):
+        return {"method": self.method, "platform": self.platform}
+
+    def __setstate__(self, state):
+        BaseTrimmer.__setstate__(self, state)
+        self.method = state["method"]
+
+    def _configure(self, params):
+        params.method = _lib.METHOD_CODES[self.method]
+
+
+class ManualTrimmer(BaseTrimmer):
+    """A sequence alignment trimmer with manually defined thresholds."""
+
+    def __init__(self, *, gap_threshold=None, gap_absolute_threshold=None, similarity_threshold=None,
+                 conservation_percentage=None, window=None, gap_window=None, similarity_window=None,
+                 platform="detect"):
+        super().__init__(platform=platform)
+        self._gap_threshold = -1
+        self._gap_absolute_threshold = -1
+        self._similarity_threshold = -1
+        self._conservation_percentage = -1
+        self._window = -1
+        self._gap_window = -1
+        self._similarity_window = -1
+        if gap_threshold is not None and gap_absolute_threshold is not None:
+            raise ValueError("Cannot specify both `gap_threshold` and `gap_absolute_threshold`")
+        if window is not None and (gap_window is not None or similarity_window is not None):
+            raise ValueError("Cannot specify both `window` and a specific window argument")
+        if gap_threshold is not None:
+            # stored as the maximum gap FRACTION in float32, like the reference's `cdef float` (:1589)
+            self._gap_threshold = float(np.float32(1) - np.float32(_check_range(gap_threshold, "gap_threshold", 0, 1)))
+        if gap_absolute_threshold is not None:
+            self._gap_absolute_threshold = _check_positive(gap_absolute_threshold, "gap_absolute_threshold")
+        if similarity_threshold is not None:
+            self._similarity_threshold = float(np.float32(_check_range(similarity_threshold, "similarity_threshold", 0, 1)))
+        if conservation_percentage is not None:
+            self._conservation_percentage = float(np.float32(
+                _check_range(conservation_percentage, "conservation_percentage", 0, 100)))
+        if window is not None:
+            self._window = _check_positive(window, "window")
+        if gap_window is not None:
+            self._gap_window = _check_positive(gap_window, "gap_window")
+        if similarity_window is not None:
+            self._similarity_window = _check_positive(similarity_window, "similarity_window")
+
+    def __repr__(self):
+        args = []
+        if self._gap_threshold != -1:
+            args.append(f"gap_threshold={float(np.float32(1) - np.float32(self._gap_threshold))!r}")
+        if self._gap_absolute_threshold != -1:
+            args.append(f"gap_absolute_threshold={self._gap_absolute_threshold!r}")
+        if self._similarity_threshold != -1:
+            args.append(f"similarity_threshold={self._similarity_threshold!r}")
+        if self._conservation_percentage != -1:
+            args.append(f"conservation_percentage={self._conservation_percentage!r}")
+        if self._window != -1:
+            args.append(f"window={self._window!r}")
+        if self._gap_window != -1:
+            args.append(f"gap_window={self._gap_window!r}")
+        if self._similarity_window != -1:
+            args.append(f"similarity_window={self._similarity_window!r}")
+        if self._platform != _BEST_PLATFORM:
+            args.append(f"platform={self.platform!r}")
+        return f"{type(self).__name__}({', '.join(args)})"
+
+    def __getstate__(self):
+        return {
+            "platform": self.platform,
+            "gap_threshold": self._gap_threshold,
+            "gap_absolute_threshold": self._gap_absolute_threshold,
+            "similarity_threshold": self._similarity_threshold,
+            "conservation_percentage": self._conservation_percentage,
+            "window": self._window,
+            "gap_window": self._gap_window,
+            "similarity_window": self._similarity_window,
+        }
+
+    def __setstate__(self, state):
+        BaseTrimmer.__setstate__(self, state)
+        self._gap_threshold = state["gap_threshold"]
+        self._gap_absolute_threshold = state["gap_absolute_threshold"]
+        self._similarity_threshold = state["similarity_threshold"]
+        self._conservation_percentage = state["conservation_percentage"]
+        self._window = state["window"]
+        self._gap_window = state["gap_window"]
+        self._similarity_window = state["similarity_window"]
+
+    def _configure(self, params):
+        params.method = 0
+        params.gap_threshold = self._gap_threshold
+        params.gap_absolute_threshold = self._gap_absolute_threshold
+        params.similarity_threshold = self._similarity_threshold
+        params.conservation_percentage = self._conservation_percentage
+        params.window = self._window
+        params.gap_window = self._gap_window
+        params.similarity_window = self._similarity_window
+
+
+class OverlapTrimmer(BaseTrimmer):
+    """A sequence alignment trimmer for overlap blocks."""
+
+    def __init__(self, sequence_overlap, residue_overlap, *, platform="detect"):
+        super().__init__(platform=platform)
+        self._sequence_overlap = float(np.float32(_check_range(sequence_overlap, "sequence_overlap", 0, 100)))
+        self._residue_overlap = float(np.float32(_check_range(residue_overlap, "residue_overlap", 0, 1)))
+
+    def __repr__(self):
+        args = [repr(self._sequence_overlap), repr(self._residue_overlap)]
+        if self._platform != _BEST_PLATFORM:
+            args.append(f"platform={self.platform!r}")
+        return f"{type(self).__name__}({', '.join(args)})"
+
+    def __getstate__(self):
+        return {"platform": self.platform, "sequence_overlap": self._sequence_overlap,
+                "residue_overlap": self._residue_overlap}
+
+    def __setstate__(self, state):
+        BaseTrimmer.__setstate__(self, state)
+        self._sequence_overlap = state["sequence_overlap"]
+        self._residue_overlap = state["residue_overlap"]
+
+    def _configure(self, params):
+        params.method = 0
+        params.residue_overlap = self._residue_overlap
+        params.sequence_overlap = self._sequence_overlap
+
+
+class RepresentativeTrimmer(BaseTrimmer):
+    """A sequence alignment trimmer for selecting representative sequences."""
+
+    def __init__(self, clusters=None, identity_threshold=None, *, platform="detect"):
+        super().__init__(platform=platform)
+        self._clusters = -1
+        self._identity_threshold = -1
+        if clusters is not None and identity_threshold is not None:
+            raise ValueError("Cannot specify both `clusters` and `identity_threshold`")
+        if clusters is not None:
+            self._clusters = _check_positive(clusters, "clusters")
+        if identity_threshold is not None:
+            self._identity_threshold = float(np.float32(_check_range(identity_threshold, "identity_threshold", 0, 1)))
+
+    def __repr__(self):
+        args = []
+        if self._clusters != -1:
+            args.append(f"clusters={self._clusters!r}")
+        elif self._identity_threshold != -1:
+            args.append(f"identity_threshold={self._identity_threshold!r}")
+        if self._platform != _BEST_PLATFORM:
+            args.append(f"platform={self.platform!r}")
+        return f"{type(self).__name__}({', '.join(args)})"
+
+    def __getstate__(self):
+        return {"platform": self.platform, "clusters": self._clusters,
+                "identity_threshold": self._identity_threshold}
+
+    def __setstate__(self, state):
+        BaseTrimmer.__setstate__(self, state)
+        self._clusters = state["clusters"]
+        self._identity_threshold = state["identity_threshold"]
+
+    def _configure(self, params):
+        params.method = 0
+        params.clusters = self._clusters
+        params.max_identity = self._identity_threshold

@@ -1,0 +1,179 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bit-exact for every integer output (gap counts, hit/dst, masks) and for the float32 identity /
+weight matrices and the similarity quotient Q (the reference's sequential accumulation order is
+reproduced); MDK = exp(-Q) is held to the 1e-6 absolute tolerance BASELINE.json states.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import EXAMPLE_001, OVERLAP_EXAMPLE, data_path, edge_msa
+from pytrimal_amd import _lib
+from pytrimal_amd.synth import synth_msa
+
+pytestmark = pytest.mark.gpu
+
+MDK_TOL = 1e-6  # BASELINE.json north_star: "within 1e-6 for float similarity"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+def load_fixture(name):
+    _, seqs = oracle.read_fasta(data_path(name))
+    return oracle.pack(seqs)
+
+
+def all_stats(ctx, a, indet=ord("X"), matrix=None):
+    """Run every statistic on the device and on the oracle; compare."""
+    m, n = a.shape
+    ctx.upload(a, indet)
+    g, x = ctx.gaps(with_indet=True)
+    og, _, _, _ = oracle.gaps(a)
+    assert np.array_equal(g, og)
+    assert np.array_equal(x, (a == indet).sum(axis=0))
+    hit, dst = ctx.pair_counts()
+    ohit, odst = oracle.pair_counts(a, indet)
+    assert np.array_equal(hit, ohit)
+    assert np.array_equal(dst, odst)
+    ident, w = ctx.identities()
+    assert np.array_equal(bits(ident), bits(oracle.identities(ohit, odst)))
+    ow = oracle.weights(ohit, odst)
+    assert np.array_equal(bits(w), bits(ow))
+    if m > 1:
+        avg, mx = ctx.identity_stats()
+        _, oavg, omx = oracle.select_method(oracle.identities(ohit, odst))
+        assert bits(avg) == bits(oavg) and bits(mx) == bits(omx)
+    vhash, dist = matrix if matrix is not None else oracle.aa_matrix()
+    try:
+        omdk, oq = oracle.similarity(a, ow, og, vhash, dist, indet)
+    except oracle.OracleError as err:
+        with pytest.raises(ValueError):
+            ctx.similarity(vhash, dist)
+        return err
+    mdk, q = ctx.similarity(vhash, dist)
+    assert np.array_equal(bits(q), bits(oq)), "similarity quotient must be bit-exact (reference order)"
+    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL if n else True
+    for thr in (0.5, 0.8):
+        ov = ctx.overlap(thr)
+        assert np.array_equal(bits(ov), bits(oracle.overlap(a, thr, indet)))
+    return None
+
+
+def test_example_001(ctx):
+    all_stats(ctx, oracle.pack(EXAMPLE_001))
+
+
+def test_overlap_docstring_example(ctx):
+    a = oracle.pack(OVERLAP_EXAMPLE)
+    err = all_stats(ctx, a)
+    assert err is None
+
+
+def test_enog(ctx, enog):
+    all_stats(ctx, enog[2])
+
+
+def test_lowercase_fixture(ctx):
+    # PF12574.full.afa has lower-case residues: raw-byte identity vs upper-cased similarity
+    names, seqs = oracle.read_fasta(data_path("PF12574.full.afa"))
+    a = oracle.pack(seqs)
+    all_stats(ctx, a)
+
+
+def test_halorhodopsin(ctx):
+    all_stats(ctx, load_fixture("halorhodopsin.afa"))
+
+
+def test_edge_symbols_raise_like_the_oracle(ctx):
+    # B / Z / lower-case x are not in the 20-letter BLOSUM62 alphabet -> UndefinedSymbol
+    err = all_stats(ctx, edge_msa())
+    assert err is not None and err.code == oracle.E_UNDEFINED_SYMBOL
+
+
+def test_edge_symbols_with_wide_matrix(ctx):
+    # same data with an alphabet that defines every letter: full numeric comparison
+    alphabet = "ABCDEFGHIKLMNPQRSTVWXYZ"
+    r = np.random.default_rng(5)
+    sim = r.integers(-4, 9, (len(alphabet), len(alphabet))).astype(np.float32)
+    sim = (sim + sim.T) / 2
+    a = edge_msa()
+    a[a == ord("x")] = ord("X")
+    err = all_stats(ctx, a, matrix=oracle.make_matrix(sim, alphabet))
+    assert err is None
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 40), (2, 1), (2, 5), (3, 31), (3, 33), (5, 64), (63, 100),
+                                 (64, 64), (65, 129), (127, 200), (129, 95), (130, 257), (200, 33)])
+def test_ragged_sizes(ctx, m, n):
+    a = synth_msa(m, n, 100 + m * 7 + n)
+    all_stats(ctx, a)
+
+
+def test_all_gap_and_single_residue_columns(ctx):
+    a = synth_msa(40, 120, 3)
+    a[:, 5] = ord("-")
+    a[:, 6] = ord("-")
+    a[3, 6] = ord("A")       # one residue only: den == 0 -> MDK 0
+    a[:, 7] = ord("X")
+    a[:, 8] = ord("A")       # fully conserved: Q == 0 -> MDK 1
+    all_stats(ctx, a)
+
+
+def test_incorrect_symbol_position(ctx):
+    a = synth_msa(20, 90, 4)
+    a[a == ord("X")] = ord("A")
+    a[7, 40] = ord("*")      # not a letter -> IncorrectSymbol
+    a[9, 40] = ord("B")
+    a[2, 60] = ord("B")
+    ctx.upload(a, ord("X"))
+    vhash, dist = oracle.aa_matrix()
+    hit, dst = oracle.pair_counts(a)
+    g, _, _, _ = oracle.gaps(a)
+    with pytest.raises(oracle.OracleError) as o:
+        oracle.similarity(a, oracle.weights(hit, dst), g, vhash, dist)
+    assert o.value.code == oracle.E_INCORRECT_SYMBOL and o.value.detail[:2] == (7, 40)
+    with pytest.raises(ValueError, match="incorrect"):
+        ctx.similarity(vhash, dist)
+
+
+def test_windowed_gap_cut_vector(ctx):
+    a = synth_msa(50, 300, 21)
+    ctx.upload(a, ord("X"))
+    g = ctx.gaps()
+    gw = oracle.gaps_window(g, 3)
+    vhash, dist = oracle.aa_matrix()
+    hit, dst = oracle.pair_counts(a)
+    omdk, oq = oracle.similarity(a, oracle.weights(hit, dst), gw, vhash, dist)
+    mdk, q = ctx.similarity(vhash, dist, gw)
+    assert np.array_equal(bits(q), bits(oq))
+    assert np.max(np.abs(mdk - omdk)) <= MDK_TOL
+
+
+def test_c2_full_size(ctx):
+    # BASELINE config 2: 500 x 2000, every statistic against the oracle
+    all_stats(ctx, synth_msa(500, 2000, 1002))
+
+
+def test_attach_device_buffer(ctx):
+    torch = pytest.importorskip("torch")
+    a = synth_msa(70, 333, 9)
+    ld = 384
+    buf = torch.zeros((70, ld), dtype=torch.uint8, device="cuda:0")
+    buf[:, :333] = torch.from_numpy(a).to("cuda:0")
+    buf[:, 333:] = 0x41  # garbage in the padding must not matter
+    torch.cuda.synchronize()
+    ctx.attach(buf.data_ptr(), 70, 333, ld, ord("X"))
+    assert np.array_equal(ctx.gaps(), oracle.gaps(a)[0])
+    hit, dst = ctx.pair_counts()
+    ohit, odst = oracle.pair_counts(a)
+    assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
