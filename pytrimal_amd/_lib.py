@@ -4,6 +4,10 @@ This is the only way the package computes anything: there is no CPU fallback.  I
 library is missing or no MI355X device is visible, the trimmers fail loudly with `RuntimeError`
 (the reference does the same for a SIMD platform that is not available,
 ``/root/reference/src/pytrimal/_trimal.pyx:1205-1218``).
+
+Note for processes that also use PyTorch-ROCm (bench.py, pytrimal_amd.batch): ``import torch``
+BEFORE the first call into this module.  The torch wheel bundles its own ``libamdhip64.so``; if
+the system runtime is mapped first (through this library), torch later finds no GPU.
 """
 import ctypes
 import os

@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch's wheel bundles its own libamdhip64; it has to be the first HIP runtime mapped into the
+# process, otherwise torch later reports "No HIP GPUs are available" (two runtimes, one KFD).
+# libmsastat_hip.so then binds to the already-loaded runtime (same SONAME).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
