@@ -336,20 +336,22 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         gw_dev = c->gaps_w.p;
     }
-    HIPCHK(c, c->codes4.reserve((size_t)G * c->ld + 64));
+    (void)G;
+    const int G8 = (m + 7) / 8;
+    HIPCHK(c, c->codes4.reserve((size_t)4 * (G8 + 1) * c->ld + 64));  // [G8 + 1][ld] x 16 B
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     {
         ProfScope ps(c, "encode");
-        msak::launch_sim_encode(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codes4.p, c->errkey.p);
+        msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes4.p, c->errkey.p);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->q.reserve((size_t)n + 64));
     HIPCHK(c, c->mdk.reserve((size_t)n + 64));
     {
         ProfScope ps(c, "sim");
-        int e = msak::launch_similarity(c->stream, c->codes4.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, gw_dev,
-                                        c->q.p, c->mdk.p);
+        int e = msak::launch_similarity_pc(c->stream, c->codes4.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
+                                           gw_dev, c->q.p, c->mdk.p);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     HIPCHK(c, hipGetLastError());
@@ -638,6 +640,11 @@ int msa_identities(msa_ctx *c, float *ident, float *w) {
         HIPCHK(c, hipMemcpy2DAsync(w, row, c->wmat.p, (size_t)c->ldw * sizeof(float), row, c->m, hipMemcpyDeviceToHost,
                                    c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (w) {  // the device keeps W strictly upper triangular; the ABI returns the symmetric matrix
+        const size_t m = c->m;
+        for (size_t i = 0; i < m; ++i)
+            for (size_t j = i + 1; j < m; ++j) w[j * m + i] = w[i * m + j];
+    }
     return MSA_OK;
 }
 

@@ -7,13 +7,15 @@
 //                                      (chunk c, row r) is column 32c+b.  Row index is fastest, so a
 //                                      wave whose lanes own 64 consecutive rows loads 256 B per plane.
 //   gaps / indet [n]             i32  per-column '-' / indetermination counts
-//   ident, w [m][ldw]            f32  pairwise identity and 1-identity (ldw % 64 == 0, pad = 0)
+//   ident [m][ldw]               f32  pairwise identity, symmetric (ldw % 64 == 0, pad = 0)
+//   w     [m][ldw]               f32  1 - identity, STRICTLY UPPER triangular (0 elsewhere)
 //   codes4  [ceil(m/4)][ld]      u32  per column, 4 consecutive rows' similarity-table offsets
 //   tab     [29][32]             f32x2 {distance, both-valid} indexed by (row code, column code)
 //
 // No MFMA anywhere: this is integer / lookup / ordered-fp32 work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msastat_kernels.h"
 
@@ -196,10 +198,10 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
                     ident[(size_t)i * ldw + j] = v;
                     ident[(size_t)j * ldw + i] = v;
                 }
-                if (wmat) {
-                    const float v = diag ? 0.0f : 1.0f - r;
-                    wmat[(size_t)i * ldw + j] = v;
-                    wmat[(size_t)j * ldw + i] = v;
+                if (wmat && i != j) {  // strictly upper triangular: the similarity pass reads W[j][k], k > j
+                    const float v = 1.0f - r;
+                    if (i < j) wmat[(size_t)i * ldw + j] = v;
+                    else wmat[(size_t)j * ldw + i] = v;
                 }
             }
         }
@@ -361,6 +363,293 @@ __global__ __launch_bounds__(64) void similarity_kernel(const uint32_t *__restri
         }
         if (q_out) q_out[c] = q;
         mdk_out[c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity_mdk, producer/consumer form (the one msa_similarity launches).
+//
+// The float32 sums of one column are a strictly sequential chain, so the only way to go faster
+// than one-wave-does-everything is to strip the chain-carrying wave down to the chain itself.
+// One workgroup = 64 columns = 1 consumer wave + NP producer waves (two waves per SIMD: a lone
+// wave issues one instruction per ~4.75 cycles whatever its type, so instruction count per wave,
+// not ALU width, is the currency here):
+//   producers  walk the (j,k) pair sequence in units of 8 consecutive k ("octs"), look up
+//              {D[a_j][a_k], valid} for their lane's column, multiply by the wave-uniform
+//              W[j][k] (separate rounding), and store {x, w_eff} pairs into an LDS ring;
+//   consumer   reads the ring in pair order and does ONE v_pk_add_f32 per step:
+//              {num, den} += {x, w_eff}   -- bit-identical to the reference's two scalar adds
+//              (a skipped pair contributes {+0, +0}, which leaves both sums unchanged).
+// Each producer keeps a private, lane-interleaved copy of the table row of its current j
+// ([entry][lane] x 8 B: every lane owns its bank pair, so the per-step gather is conflict-free).
+// codes16 [ceil(m/8) + 1][ld] x 8 u16: entry * 512 + (column & 63) * 8, i.e. the byte offset
+// into such a slice; entry `npos` is the all-zero entry of skipped residues; the extra last
+// row is all-skipped and is what producers read once they run past the end of the sequence.
+// W is strictly upper triangular, so the rows k <= j of a row's first oct need no masking.
+// ------------------------------------------------------------------------------------------
+// Rounds are row-aligned: a round (ROUND_OCTS octs) never spans two rows j -- the tail of a row
+// is padded with null octs that read the all-skipped codes row -- so every producer is always on
+// the same row, positions are a function of the round alone, and ONE double-buffered table slice
+// (row parity) serves the whole workgroup.  The padding costs ~ROUND_OCTS/2 octs per row.
+constexpr int SIM_NP = 7;    // producer waves (+1 consumer = 8 waves = 2 per SIMD)
+constexpr int SIM_OCTS = 2;  // octs per producer per round
+constexpr int SIM_ROUND_OCTS = SIM_NP * SIM_OCTS;       // 14 octs = 112 steps per round
+constexpr int SIM_PAIRS = SIM_ROUND_OCTS * 4;           // float4 {x0,w0,x1,w1} per lane per round
+constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29][32] x 8 B
+constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
+__host__ __device__ constexpr int sim_slice_bytes(int npos) { return (npos + 1) * 512; }
+__host__ __device__ constexpr int sim_lds_bytes(int npos) {
+    return SIM_MASTER_BYTES + 2 * sim_slice_bytes(npos) + SIM_RING_BYTES;  // 151808 at npos = 28
+}
+
+__global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                           const uint8_t *__restrict__ lut_g, int npos,
+                                                           const int32_t *__restrict__ gaps_w,
+                                                           uint4 *__restrict__ codes16,
+                                                           unsigned long long *__restrict__ err_key) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ld) return;
+    const int g = blockIdx.y;  // 0 .. G8: the extra row G8 lies past row m-1 => all skipped
+    bool skipcol = true;
+    if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+    uint32_t half[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = g * 8 + r;
+        uint32_t idx = (uint32_t)npos;
+        if (row < m && c < n) {
+            const uint32_t byte = raw[(size_t)row * ld + c];
+            const uint32_t code = lut[byte];  // idx * 8, 224 = skipped, 0xFE / 0xFF = bad symbol
+            if (code >= 0xFEu) {
+                if (!skipcol) {
+                    const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
+                                                   ((unsigned long long)(code & 1u) << 8) | byte;
+                    atomicMin(err_key, key);
+                }
+            } else if (code != 224u) {
+                idx = code >> 3;
+            }
+        }
+        half[r] = idx * 512u + (uint32_t)(c & 63) * 8u;
+    }
+    codes16[(size_t)g * ld + c] = make_uint4(half[0] | (half[1] << 16), half[2] | (half[3] << 16),
+                                             half[4] | (half[5] << 16), half[6] | (half[7] << 16));
+}
+
+__device__ __forceinline__ void sim_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Diagnostics (MSA_SIM_MODE bit 6): per-phase cycle sums of workgroup 0, [wave][phase].
+__device__ unsigned long long g_sim_stamps[8 * 8];
+__device__ __forceinline__ unsigned long long sim_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// everything a producer needs for one oct, fetched one round ahead
+struct SimOct {
+    uint4 codes;  // codes16 of rows 8g..8g+7 (the all-skipped row G8 for a null oct): VMEM
+    float w[8];   // W[j][8g..8g+7], wave-uniform: scalar loads into SGPRs (a 64-lane broadcast
+                  // load of 16 B costs the vector memory pipe as much as a full 1-KiB load)
+};
+
+// round position: row j and first oct gb of the round; rows own the octs (j+1)>>3 .. G8-1
+struct SimPos {
+    int j, gb;
+};
+__device__ __forceinline__ SimPos sim_next(SimPos p, int G8) {
+    p.gb += SIM_ROUND_OCTS;
+    if (p.gb >= G8) {
+        ++p.j;
+        p.gb = (p.j + 1) >> 3;
+    }
+    return p;
+}
+
+__device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16,
+                                             int m, int64_t ld, const float *__restrict__ wmat, int ldw, int npos,
+                                             int lane, int c, int rounds, int mode) {
+    const f32x2 *master = reinterpret_cast<const f32x2 *>(smem);
+    unsigned char *slices = smem + SIM_MASTER_BYTES;
+    const int slice_bytes = sim_slice_bytes(npos);
+    float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * slice_bytes);
+    const int G8 = (m + 7) >> 3;
+    const uint4 *col = codes16 + c;
+    const float *wbase = wmat;
+
+    auto fetch = [&](SimOct (&u)[SIM_OCTS], SimPos p) {  // branch-free: null octs read the skipped row
+        const bool past = p.j >= m - 1;
+        const int jr = past ? 0 : p.j;
+        const float *wrow = wbase + (size_t)jr * ldw;
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const int g = p.gb + P * SIM_OCTS + t;
+            int gc = (past || g >= G8) ? G8 : g;
+            const int gw = g >= G8 ? G8 - 1 : g;
+            if (mode & 32) gc = P;  // diagnostics: always the same few cache lines
+            u[t].codes = col[(size_t)gc * ld];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) u[t].w[s] = wrow[8 * gw + s];
+        }
+    };
+    // Scalar loads and LDS traffic share lgkmcnt, and scalar data returns out of order: the
+    // only cheap place to wait for the W values is where the LDS queue is empty anyway, i.e.
+    // right after a barrier.  Touching them there makes the compiler put its wait there.
+    auto settle = [&](const SimOct (&u)[SIM_OCTS]) {
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) asm volatile("" ::"s"(u[t].w[s]));
+    };
+    // this lane's table row index for row jn (its residue in that row), npos when skipped
+    auto load_cj = [&](int jn) -> uint32_t {
+        if (jn >= m - 1) return (uint32_t)npos << 9;
+        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
+        return cj[jn & 7];
+    };
+    // producers share the copy of table row idx into slice[jn & 1]: entry e -> [e][lane]
+    auto refresh = [&](int jn, uint32_t cjcode) {
+        const uint32_t idx = cjcode >> 9;
+        f32x2 *sl = reinterpret_cast<f32x2 *>(slices + (jn & 1) * slice_bytes) + lane;
+        const f32x2 *mrow = master + idx * 32;
+        for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
+    };
+    auto gather = [&](const SimOct &o, const unsigned char *slice, f32x2 (&tv)[8]) {
+        const uint32_t cw[4] = {o.codes.x, o.codes.y, o.codes.z, o.codes.w};
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            tv[2 * pp] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] & 0xFFFFu));
+            tv[2 * pp + 1] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] >> 16));
+        }
+    };
+    auto emit = [&](const SimOct &o, const f32x2 (&tv)[8], float4 *out) {
+        // {x, w_eff} = {D, valid} * {W, W}: one v_pk_mul_f32 per step, W broadcast from the low or
+        // the high half of an aligned register pair through op_sel (no moves, no scratch)
+        const f32x2 wp[4] = {{o.w[0], o.w[1]}, {o.w[2], o.w[3]}, {o.w[4], o.w[5]}, {o.w[6], o.w[7]}};
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            f32x2 xa, xb;
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tv[2 * pp]), "s"(wp[pp]));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tv[2 * pp + 1]), "s"(wp[pp]));
+            out[pp * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
+        }
+    };
+    auto produce = [&](const SimOct (&u)[SIM_OCTS], int j, int r) {
+        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
+        const unsigned char *slice = slices + (j & 1) * slice_bytes;
+        if (mode & 1) return;
+        f32x2 tv[SIM_OCTS][8];
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], slice, tv[t]);
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) emit(u[t], tv[t], out + t * 4 * 64);
+    };
+
+    SimPos pos = {0, 0};
+    refresh(0, load_cj(0));
+    uint32_t cj_next = load_cj(1);  // code of the next row, loaded a whole row ahead of its use
+    sim_barrier();                  // slice[0] complete
+    // Loads run TWO rounds ahead of their use (three register sets): under load an L2 hit takes
+    // about as long as a whole round, so one round of distance leaves the latency exposed.
+    SimOct a[SIM_OCTS], b[SIM_OCTS], d[SIM_OCTS];
+    SimPos pos1 = sim_next(pos, G8);
+    fetch(a, pos);
+    fetch(b, pos1);
+    const bool stamp = (mode & 64) && blockIdx.x == 0;
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+    auto round = [&](SimOct (&cur)[SIM_OCTS], SimOct (&far)[SIM_OCTS], int r) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (stamp) t0 = sim_now();
+        settle(cur);
+        if (stamp) t1 = sim_now();
+        const SimPos pos2 = sim_next(pos1, G8);
+        fetch(far, pos2);
+        if (stamp) t2 = sim_now();
+        produce(cur, pos.j, r);
+        if (stamp) t3 = sim_now();
+        if (pos1.j != pos.j) {  // last round of row j (wave- and workgroup-uniform): stage row j+1
+            refresh(pos1.j, cj_next);
+            cj_next = load_cj(pos1.j + 1);
+        }
+        if (stamp) t4 = sim_now();
+        sim_barrier();
+        if (stamp) {
+            const unsigned long long t5 = sim_now();
+            acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += t5 - t4;
+        }
+        pos = pos1;
+        pos1 = pos2;
+    };
+    for (int r = 0; r < rounds; r += 3) {
+        round(a, d, r);
+        if (r + 1 < rounds) round(b, a, r + 1);
+        if (r + 2 < rounds) round(d, b, r + 2);
+    }
+    if (stamp && lane == 0)
+        for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
+    sim_barrier();  // the consumer's drain round
+}
+
+__global__ __launch_bounds__(64 * (SIM_NP + 1)) void similarity_pc_kernel(
+    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
+    const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int rounds, int mode,
+    float *__restrict__ q_out, float *__restrict__ mdk_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + lane;  // < ld
+    {
+        f32x2 *master = reinterpret_cast<f32x2 *>(smem);
+        for (int t = threadIdx.x; t < 29 * 32; t += 64 * (SIM_NP + 1)) master[t] = tab_g[t];
+    }
+    __syncthreads();
+    if (wave != 0) {
+        sim_producer(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, rounds, mode);
+    } else {
+        __builtin_amdgcn_s_setprio(3);  // the chain wave wins every issue arbitration on its SIMD
+        const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * sim_slice_bytes(npos));
+        f32x2 acc = {0.0f, 0.0f};  // {num, den}
+        sim_barrier();             // slice[0] staged
+        sim_barrier();             // round 0 produced
+        const bool stamp = (mode & 64) && blockIdx.x == 0;
+        unsigned long long tw = 0, tb = 0;
+        for (int r = 1; r <= rounds; ++r) {
+            unsigned long long t0 = 0, t1 = 0;
+            if (stamp) t0 = sim_now();
+            const float4 *in = ring + ((r - 1) & 1) * SIM_PAIRS * 64 + lane;
+            if (!(mode & 2))
+#pragma unroll
+                for (int p = 0; p < SIM_PAIRS; ++p) {
+                    const float4 v = in[p * 64];
+                    acc += f32x2{v.x, v.y};
+                    acc += f32x2{v.z, v.w};
+                }
+            if (stamp) t1 = sim_now();
+            sim_barrier();
+            if (stamp) {
+                tw += t1 - t0;
+                tb += sim_now() - t1;
+            }
+        }
+        if (stamp && lane == 0) {
+            g_sim_stamps[0] = tw;
+            g_sim_stamps[1] = tb;
+            g_sim_stamps[2] = (unsigned long long)rounds;
+        }
+        if (c < n) {
+            const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+            float q = 0.0f, v = 0.0f;
+            if (!skip && acc.y != 0.0f) {
+                q = acc.x / acc.y;
+                v = (float)exp(-(double)q);
+                v = v > 1.0f ? 1.0f : v;
+            }
+            if (q_out) q_out[c] = q;
+            mdk_out[c] = v;
+        }
     }
 }
 
@@ -548,6 +837,39 @@ int launch_similarity(hipStream_t s, const uint32_t *codes4, int m, int n, int64
         similarity_kernel<false><<<blocks, 64, 7424, s>>>(codes4, m, n, ld, wmat, ldw,
                                                           reinterpret_cast<const f32x2 *>(tab), gaps_w, q_out, mdk_out);
     }
+    return 0;
+}
+
+void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
+                         const int32_t *gaps_w, void *codes16, unsigned long long *err_key) {
+    dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
+    sim_encode16_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes16),
+                                             err_key);
+}
+
+// MSA_SIM_MODE (diagnostics only, never set in production): bit0 producers skip gather/emit,
+// bit1 consumer skips the chain
+static int sim_debug_mode() {
+    const char *e = getenv("MSA_SIM_MODE");
+    return e ? atoi(e) : 0;
+}
+
+extern "C" int msa_debug_sim_stamps(unsigned long long *out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sim_stamps), sizeof(unsigned long long) * 64);
+}
+
+int launch_similarity_pc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
+                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out) {
+    const int G8 = (m + 7) / 8;
+    long long rounds = 0;  // row-aligned: every row j takes ceil(octs_j / ROUND_OCTS) rounds
+    for (int j = 0; j + 1 < m; ++j) rounds += (G8 - ((j + 1) >> 3) + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
+    const int lds = sim_lds_bytes(npos);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_pc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    similarity_pc_kernel<<<(n + 63) / 64, 64 * (SIM_NP + 1), lds, s>>>(
+        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, gaps_w,
+        (int)rounds, sim_debug_mode(), q_out, mdk_out);
     return 0;
 }
 

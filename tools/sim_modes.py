@@ -1,0 +1,30 @@
+import os, sys, subprocess, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:
+    import numpy as np
+    from pytrimal_amd import _lib
+    from pytrimal_amd.synth import synth_msa
+    from pytrimal_amd.matrix import SimilarityMatrix
+    m, n = 2000, 10000
+    a = synth_msa(m, n, 1003)
+    ctx = _lib.Context(0)
+    ctx.upload(a, ord("X"))
+    mx = SimilarityMatrix.aa()
+    ctx.similarity(mx._vhash, mx._dist)
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(3): ctx.similarity(mx._vhash, mx._dist)
+    ms, k = ctx.prof_get("sim")
+    print("mode", os.environ.get("MSA_SIM_MODE", "0"), "sim ms", round(ms / k, 3))
+    if int(os.environ.get("MSA_SIM_MODE", "0")) & 64:
+        import ctypes
+        buf = (ctypes.c_uint64 * 64)()
+        ctx.lib.msa_debug_sim_stamps(buf)
+        r = buf[2]
+        print(" consumer: work %.0f  barrier %.0f cycles/round (rounds %d)" % (buf[0] / r, buf[1] / r, r))
+        for p in range(1, 8):
+            v = [buf[p * 8 + k] / r for k in range(5)]
+            print(" producer %d: settle %.0f fetch %.0f produce %.0f refresh %.0f barrier %.0f" % (p - 1, *v))
+else:
+    for mode in (64, 65, 66):
+        env = dict(os.environ, MSA_SIM_MODE=str(mode))
+        subprocess.run([sys.executable, __file__, "x"], env=env)
