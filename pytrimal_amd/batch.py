@@ -1,0 +1,96 @@
+"""Batches of independent alignments across the GPUs of a node.
+
+Alignments are independent units (the reference treats them so: one local `trimAlManager` per
+`trim` call, ``/root/reference/src/pytrimal/_trimal.pyx:1314-1316``, and a thread pool over
+alignments in ``README.md:136-152``), so the path shards at alignment granularity: one process per
+GPU, static round-robin of the alignments over the ranks, no collective inside an alignment.
+The only communication is control-plane sized: an optional broadcast of the trimmer from rank 0
+and a gather of the kept-column / kept-sequence masks to rank 0 (`torch.distributed`, backend
+"nccl" = RCCL on ROCm for device tensors, "gloo" for the CPU tests).
+
+Import order matters in a process that uses PyTorch-ROCm: this module imports torch before the
+HIP library is loaded (see pytrimal_amd._lib).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .alignment import Alignment, TrimmedAlignment
+
+
+def shard_indices(n_items, world_size, rank):
+    """Static round-robin: item i belongs to rank i % world_size."""
+    return list(range(rank, n_items, world_size))
+
+
+def broadcast_trimmer(trimmer, src=0, group=None):
+    """Make every rank use rank `src`'s trimmer (pickle state, a few hundred bytes)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return trimmer
+    box = [trimmer if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def _pack_masks(results):
+    """[(keep_res bool[n], keep_seq bool[m]), ...] -> one uint8 vector."""
+    parts = []
+    for res, seq in results:
+        parts.append(np.asarray(res, dtype=np.uint8))
+        parts.append(np.asarray(seq, dtype=np.uint8))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+
+
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None):
+    """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
+    `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
+    initialised process group it simply trims everything locally.
+
+    `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
+    which have no device).
+    """
+    if trim_fn is None:
+        def trim_fn(ali):
+            return trimmer.trim(ali, matrix)
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    mine = shard_indices(len(alignments), world, rank)
+    local = []
+    for i in mine:
+        t = trim_fn(alignments[i])
+        local.append((np.array(t.residues_mask, dtype=bool), np.array(t.sequences_mask, dtype=bool)))
+    if not distributed or world == 1:
+        return [_rebuild(alignments[i], r, s) for i, (r, s) in zip(mine, local)]
+
+    # every rank knows every shape, so shard payload sizes are known without a size exchange
+    def payload(r):
+        return sum(len(alignments[i].residues) + len(alignments[i].sequences) for i in shard_indices(len(alignments), world, r))
+
+    width = max(payload(r) for r in range(world))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf = torch.zeros(max(width, 1), dtype=torch.uint8, device=device)
+    packed = _pack_masks(local)
+    if packed.size:
+        buf[:packed.size] = torch.from_numpy(packed).to(device)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = [None] * len(alignments)
+    for r in range(world):
+        flat = gathered[r].cpu().numpy()
+        pos = 0
+        for i in shard_indices(len(alignments), world, r):
+            n, m = len(alignments[i].residues), len(alignments[i].sequences)
+            res = flat[pos:pos + n].astype(bool)
+            seq = flat[pos + n:pos + n + m].astype(bool)
+            pos += n + m
+            out[i] = _rebuild(alignments[i], res, seq)
+    return out
+
+
+def _rebuild(alignment, keep_res, keep_seq):
+    dense = alignment._dense()
+    return TrimmedAlignment._from_parts(alignment.names, dense, alignment._datatype, keep_seq, keep_res)

@@ -1,0 +1,223 @@
+"""Host API mirror: constructors, validation, repr, pickle, Alignment views and I/O,
+SimilarityMatrix lookups -- the non-compute parts of the reference's own tests
+(src/pytrimal/tests/test_*_trimmer.py, test_alignment.py, test_similarity_matrix.py)."""
+import io
+import json
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import EXAMPLE_001, EXAMPLE_001_NAMES, data_path
+from pytrimal_amd import (
+    Alignment,
+    AutomaticTrimmer,
+    ManualTrimmer,
+    OverlapTrimmer,
+    RepresentativeTrimmer,
+    SimilarityMatrix,
+    TrimmedAlignment,
+    trimmer as trimmer_mod,
+)
+
+BEST = trimmer_mod._BEST_PLATFORM
+OTHER = None if BEST == "hip" else "nonexistent"
+
+
+def rp(text):
+    """repr with the non-default platform appended, as the reference prints it."""
+    return text
+
+
+def test_automatic_trimmer_validation_and_repr():
+    with pytest.raises(ValueError):
+        AutomaticTrimmer(method="nonsense")
+    with pytest.raises(TypeError):
+        AutomaticTrimmer(method=1)
+    assert repr(AutomaticTrimmer("strict")) == "AutomaticTrimmer('strict')"
+    assert repr(AutomaticTrimmer("automated1")) == "AutomaticTrimmer('automated1')"
+    assert AutomaticTrimmer.METHODS == frozenset({"strict", "strictplus", "gappyout", "nogaps", "noallgaps",
+                                                  "automated1", "automated2", "noduplicateseqs"})
+    if BEST == "hip":
+        assert repr(AutomaticTrimmer("noduplicateseqs", platform=None)) == "AutomaticTrimmer('noduplicateseqs', platform=None)"
+
+
+def test_platform_argument():
+    with pytest.raises(ValueError):
+        AutomaticTrimmer("strict", platform="avx512")
+    t = AutomaticTrimmer("strict", platform=None)
+    assert t.platform is None
+    if BEST != "hip":
+        with pytest.raises(RuntimeError):
+            AutomaticTrimmer("strict", platform="hip")
+    assert AutomaticTrimmer("strict").platform == BEST
+
+
+def test_manual_trimmer_validation_and_repr():
+    for kw in (dict(gap_threshold=100), dict(gap_threshold=-1), dict(gap_absolute_threshold=-1),
+               dict(conservation_percentage=1000), dict(conservation_percentage=-2),
+               dict(gap_threshold=0.5, gap_absolute_threshold=0.5), dict(window=5, gap_window=5),
+               dict(window=3, gap_window=3, similarity_window=3)):
+        with pytest.raises(ValueError):
+            ManualTrimmer(**kw)
+    assert repr(ManualTrimmer(gap_threshold=0.5)) == "ManualTrimmer(gap_threshold=0.5)"
+    long = ManualTrimmer(gap_absolute_threshold=10, similarity_threshold=0.5, conservation_percentage=50.0,
+                         gap_window=5, similarity_window=5)
+    assert repr(long) == ("ManualTrimmer(gap_absolute_threshold=10, similarity_threshold=0.5, "
+                          "conservation_percentage=50.0, gap_window=5, similarity_window=5)")
+    assert repr(ManualTrimmer(window=5)) == "ManualTrimmer(window=5)"
+
+
+def test_overlap_and_representative_repr_and_validation():
+    assert repr(OverlapTrimmer(80, 0.5)) == "OverlapTrimmer(80.0, 0.5)"
+    assert repr(OverlapTrimmer(50, 1.0)) == "OverlapTrimmer(50.0, 1.0)"
+    with pytest.raises(ValueError):
+        OverlapTrimmer(120, 0.5)
+    with pytest.raises(ValueError):
+        OverlapTrimmer(50, 1.5)
+    assert repr(RepresentativeTrimmer(identity_threshold=0.25)) == "RepresentativeTrimmer(identity_threshold=0.25)"
+    assert repr(RepresentativeTrimmer(clusters=2)) == "RepresentativeTrimmer(clusters=2)"
+    with pytest.raises(ValueError):
+        RepresentativeTrimmer(clusters=2, identity_threshold=0.5)
+    with pytest.raises(ValueError):
+        RepresentativeTrimmer(clusters=0)
+    with pytest.raises(ValueError):
+        RepresentativeTrimmer(identity_threshold=2)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: AutomaticTrimmer("automated1"), lambda: ManualTrimmer(gap_threshold=0.4, window=5),
+    lambda: OverlapTrimmer(40, 0.5), lambda: RepresentativeTrimmer(identity_threshold=0.6),
+    lambda: RepresentativeTrimmer(clusters=4)])
+def test_pickle_roundtrip(make):
+    t = make()
+    u = pickle.loads(pickle.dumps(t))
+    assert type(u) is type(t) and repr(u) == repr(t) and u.__getstate__() == t.__getstate__()
+
+
+def test_pickle_falls_back_when_platform_unavailable():
+    t = AutomaticTrimmer("strict")
+    state = t.__getstate__()
+    state["platform"] = "hip" if BEST != "hip" else "sse2"   # not usable here
+    u = AutomaticTrimmer.__new__(AutomaticTrimmer)
+    u.__setstate__(state)
+    assert u.platform == BEST and u.method == "strict"
+
+
+def test_trim_without_device_fails_loudly():
+    if BEST == "hip":
+        pytest.skip("a GPU is visible")
+    ali = Alignment(EXAMPLE_001_NAMES, EXAMPLE_001)
+    with pytest.raises(RuntimeError, match="no CPU platform"):
+        AutomaticTrimmer("strict").trim(ali)
+    with pytest.raises(TypeError):
+        AutomaticTrimmer("strict").trim("not an alignment")
+
+
+# --- Alignment ---------------------------------------------------------------------------------
+
+def test_alignment_basics():
+    ali = Alignment(EXAMPLE_001_NAMES, EXAMPLE_001)
+    assert ali.names == EXAMPLE_001_NAMES
+    assert len(ali.sequences) == 6 and len(ali.residues) == 46
+    assert ali.sequences[0] == EXAMPLE_001[0] and ali.sequences[-1] == EXAMPLE_001[-1]
+    assert ali.residues[0] == "--A---" and ali.residues[-1] == "IIIIFL"
+    assert sum(s.count("-") for s in ali.sequences) == 43
+    assert ali.sequence_type == "protein"
+    with pytest.raises(IndexError):
+        ali.sequences[6]
+    sub = Alignment(ali.names[:4:2], ali.sequences[:4:2])
+    assert len(sub.sequences) == 2 and sub.sequences[1] == ali.sequences[2]
+    cp = ali.copy()
+    assert cp.names == ali.names and list(cp.sequences) == list(ali.sequences)
+    assert repr(Alignment([b"a"], ["AC"])) == "Alignment(names=[b'a'], sequences=['AC'])"
+
+
+def test_alignment_validation():
+    with pytest.raises(ValueError, match="given 3 names but 2 sequences"):
+        Alignment([b"Sp8", b"Sp10", b"Sp26"], ["GLQIHMMGII", "GLEINMMVII"])
+    with pytest.raises(ValueError, match=r'The sequence "Sp10" has an unknown \(49\) character'):
+        Alignment([b"Sp8", b"Sp10"], ["GLQIHMMGII", "GLEINMM123"])
+    with pytest.raises(ValueError, match="Sequence length mismatch"):
+        Alignment([b"a", b"b"], ["ACGT", "ACG"])
+    with pytest.raises(ValueError, match="invalid `sequence_type`"):
+        Alignment([b"a"], ["ACGT"], sequence_type="peptide")
+    assert Alignment([b"a", b"b"], ["ACGTACGTAA", "ACGTTCGTAA"]).sequence_type == "dna"
+    assert Alignment([b"a", b"b"], ["ACGTACGTAA", "ACGTTCGTAA"], sequence_type="protein").sequence_type == "protein"
+    empty = Alignment([], [])
+    assert len(empty.sequences) == 0 and empty.names == []
+
+
+def test_alignment_load_and_dump(tmp_path):
+    ali = Alignment.load(data_path("ENOG411BWBU.seq40.res60.fasta"))
+    assert len(ali.names) == 209 and len(ali.sequences[0]) == 1227 and ali.names[0] == b"4577.AC195313.3_FGP002"
+    clw = Alignment.load(data_path("example.001.gt90.w3.clw"))
+    assert clw.names == EXAMPLE_001_NAMES and clw.sequences[0] == "IVLGTKSDLFPWNGLQIHMMGII"
+    with open(data_path("example.001.gt90.w3.clw"), "rb") as f:
+        assert Alignment.load(f, "clustal").names == EXAMPLE_001_NAMES
+    with open(data_path("example.001.gt90.w3.clw"), "rb") as f:
+        with pytest.raises(ValueError):
+            Alignment.load(f)
+    with pytest.raises(ValueError):
+        Alignment.load(io.BytesIO(b">a\nAC\n"), "nonsense")
+    with pytest.raises(IsADirectoryError):
+        Alignment.load(str(tmp_path))
+    out = tmp_path / "x.fasta"
+    clw.dump(str(out))
+    back = Alignment.load(str(out))
+    assert back.names == clw.names and list(back.sequences) == list(clw.sequences)
+    again = Alignment.load(io.BytesIO(clw.dumps("clustal").encode()), "clustal")
+    assert list(again.sequences) == list(clw.sequences)
+    with pytest.raises(ValueError):
+        clw.dumps("nonsense")
+
+
+def test_trimmed_alignment_masks():
+    t = TrimmedAlignment([b"Sp8", b"Sp10", b"Sp26"], ["QFSNWV", "KFS--S", "NFA--A"],
+                         sequences_mask=[True, True, False], residues_mask=[True, True, True, False, False, True])
+    assert list(t.names) == [b"Sp8", b"Sp10"] and list(t.sequences) == ["QFSV", "KFSS"]
+    assert t.residues_mask == [True, True, True, False, False, True]
+    assert t.sequences_mask == [True, True, False]
+    assert list(t.residues) == ["QK", "FF", "SS", "VS"]
+    o = t.original_alignment()
+    assert list(o.names) == [b"Sp8", b"Sp10", b"Sp26"] and list(o.sequences) == ["QFSNWV", "KFS--S", "NFA--A"]
+    assert type(o) is Alignment
+    with pytest.raises(ValueError):
+        TrimmedAlignment([b"a"], ["AC"], sequences_mask=[True, False])
+    with pytest.raises(ValueError):
+        TrimmedAlignment([b"a"], ["AC"], residues_mask=[True])
+    term = TrimmedAlignment([b"a"], ["ACDEFG"], residues_mask=[False, True, False, True, True, False]).terminal_only()
+    assert term.residues_mask == [False, True, True, True, True, False]
+    c = t.copy()
+    assert c.residues_mask == t.residues_mask and list(c.sequences) == list(t.sequences)
+
+
+# --- SimilarityMatrix (tests/test_similarity_matrix.py) -------------------------------------------
+
+def test_similarity_matrix():
+    mx = SimilarityMatrix([[5, 0, 0, 4], [0, 5, 4, 0], [0, 4, 5, 0], [4, 0, 0, 5]], "ATCG")
+    assert mx.similarity("A", "A") == 5.0 and mx.similarity("A", "T") == 0.0 and mx.similarity("A", "G") == 4.0
+    with pytest.raises(ValueError):
+        SimilarityMatrix([[5, 0, 0, 4], [0, 5, 4, 0], [0, 4, 5, 0], [4, 0, 0, 5]], "ATC")
+    with pytest.raises(ValueError):
+        SimilarityMatrix([[1]], "a")
+    assert len(SimilarityMatrix.aa()) == 20 and len(SimilarityMatrix.nt()) == 5
+    assert len(SimilarityMatrix.nt(degenerated=True)) == 15
+    nt = SimilarityMatrix.nt()
+    assert nt.similarity("A", "A") == 1.0 and nt.similarity("A", "T") == 0.0
+    assert nt.distance("A", "A") == 0.0 and nt.distance("A", "T") > 0.0
+    with pytest.raises(ValueError):
+        nt.distance("+", ":")
+    with pytest.raises(ValueError):
+        nt.distance("nonsense", "nonsense")
+    assert abs(SimilarityMatrix.nt(degenerated=True).distance("A", "T") - 1.5184) < 1e-4
+    aa = SimilarityMatrix.aa()
+    assert aa.distance("A", "A") == 0.0 and aa.distance("A", "R") > 0.0
+    assert np.float32(aa.distance("A", "R")).view(np.uint32) == 0x412D1104
+    with pytest.raises(ValueError, match="not defined"):
+        aa.similarity("A", "B")
+    p = pickle.loads(pickle.dumps(aa))
+    assert p == aa and p.name == "BLOSUM62"
+    with open(data_path("pam70.json")) as f:
+        pam70 = SimilarityMatrix(**json.load(f))  # tests/test_automatic_trimmer.py:64-72
+    assert len(pam70) == 23

@@ -1,0 +1,222 @@
+"""The reference's trimmer tests with platform="hip": every test class of
+src/pytrimal/tests/test_{automatic,manual,overlap,representative}_trimmer.py, run through the
+public API of this package against the same golden files (those that survive in the reference
+checkout) and, where the reference's fixture is a dangling symlink, against the oracle.
+"""
+import json
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import EXAMPLE_001, EXAMPLE_001_NAMES, GOLDEN, OVERLAP_EXAMPLE, OVERLAP_NAMES, data_path, edge_msa
+from pytrimal_amd import (
+    Alignment,
+    AutomaticTrimmer,
+    ManualTrimmer,
+    OverlapTrimmer,
+    RepresentativeTrimmer,
+    SimilarityMatrix,
+    TrimmedAlignment,
+)
+from pytrimal_amd.synth import synth_msa
+
+pytestmark = pytest.mark.gpu
+PLATFORM = "hip"
+
+
+def load(name, fmt="fasta"):
+    with open(data_path(name), "rb") as f:
+        return Alignment.load(f, format=fmt)
+
+
+def assert_trimmed_equal(trimmed, expected):
+    assert len(trimmed.names) == len(expected.names)
+    assert len(trimmed.sequences) == len(expected.sequences)
+    assert trimmed.names == expected.names
+    for s1, s2 in zip(trimmed.sequences, expected.sequences):
+        assert s1 == s2
+
+
+def assert_matches_oracle(trimmed, a, **kw):
+    res, seq, _ = oracle.trim(a, **kw)
+    assert trimmed.residues_mask == [bool(x) for x in res]
+    assert trimmed.sequences_mask == [bool(x) for x in seq]
+
+
+@pytest.fixture(scope="module")
+def enog_ali():
+    return load("ENOG411BWBU.seq40.res60.fasta")  # == ENOG411BWBU.fasta
+
+
+# --- TestManualTrimmer ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("gt,cons", [(0.9, 60), (0.4, 40)])
+def test_gap_threshold(enog_ali, gt, cons):
+    expected = load("ENOG411BWBU.cons%02d.gt%02d.fasta" % (cons, int(gt * 100)))
+    trimmed = ManualTrimmer(gap_threshold=gt, conservation_percentage=cons, platform=PLATFORM).trim(enog_ali)
+    assert_trimmed_equal(trimmed, expected)
+
+
+def test_window():
+    ali = Alignment(EXAMPLE_001_NAMES, EXAMPLE_001)
+    expected = load("example.001.gt90.w3.clw", "clustal")
+    trimmed = ManualTrimmer(gap_threshold=0.9, window=3, platform=PLATFORM).trim(ali)
+    assert trimmed.names == expected.names
+    assert list(trimmed.sequences) == list(expected.sequences)
+
+
+def test_large_window():
+    ali = Alignment([b"seq1", b"seq2"], ["M-KKV", "MY-KV"])
+    with pytest.raises(Exception):
+        ManualTrimmer(gap_threshold=0.9, window=100, platform=PLATFORM).trim(ali)
+
+
+@pytest.mark.parametrize("kw", [dict(gap_threshold=0.5, similarity_threshold=0.5),
+                                dict(similarity_threshold=0.3, conservation_percentage=50),
+                                dict(gap_threshold=0.8, window=2),
+                                dict(gap_threshold=0.7, similarity_threshold=0.2, gap_window=2, similarity_window=3),
+                                dict(gap_absolute_threshold=20)])
+def test_manual_against_oracle(enog_ali, kw):
+    trimmed = ManualTrimmer(platform=PLATFORM, **kw).trim(enog_ali)
+    a = oracle.pack(list(enog_ali.sequences))
+    assert_matches_oracle(trimmed, a, **kw)
+
+
+# --- TestAutomaticTrimmer ------------------------------------------------------------------------
+
+def test_noduplicateseqs_method(enog_ali):
+    trimmed = AutomaticTrimmer("noduplicateseqs", platform=PLATFORM).trim(enog_ali)
+    assert_trimmed_equal(trimmed, load("ENOG411BWBU.noduplicateseqs.fasta"))
+
+
+@pytest.mark.parametrize("method", ["strict", "strictplus", "gappyout", "automated1", "nogaps", "noallgaps"])
+def test_automatic_methods_against_oracle(enog_ali, method):
+    # the reference's golden files for these methods are dangling symlinks in its checkout
+    trimmed = AutomaticTrimmer(method, platform=PLATFORM).trim(enog_ali)
+    assert_matches_oracle(trimmed, oracle.pack(list(enog_ali.sequences)), method=method)
+
+
+def test_automated1_docstring_example():
+    ali = Alignment(EXAMPLE_001_NAMES, EXAMPLE_001)
+    trimmed = AutomaticTrimmer("automated1", platform=PLATFORM).trim(ali)
+    assert list(trimmed.sequences) == ["VWLFPWNGLQIHMMGII", "EWFFAWLGLEINMMVII", "AAANAWLGLEINMMAQI",
+                                       "SWYLAWLGLEINMMAII", "TWFQLWQGLDLNKMPVF", "AWFQAWGGLEINKQAIL"]
+
+
+def test_strictplus_readme_example():
+    ali = Alignment(EXAMPLE_001_NAMES, EXAMPLE_001)
+    trimmed = AutomaticTrimmer("strictplus", platform=PLATFORM).trim(ali)
+    assert list(trimmed.sequences) == ["GIVLVWLFPWNGLQIHMMGII", "VIMLEWFFAWLGLEINMMVII", "GLFLAAANAWLGLEINMMAQI",
+                                       "GIYLSWYLAWLGLEINMMAII", "GFLLTWFQLWQGLDLNKMPVF", "GLHMAWFQAWGGLEINKQAIL"]
+
+
+def test_automated2_is_not_implemented(enog_ali):
+    with pytest.raises(RuntimeError):
+        AutomaticTrimmer("automated2", platform=PLATFORM).trim(enog_ali)
+
+
+def test_custom_similarity_matrix(enog_ali):
+    with open(data_path("pam70.json")) as f:
+        pam70 = SimilarityMatrix(**json.load(f))
+    trimmed = AutomaticTrimmer("strict", platform=PLATFORM).trim(enog_ali, pam70)
+    a = oracle.pack(list(enog_ali.sequences))
+    assert_matches_oracle(trimmed, a, method="strict", matrix=(pam70._vhash, pam70._dist))
+
+
+def test_invalid_characters():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ali = Alignment([b"seq1", b"seq2"], ["MKKBO", "MKKAY"])
+        with pytest.raises(ValueError):
+            AutomaticTrimmer("strict", platform=PLATFORM).trim(ali)
+
+
+def test_pickle_automatic():
+    t = AutomaticTrimmer("automated1", platform=PLATFORM)
+    p = pickle.loads(pickle.dumps(t))
+    ali = Alignment(OVERLAP_NAMES, OVERLAP_EXAMPLE)
+    assert_trimmed_equal(p.trim(ali), t.trim(ali))
+
+
+def test_repr_on_gpu_host():
+    assert repr(AutomaticTrimmer("strict")) == "AutomaticTrimmer('strict')"
+    assert repr(AutomaticTrimmer("noduplicateseqs", platform=None)) == "AutomaticTrimmer('noduplicateseqs', platform=None)"
+    assert repr(ManualTrimmer(window=5, platform=None)) == "ManualTrimmer(window=5, platform=None)"
+    assert repr(OverlapTrimmer(30, 0.25, platform=None)) == "OverlapTrimmer(30.0, 0.25, platform=None)"
+    with pytest.raises(RuntimeError):
+        AutomaticTrimmer("strict", platform=None).trim(Alignment(EXAMPLE_001_NAMES, EXAMPLE_001))
+
+
+# --- TestOverlapTrimmer --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seq,res", [(80, 80), (40, 60)])
+def test_overlap(enog_ali, seq, res):
+    expected = load("ENOG411BWBU.seq%d.res%d.fasta" % (seq, res))
+    trimmed = OverlapTrimmer(sequence_overlap=seq, residue_overlap=res / 100, platform=PLATFORM).trim(enog_ali)
+    assert_trimmed_equal(trimmed, expected)
+
+
+def test_overlap_docstring_example():
+    ali = Alignment(OVERLAP_NAMES, OVERLAP_EXAMPLE)
+    trimmed = OverlapTrimmer(40.0, 0.5, platform=PLATFORM).trim(ali)
+    assert trimmed.names == [b"Sp17", b"Sp10", b"Sp26"]
+    assert list(trimmed.sequences) == ["APDLLL-IGFLLKTV-ATFGDTWFQLWQGLD", "DPAVL--FVIMLGTI-TKFSSEWFFAWLGLE",
+                                       "AAALLTYLGLFLGTDYENFAAAAANAWLGLE"]
+
+
+# --- TestRepresentativeTrimmer -------------------------------------------------------------------
+
+@pytest.mark.parametrize("thr,fname", [(0.75, "maxidentity75"), (0.7, "id70"), (0.5, "id50")])
+def test_identity_threshold(enog_ali, thr, fname):
+    trimmed = RepresentativeTrimmer(identity_threshold=thr, platform=PLATFORM).trim(enog_ali)
+    assert_trimmed_equal(trimmed, load("ENOG411BWBU.%s.fasta" % fname))
+
+
+@pytest.mark.parametrize("clusters", [1, 2, 5, 10, 50, 209])
+def test_clusters_bounds(enog_ali, clusters):
+    trimmed = RepresentativeTrimmer(clusters=clusters, platform=PLATFORM).trim(enog_ali)
+    assert len(trimmed.sequences) <= max(clusters, 1)
+    assert_matches_oracle(trimmed, oracle.pack(list(enog_ali.sequences)), clusters=clusters)
+
+
+# --- beyond the reference's tests ----------------------------------------------------------------
+
+def test_trimming_a_trimmed_alignment(enog_ali):
+    first = ManualTrimmer(gap_threshold=0.9, conservation_percentage=60, platform=PLATFORM).trim(enog_ali)
+    assert isinstance(first, TrimmedAlignment)
+    second = AutomaticTrimmer("gappyout", platform=PLATFORM).trim(first)
+    dense = oracle.pack(list(first.sequences))
+    assert_matches_oracle(second, dense, method="gappyout")
+
+
+def test_golden_vectors(enog_ali):
+    vec = np.load(GOLDEN + "/vectors.npz")
+    for cname, make in {"strict": lambda: AutomaticTrimmer("strict", platform=PLATFORM),
+                        "gt50st50": lambda: ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5, platform=PLATFORM),
+                        "ov60_50": lambda: OverlapTrimmer(60, 0.5, platform=PLATFORM),
+                        "id50": lambda: RepresentativeTrimmer(identity_threshold=0.5, platform=PLATFORM)}.items():
+        t = make().trim(enog_ali)
+        assert np.array_equal(np.packbits(np.array(t.residues_mask)), vec[f"enog.{cname}.res"]), cname
+        assert np.array_equal(np.packbits(np.array(t.sequences_mask)), vec[f"enog.{cname}.seq"]), cname
+
+
+@pytest.mark.parametrize("method", ["automated1", "strictplus", "gappyout"])
+def test_c2_config_masks(method):
+    # BASELINE configs[1] size (500 x 2000): masks identical to the oracle's
+    a = synth_msa(500, 2000, 1002)
+    ali = Alignment([b"s%d" % i for i in range(500)], [bytes(r) for r in a])
+    assert_matches_oracle(AutomaticTrimmer(method, platform=PLATFORM).trim(ali), a, method=method)
+
+
+def test_threads_are_independent(enog_ali):
+    from multiprocessing.pool import ThreadPool
+
+    trimmer = AutomaticTrimmer("strict", platform=PLATFORM)
+    alis = [enog_ali, Alignment(EXAMPLE_001_NAMES, EXAMPLE_001), load("halorhodopsin.afa")] * 2
+    with ThreadPool(3) as pool:  # README.md:136-152 usage
+        out = pool.map(trimmer.trim, alis)
+    for ali, t in zip(alis, out):
+        assert_matches_oracle(t, oracle.pack(list(ali.sequences)), method="strict")
