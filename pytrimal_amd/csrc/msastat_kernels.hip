@@ -480,19 +480,23 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     const uint4 *col = codes16 + c;
     const float *wbase = wmat;
 
+    // 32-bit offsets (the launcher checks the arrays are < 4 GiB): 64-bit scalar multiplies would
+    // dominate the fetch, and every instruction of a lone wave costs ~4.75 cycles.
+    const unsigned char *codes_bytes = reinterpret_cast<const unsigned char *>(codes16);
+    const uint32_t ld16 = (uint32_t)ld * 16u, c16 = (uint32_t)c * 16u;
     auto fetch = [&](SimOct (&u)[SIM_OCTS], SimPos p) {  // branch-free: null octs read the skipped row
         const bool past = p.j >= m - 1;
-        const int jr = past ? 0 : p.j;
-        const float *wrow = wbase + (size_t)jr * ldw;
+        const uint32_t wrow = (uint32_t)(past ? 0 : p.j) * (uint32_t)ldw;
 #pragma unroll
         for (int t = 0; t < SIM_OCTS; ++t) {
             const int g = p.gb + P * SIM_OCTS + t;
             int gc = (past || g >= G8) ? G8 : g;
             const int gw = g >= G8 ? G8 - 1 : g;
             if (mode & 32) gc = P;  // diagnostics: always the same few cache lines
-            u[t].codes = col[(size_t)gc * ld];
+            u[t].codes = *reinterpret_cast<const uint4 *>(codes_bytes + ((uint32_t)gc * ld16 + c16));
+            const float *wp = wbase + (wrow + 8u * (uint32_t)gw);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) u[t].w[s] = wrow[8 * gw + s];
+            for (int s = 0; s < 8; ++s) u[t].w[s] = wp[s];
         }
     };
     // Scalar loads and LDS traffic share lgkmcnt, and scalar data returns out of order: the
@@ -566,10 +570,20 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         settle(cur);
         if (stamp) t1 = sim_now();
         const SimPos pos2 = sim_next(pos1, G8);
-        fetch(far, pos2);
-        if (stamp) t2 = sim_now();
-        produce(cur, pos.j, r);
-        if (stamp) t3 = sim_now();
+        // The LDS is the shared bottleneck of the workgroup: half of the producers burst into it
+        // right after the barrier and fetch afterwards, the other half fetch first, so the two
+        // bursts do not pile up (no extra synchronisation, the skew is just instruction order).
+        if (P < SIM_NP / 2 + 1) {
+            produce(cur, pos.j, r);
+            if (stamp) t2 = sim_now();
+            fetch(far, pos2);
+            if (stamp) t3 = sim_now();
+        } else {
+            fetch(far, pos2);
+            if (stamp) t2 = sim_now();
+            produce(cur, pos.j, r);
+            if (stamp) t3 = sim_now();
+        }
         if (pos1.j != pos.j) {  // last round of row j (wave- and workgroup-uniform): stage row j+1
             refresh(pos1.j, cj_next);
             cj_next = load_cj(pos1.j + 1);
@@ -620,13 +634,20 @@ __global__ __launch_bounds__(64 * (SIM_NP + 1)) void similarity_pc_kernel(
             unsigned long long t0 = 0, t1 = 0;
             if (stamp) t0 = sim_now();
             const float4 *in = ring + ((r - 1) & 1) * SIM_PAIRS * 64 + lane;
-            if (!(mode & 2))
+            if (!(mode & 2)) {
+                // All reads of the round are issued up front: right after a barrier the producers
+                // flood the LDS queue, and a shallow prefetch would leave the chain starving.
+                // (Slotting half of them between the adds measured 2 % slower.)
+                float4 v[SIM_PAIRS];
+#pragma unroll
+                for (int p = 0; p < SIM_PAIRS; ++p) v[p] = in[p * 64];
+                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from re-serialising them
 #pragma unroll
                 for (int p = 0; p < SIM_PAIRS; ++p) {
-                    const float4 v = in[p * 64];
-                    acc += f32x2{v.x, v.y};
-                    acc += f32x2{v.z, v.w};
+                    acc += f32x2{v[p].x, v[p].y};
+                    acc += f32x2{v[p].z, v[p].w};
                 }
+            }
             if (stamp) t1 = sim_now();
             sim_barrier();
             if (stamp) {

@@ -25,6 +25,6 @@ if len(sys.argv) > 1:
             v = [buf[p * 8 + k] / r for k in range(5)]
             print(" producer %d: settle %.0f fetch %.0f produce %.0f refresh %.0f barrier %.0f" % (p - 1, *v))
 else:
-    for mode in (64, 65, 66):
+    for mode in (0, 64):
         env = dict(os.environ, MSA_SIM_MODE=str(mode))
         subprocess.run([sys.executable, __file__, "x"], env=env)
