@@ -30,33 +30,56 @@ def _is_valid_table():
 _VALID = _is_valid_table()
 
 
+_DNA = np.frombuffer(b"AGCTN", dtype=np.uint8)
+_RNA = np.frombuffer(b"AGCUN", dtype=np.uint8)
+_DEG = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
+_NOT_LETTER = np.frombuffer(b"-.?", dtype=np.uint8)
+
+
+def _first100_counts(block):
+    """Per row of `block`: (letters seen, DNA hits, RNA hits, degenerate hits) among the first
+    100 non-gap letters."""
+    upper = np.where((block >= 97) & (block <= 122), block - 32, block)
+    letter = ~np.isin(block, _NOT_LETTER)
+    first100 = letter & (np.cumsum(letter, axis=1) <= 100)
+    k = first100.sum(axis=1)
+    hd = (np.isin(upper, _DNA) & first100).sum(axis=1)
+    hr = (np.isin(upper, _RNA) & first100).sum(axis=1)
+    dg = (np.isin(upper, _DEG) & first100).sum(axis=1)
+    return k, hd, hr, dg
+
+
 def detect_alignment_type(matrix):
     """trimAl ``utils::checkAlignmentType`` (behind ``Alignment::getAlignmentType``,
     ``_trimal.pyx:891``): look at the first 100 non-gap letters of every sequence; an alignment
-    is amino-acid as soon as one sequence has < 70 % nucleotide letters."""
-    upper = np.where((matrix >= 97) & (matrix <= 122), matrix - 32, matrix)
-    dna = np.isin(upper, np.frombuffer(b"AGCTN", dtype=np.uint8))
-    rna = np.isin(upper, np.frombuffer(b"AGCUN", dtype=np.uint8))
-    deg = np.isin(upper, np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8))
-    letter = ~np.isin(matrix, np.frombuffer(b"-.?", dtype=np.uint8))
-    rank = np.cumsum(letter, axis=1)
-    first100 = letter & (rank <= 100)
+    is amino-acid as soon as one sequence has < 70 % nucleotide letters.  Only a prefix of the
+    columns is scanned (widened for the rows that have not shown 100 letters yet)."""
+    m, n = matrix.shape
+    k = np.zeros(m, dtype=np.int64)
+    hd, hr, dg = k.copy(), k.copy(), k.copy()
+    rows = np.arange(m)
+    width = min(n, 256)
+    while True:
+        kk, a, b, c = _first100_counts(matrix[rows, :width] if len(rows) < m else matrix[:, :width])
+        k[rows], hd[rows], hr[rows], dg[rows] = kk, a, b, c
+        rows = rows[(kk < 100)]
+        if width >= n or len(rows) == 0:
+            break
+        width = min(n, width * 4)
     g_dna = g_rna = ext_dna = ext_rna = 0
-    for i in range(matrix.shape[0]):
-        sel = first100[i]
-        k = int(sel.sum())
-        if k == 0:
+    for i in range(m):  # in row order: the first protein-looking sequence decides
+        if k[i] == 0:
             continue
-        hd, hr, dg = int(dna[i][sel].sum()), int(rna[i][sel].sum()), int(deg[i][sel].sum())
-        if (np.float32(hd + dg) / np.float32(k)) < 0.7 and (np.float32(hr + dg) / np.float32(k)) < 0.7:
+        kf = np.float32(k[i])
+        if (np.float32(hd[i] + dg[i]) / kf) < 0.7 and (np.float32(hr[i] + dg[i]) / kf) < 0.7:
             return 4
-        if hr > hd and dg == 0:
+        if hr[i] > hd[i] and dg[i] == 0:
             g_rna += 1
-        elif hr < hd and dg == 0:
+        elif hr[i] < hd[i] and dg[i] == 0:
             g_dna += 1
-        elif hr > hd and dg != 0:
+        elif hr[i] > hd[i] and dg[i] != 0:
             ext_rna += 1
-        elif hr < hd and dg != 0:
+        elif hr[i] < hd[i] and dg[i] != 0:
             ext_dna += 1
     if ext_dna != 0 and ext_dna > ext_rna:
         return 1 | 8
@@ -172,6 +195,7 @@ class Alignment:
     def _reindex(self):
         self._seq_idx = np.flatnonzero(self._seq_mask)
         self._res_idx = np.flatnonzero(self._res_mask)
+        self._detected_type = None
 
     def _dense(self):
         """The visible (kept) residues as a C-contiguous uint8 matrix."""
@@ -182,10 +206,11 @@ class Alignment:
     def _alignment_type(self):
         if self._datatype:
             return self._datatype
-        dense = self._dense()
-        if dense.size == 0:
-            return 0
-        return detect_alignment_type(dense)
+        cached = getattr(self, "_detected_type", None)
+        if cached is None:
+            dense = self._dense()
+            cached = self._detected_type = 0 if dense.size == 0 else detect_alignment_type(dense)
+        return cached
 
     # --- parser / loader --------------------------------------------------------
 

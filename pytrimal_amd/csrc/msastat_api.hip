@@ -90,7 +90,7 @@ struct msa_ctx {
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, stats2;
-    DevBuf<uint32_t> codes4;
+    DevBuf<uint32_t> codes16;  // [G8 + 1][ld] x 16 B
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
     DevBuf<int32_t> gaps_w;
@@ -314,7 +314,6 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     rc = ensure_gaps(c, false);
     if (rc) return rc;
     const int m = c->m, n = c->n;
-    const int G = (m + 3) / 4;
     // tables
     uint8_t lut[256];
     std::vector<float> tab(2 * 29 * 32);
@@ -336,21 +335,20 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         gw_dev = c->gaps_w.p;
     }
-    (void)G;
     const int G8 = (m + 7) / 8;
-    HIPCHK(c, c->codes4.reserve((size_t)4 * (G8 + 1) * c->ld + 64));  // [G8 + 1][ld] x 16 B
+    HIPCHK(c, c->codes16.reserve((size_t)4 * (G8 + 1) * c->ld + 64));  // [G8 + 1][ld] x 16 B
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     {
         ProfScope ps(c, "encode");
-        msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes4.p, c->errkey.p);
+        msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->q.reserve((size_t)n + 64));
     HIPCHK(c, c->mdk.reserve((size_t)n + 64));
     {
         ProfScope ps(c, "sim");
-        int e = msak::launch_similarity_pc(c->stream, c->codes4.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
+        int e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                            gw_dev, c->q.p, c->mdk.p);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
@@ -546,7 +544,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release();
-    c->stats2.release(); c->codes4.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
+    c->stats2.release(); c->codes16.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();

@@ -16,11 +16,6 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
                         uint32_t *dst, float *ident, float *wmat);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2);
-void launch_sim_encode(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
-                       const int32_t *gaps_w, uint32_t *codes4, unsigned long long *err_key);
-size_t similarity_lds_bytes(int m);
-int launch_similarity(hipStream_t s, const uint32_t *codes4, int m, int n, int64_t ld, const float *wmat, int ldw,
-                      const void *tab, const int32_t *gaps_w, float *q_out, float *mdk_out);
 void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                          const int32_t *gaps_w, void *codes16, unsigned long long *err_key);
 int launch_similarity_pc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,

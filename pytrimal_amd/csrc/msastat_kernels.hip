@@ -9,8 +9,8 @@
 //   gaps / indet [n]             i32  per-column '-' / indetermination counts
 //   ident [m][ldw]               f32  pairwise identity, symmetric (ldw % 64 == 0, pad = 0)
 //   w     [m][ldw]               f32  1 - identity, STRICTLY UPPER triangular (0 elsewhere)
-//   codes4  [ceil(m/4)][ld]      u32  per column, 4 consecutive rows' similarity-table offsets
-//   tab     [29][32]             f32x2 {distance, both-valid} indexed by (row code, column code)
+//   codes16 [ceil(m/8)+1][ld]    8xu16 per column, 8 consecutive rows' byte offsets into a table slice
+//   tab     [29][32]             f32x2 {distance, both-valid} indexed by (row index, column index)
 //
 // No MFMA anywhere: this is integer / lookup / ordered-fp32 work.
 #include <hip/hip_runtime.h>
@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------
 // pair_counts: hit/dst of every sequence pair (Cleaner::calculateSeqIdentity ==
 // Similarity::calculateMatrixIdentity integers).  One wave = TI rows "i" (wave-uniform, read
-// through the scalar cache) x 64 rows "j" (one per lane); per 32 columns and pair:
-// 7 xor + 3 or3 (difference mask) + bfi + 2 bcnt + or.  Integer work, any order is exact.
+// through the scalar cache, used as SGPR operands) x 64*TJ rows "j" (TJ per lane); per 32
+// columns and pair: 7 xor/or (v_or3 / v_bitop3 fuse most of them) + and-not + 2 bcnt + or.
+// Integer work, any order is exact.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
 
@@ -213,26 +214,72 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
 // rows, every sum in the reference's order (ascending index, float32).  Lane = row i; the
 // symmetric matrix is read column-wise so that loads coalesce.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
-                                                           float *__restrict__ row_avg, float *__restrict__ row_max) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= m) return;
-    float mx = 0.0f, avg = 0.0f;
-    const float *p = ident + i;
+// The sums are short sequential float32 chains (m adds per row); what costs time is feeding
+// them.  Four waves stage [256 rows j][64 columns i] tiles of the symmetric matrix through LDS
+// (every wave loads, so 4x the memory-level parallelism of the chain wave alone), wave 0 walks
+// each tile in ascending j.
+constexpr int IDS_TJ = 128;
+
+__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+                                                            float *__restrict__ row_avg, float *__restrict__ row_max) {
+    __shared__ float tile[2][IDS_TJ][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64;
+    const int i = i0 + lane;           // < ldw (ldw % 64 == 0; padding columns are zero)
+    const int ntiles = (m + IDS_TJ - 1) / IDS_TJ;
+    auto load_tile = [&](int t, int buf) {
+        const int jb = t * IDS_TJ;
 #pragma unroll 8
-    for (int j = 0; j < m; ++j) {
-        const float v = p[(size_t)j * ldw];  // ident[j][i] == ident[i][j]
-        if (j != i) {
-            mx = mx < v ? v : mx;
-            avg += v;
+        for (int r = wave; r < IDS_TJ; r += 4) {
+            const int j = jb + r;
+            tile[buf][r][lane] = (j < m) ? ident[(size_t)j * ldw + i] : 0.0f;  // ident[j][i] == ident[i][j]
         }
+    };
+    float mx = 0.0f, avg = 0.0f;
+    load_tile(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1, (t + 1) & 1);
+        if (wave == 0) {
+            const int jb = t * IDS_TJ;
+            const int cnt = min(IDS_TJ, m - jb);
+            for (int r = 0; r < cnt; ++r) {
+                const float v = tile[t & 1][r][lane];
+                if (jb + r != i) {
+                    mx = mx < v ? v : mx;
+                    avg += v;
+                }
+            }
+        }
+        __syncthreads();
     }
-    row_avg[i] = avg / (float)(m - 1);
-    row_max[i] = mx;
+    if (wave == 0 && i < m) {
+        row_avg[i] = avg / (float)(m - 1);
+        row_max[i] = mx;
+    }
 }
 
-__global__ void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max, int m,
-                                      float *__restrict__ out2) {
+__global__ __launch_bounds__(256) void identity_final_kernel(const float *__restrict__ row_avg,
+                                                             const float *__restrict__ row_max, int m,
+                                                             float *__restrict__ out2) {
+    extern __shared__ float stage[];  // [2][m]
+    for (int t = threadIdx.x; t < m; t += 256) {
+        stage[t] = row_avg[t];
+        stage[m + t] = row_max[t];
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    float a = 0.0f, x = 0.0f;
+    for (int i = 0; i < m; ++i) {
+        a += stage[i];
+        x += stage[m + i];
+    }
+    out2[0] = a / (float)m;
+    out2[1] = x / (float)m;
+}
+
+__global__ void identity_final_big_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max, int m,
+                                          float *__restrict__ out2) {
     if (threadIdx.x || blockIdx.x) return;
     float a = 0.0f, x = 0.0f;
     for (int i = 0; i < m; ++i) {
@@ -243,128 +290,7 @@ __global__ void identity_final_kernel(const float *__restrict__ row_avg, const f
     out2[1] = x / (float)m;
 }
 
-// ------------------------------------------------------------------------------------------
-// sim_encode: residues -> similarity-table offsets, 4 rows packed per dword per column, and the
-// first offending residue (reference order: lowest non-skipped column, then lowest row).
-// lut[256]: byte -> code*8 (0..216), 224 = skipped (gap / indetermination),
-//           0xFE = incorrect symbol, 0xFF = symbol not in the matrix alphabet.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sim_encode_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                         const uint8_t *__restrict__ lut_g,
-                                                         const int32_t *__restrict__ gaps_w,
-                                                         uint32_t *__restrict__ codes4,
-                                                         unsigned long long *__restrict__ err_key) {
-    __shared__ uint8_t lut[256];
-    lut[threadIdx.x] = lut_g[threadIdx.x];
-    __syncthreads();
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    if ((int64_t)c4 * 4 >= ld) return;
-    const int g = blockIdx.y;  // row group
-    uint32_t x[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = g * 4 + r;
-        x[r] = (row < m) ? *(reinterpret_cast<const uint32_t *>(raw + (size_t)row * ld) + c4) : 0x2d2d2d2du;
-    }
-    uint32_t out[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c4 * 4 + k;
-        uint32_t o = 0;
-        bool skipcol = true;
-        if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t byte = (x[r] >> (8 * k)) & 0xFFu;
-            uint32_t code = (c < n) ? lut[byte] : 224u;
-            if (code >= 0xFEu) {
-                if (!skipcol) {
-                    const unsigned long long key = ((unsigned long long)c << 40) |
-                                                   ((unsigned long long)(g * 4 + r) << 16) |
-                                                   ((unsigned long long)(code & 1u) << 8) | byte;
-                    atomicMin(err_key, key);
-                }
-                code = 224u;
-            }
-            o |= code << (8 * r);
-        }
-        out[k] = o;
-    }
-    *reinterpret_cast<uint4 *>(codes4 + (size_t)g * ld + (size_t)c4 * 4) = make_uint4(out[0], out[1], out[2], out[3]);
-}
-
-// ------------------------------------------------------------------------------------------
-// similarity_mdk (order-preserving): statistics::Similarity::calculateVectors.
-// One lane = one column; a wave walks the pairs (j,k), j<k, in the reference's lexicographic
-// order, so W[j][k] is wave-uniform and each lane carries its own {num, den} float32 chain:
-//     num = fl(num + fl(W*D));  den = fl(den + W)       (no FMA contraction)
-// Skipped rows contribute W*0 / +0, which leaves both sums bit-identical to skipping them.
-// The column tile (m x 64 codes) and the {D, valid} table live in LDS.
-// ------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <bool TILE_IN_LDS>
-__global__ __launch_bounds__(64) void similarity_kernel(const uint32_t *__restrict__ codes4, int m, int n, int64_t ld,
-                                                        const float *__restrict__ wmat, int ldw,
-                                                        const f32x2 *__restrict__ tab_g,
-                                                        const int32_t *__restrict__ gaps_w, float *__restrict__ q_out,
-                                                        float *__restrict__ mdk_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x2 *tab = reinterpret_cast<f32x2 *>(smem);                 // [29][32] -> 7424 B
-    uint32_t *tile = reinterpret_cast<uint32_t *>(smem + 7424);   // [G][64]
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x * 64 + lane;
-    const int G = (m + 3) >> 2;
-    for (int t = lane; t < 29 * 32; t += 64) tab[t] = tab_g[t];
-    const uint32_t *col = codes4 + c;  // c < ld always (ld % 64 == 0)
-    if (TILE_IN_LDS) {
-        for (int g = 0; g < G; ++g) tile[g * 64 + lane] = col[(size_t)g * ld];
-    }
-    __syncthreads();
-    const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
-
-    f32x2 acc = {0.0f, 0.0f};  // {num, den}
-    for (int j = 0; j + 1 < m; ++j) {
-        const uint32_t wj = TILE_IN_LDS ? tile[(j >> 2) * 64 + lane] : col[(size_t)(j >> 2) * ld];
-        const uint32_t cj8 = (wj >> ((j & 3) * 8)) & 0xFFu;
-        const unsigned char *trow = tabb + cj8 * 32u;  // row stride 32 entries * 8 B
-        const float *wrow = wmat + (size_t)j * ldw;    // wave-uniform
-        int g = (j + 1) >> 2;
-        {   // first group: rows k <= j are masked with W = 0
-            const uint32_t cw = TILE_IN_LDS ? tile[g * 64 + lane] : col[(size_t)g * ld];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 4 * g + s;
-                const float w = (k > j) ? wrow[k] : 0.0f;
-                const f32x2 t = *reinterpret_cast<const f32x2 *>(trow + ((cw >> (8 * s)) & 0xFFu));
-                const f32x2 ww = {w, w};
-                acc += t * ww;
-            }
-        }
-        for (++g; g < G; ++g) {
-            const uint32_t cw = TILE_IN_LDS ? tile[g * 64 + lane] : col[(size_t)g * ld];
-            const float4 w4 = *reinterpret_cast<const float4 *>(wrow + 4 * g);
-            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x2 t = *reinterpret_cast<const f32x2 *>(trow + ((cw >> (8 * s)) & 0xFFu));
-                const f32x2 ww = {wv[s], wv[s]};
-                acc += t * ww;
-            }
-        }
-    }
-    if (c < n) {
-        const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
-        float q = 0.0f, v = 0.0f;
-        if (!skip && acc.y != 0.0f) {
-            q = acc.x / acc.y;
-            v = (float)exp(-(double)q);
-            v = v > 1.0f ? 1.0f : v;
-        }
-        if (q_out) q_out[c] = q;
-        mdk_out[c] = v;
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // similarity_mdk, producer/consumer form (the one msa_similarity launches).
@@ -832,33 +758,12 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2) {
-    identity_rows_kernel<<<(m + 63) / 64, 64, 0, s>>>(ident, m, ldw, row_avg, row_max);
-    identity_final_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
-}
-
-void launch_sim_encode(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
-                       const int32_t *gaps_w, uint32_t *codes4, unsigned long long *err_key) {
-    dim3 grid((unsigned)((ld / 4 + 255) / 256), (m + 3) / 4);
-    sim_encode_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codes4, err_key);
-}
-
-size_t similarity_lds_bytes(int m) { return 7424 + (size_t)((m + 3) / 4) * 256; }
-
-int launch_similarity(hipStream_t s, const uint32_t *codes4, int m, int n, int64_t ld, const float *wmat, int ldw,
-                      const void *tab, const int32_t *gaps_w, float *q_out, float *mdk_out) {
-    const int blocks = (n + 63) / 64;
-    const size_t lds = similarity_lds_bytes(m);
-    if (lds <= 160 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        similarity_kernel<true><<<blocks, 64, lds, s>>>(codes4, m, n, ld, wmat, ldw,
-                                                        reinterpret_cast<const f32x2 *>(tab), gaps_w, q_out, mdk_out);
+    identity_rows_kernel<<<(m + 63) / 64, 256, 0, s>>>(ident, m, ldw, row_avg, row_max);
+    if ((size_t)m * 8 <= 64 * 1024) {
+        identity_final_kernel<<<1, 256, (size_t)m * 8, s>>>(row_avg, row_max, m, out2);
     } else {
-        similarity_kernel<false><<<blocks, 64, 7424, s>>>(codes4, m, n, ld, wmat, ldw,
-                                                          reinterpret_cast<const f32x2 *>(tab), gaps_w, q_out, mdk_out);
+        identity_final_big_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
     }
-    return 0;
 }
 
 void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
