@@ -6,7 +6,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ITERS 4000
 // MODE bit0: 16 conflict-free b64 gathers; bit1: 16 pk_mul; bit2: 8 b128 ring writes; bit3: consumer (8 b128 reads + 16 pk_add)
-template <int MODE>
+template <int MODE, int ACTIVE>
 __global__ __launch_bounds__(512) void k(unsigned long long *cyc, float *sink, const unsigned *codes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -21,6 +21,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long *cyc, float *sink, c
     f32x2 tv[16];
     for (int s = 0; s < 16; ++s) tv[s] = f32x2{(float)s, 1.0f};
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (lane < ACTIVE)
     for (int it = 0; it < ITERS; ++it) {
         if (MODE & 1) {
 #pragma unroll
@@ -69,16 +70,16 @@ __global__ __launch_bounds__(512) void k(unsigned long long *cyc, float *sink, c
     sink[blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y + tv[3].x;
     if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
-template <int MODE>
+template <int MODE, int ACTIVE>
 void run(int waves, unsigned long long *cyc, float *sink, const unsigned *codes) {
     const int lds = 150000;
-    hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    for (int rep = 0; rep < 2; ++rep) { k<MODE><<<256, 64 * waves, lds>>>(cyc, sink, codes); hipDeviceSynchronize(); }
+    hipFuncSetAttribute((const void *)k<MODE, ACTIVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int rep = 0; rep < 2; ++rep) { k<MODE, ACTIVE><<<256, 64 * waves, lds>>>(cyc, sink, codes); hipDeviceSynchronize(); }
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     double s = 0; for (int b = 0; b < 256; ++b) for (int w = 0; w < waves; ++w) s += h[b * 8 + w];
     const double per = s / (256.0 * waves) / ITERS;
-    printf("mode %2d waves %d: %7.1f cycles per 16-step unit per wave -> %.2f cycles/step aggregate per CU\n", MODE, waves, per, per / 16.0 / waves);
+    printf("active %2d mode %2d waves %d: %7.1f cycles per 16-step unit per wave -> %.2f cycles/step aggregate per CU\n", ACTIVE, MODE, waves, per, per / 16.0 / waves);
 }
 int main() {
     unsigned long long *cyc; float *sink; unsigned *codes;
@@ -92,9 +93,10 @@ int main() {
         hc[i] = a | (b << 16);
     }
     hipMemcpy(codes, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
-    for (int waves : {1, 2, 4, 7, 8}) {
-        run<1>(waves, cyc, sink, codes); run<4>(waves, cyc, sink, codes); run<5>(waves, cyc, sink, codes);
-        run<7>(waves, cyc, sink, codes); run<8>(waves, cyc, sink, codes);
+    for (int waves : {1, 7}) {
+        run<1, 64>(waves, cyc, sink, codes); run<4, 64>(waves, cyc, sink, codes); run<7, 64>(waves, cyc, sink, codes); run<8, 64>(waves, cyc, sink, codes);
+        run<1, 40>(waves, cyc, sink, codes); run<4, 40>(waves, cyc, sink, codes); run<7, 40>(waves, cyc, sink, codes); run<8, 40>(waves, cyc, sink, codes);
+        run<1, 32>(waves, cyc, sink, codes); run<4, 32>(waves, cyc, sink, codes); run<7, 32>(waves, cyc, sink, codes); run<8, 32>(waves, cyc, sink, codes);
     }
     return 0;
 }
