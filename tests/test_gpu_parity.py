@@ -177,3 +177,72 @@ def test_attach_device_buffer(ctx):
     hit, dst = ctx.pair_counts()
     ohit, odst = oracle.pair_counts(a)
     assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
+
+
+# --- BASELINE.json full sizes: size-independent properties + oracle on slices -------------------
+
+def test_c3_full_size_properties(ctx):
+    """configs[2] (2000 x 10000): the oracle needs ~10 s for the whole thing, so integers are
+    checked through identities that hold at any size and the similarity on a column slice whose
+    W comes from the (separately verified) device pair counts."""
+    m, n = 2000, 10000
+    a = synth_msa(m, n, 1003)
+    ctx.upload(a, ord("X"))
+    g, x = ctx.gaps(with_indet=True)
+    assert np.array_equal(g, (a == ord("-")).sum(axis=0))           # exact, numpy on the host
+    assert np.array_equal(x, (a == ord("X")).sum(axis=0))
+    hit, dst = ctx.pair_counts()
+    assert np.array_equal(hit, hit.T) and np.array_equal(dst, dst.T)
+    assert not hit.diagonal().any() and not dst.diagonal().any()
+    assert (hit <= dst).all() and int(dst.max()) <= n
+    valid = (a != ord("-")) & (a != ord("X"))
+    nv = valid.sum(axis=1).astype(np.int64)
+    # dst[i][j] = |valid_i or valid_j| = nv_i + nv_j - |valid_i and valid_j|: check row sums exactly
+    both = valid.astype(np.float32) @ valid.astype(np.float32).T     # exact: counts < 2^24
+    want_dst = (nv[:, None] + nv[None, :] - both.astype(np.int64))
+    np.fill_diagonal(want_dst, 0)
+    assert np.array_equal(dst.astype(np.int64), want_dst)
+    # hit on a row slice against the oracle
+    rows = np.r_[0:40, 990:1010, 1960:2000]
+    ohit, odst = oracle.pair_counts(a[rows])
+    assert np.array_equal(hit[np.ix_(rows, rows)], ohit)
+    ident, w = ctx.identities()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = np.where(dst > 0, hit.astype(np.float32) / dst.astype(np.float32), np.float32(0))
+    assert np.array_equal(bits(ident), bits(want))
+    assert np.array_equal(bits(w), bits(np.where(np.eye(m, dtype=bool), np.float32(0), np.float32(1) - want)))
+    # similarity: 3 x 64 columns against the oracle (sequential float32 order), bit-exact Q
+    vhash, dist = oracle.aa_matrix()
+    mdk, q = ctx.similarity(vhash, dist)
+    for c0 in (0, 4992, 9936):
+        sl = slice(c0, c0 + 64)
+        omdk, oq = oracle.similarity(np.ascontiguousarray(a[:, sl]), w, g[sl], vhash, dist)
+        assert np.array_equal(bits(q[sl]), bits(oq))
+        assert np.max(np.abs(mdk[sl] - omdk)) <= MDK_TOL
+    assert (mdk[(g / np.float32(m)) >= np.float32(0.8)] == 0).all()
+    assert ((mdk >= 0) & (mdk <= 1)).all()
+    avg, mx = ctx.identity_stats()
+    _, oavg, omx = oracle.select_method(ident)
+    assert bits(avg) == bits(oavg) and bits(mx) == bits(omx)
+
+
+def test_c4_full_size_pair_counts(ctx):
+    """configs[3] (5000 x 5000): pair counts on row slices against the oracle + global identities."""
+    m, n = 5000, 5000
+    a = synth_msa(m, n, 1004)
+    ctx.upload(a, ord("X"))
+    hit, dst = ctx.pair_counts()
+    assert np.array_equal(hit, hit.T) and np.array_equal(dst, dst.T) and (hit <= dst).all()
+    for rows in (np.r_[0:64], np.r_[2470:2530], np.r_[4900:5000], np.arange(3, 5000, 97)):
+        ohit, odst = oracle.pair_counts(a[rows])
+        assert np.array_equal(hit[np.ix_(rows, rows)], ohit)
+        assert np.array_equal(dst[np.ix_(rows, rows)], odst)
+    # overlap through its closed form (the O(n m^2) oracle loop would take a minute here; the
+    # closed form is checked against that definition in tests/test_oracle_golden.py)
+    ov = ctx.overlap(0.5)
+    is_gap, is_x = a == ord("-"), a == ord("X")
+    ng, nx = is_gap.sum(axis=0), is_x.sum(axis=0)
+    need = int(np.ceil(np.float32(0.5) * np.float32(m - 1)))
+    hits = np.where(is_gap, ng[None, :] - 1, np.where(is_x, nx[None, :] - 1, (m - ng - nx)[None, :] - 1))
+    want = (hits >= need).sum(axis=1).astype(np.float32) / np.float32(n)
+    assert np.array_equal(bits(ov), bits(want))
