@@ -30,23 +30,34 @@ def _is_valid_table():
 _VALID = _is_valid_table()
 
 
-_DNA = np.frombuffer(b"AGCTN", dtype=np.uint8)
-_RNA = np.frombuffer(b"AGCUN", dtype=np.uint8)
-_DEG = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
-_NOT_LETTER = np.frombuffer(b"-.?", dtype=np.uint8)
+def _class_table():
+    """byte -> bit flags: 1 letter (not '-', '.', '?'), 2 DNA letter, 4 RNA letter, 8 degenerate."""
+    t = np.zeros(256, dtype=np.uint8)
+    for c in range(256):
+        up = chr(c).upper()
+        flags = 0 if chr(c) in "-.?" else 1
+        if up in "AGCTN":
+            flags |= 2
+        if up in "AGCUN":
+            flags |= 4
+        if up in "RYKMSWBDHV":
+            flags |= 8
+        t[c] = flags
+    return t
+
+
+_CLASS = _class_table()
 
 
 def _first100_counts(block):
     """Per row of `block`: (letters seen, DNA hits, RNA hits, degenerate hits) among the first
     100 non-gap letters."""
-    upper = np.where((block >= 97) & (block <= 122), block - 32, block)
-    letter = ~np.isin(block, _NOT_LETTER)
-    first100 = letter & (np.cumsum(letter, axis=1) <= 100)
-    k = first100.sum(axis=1)
-    hd = (np.isin(upper, _DNA) & first100).sum(axis=1)
-    hr = (np.isin(upper, _RNA) & first100).sum(axis=1)
-    dg = (np.isin(upper, _DEG) & first100).sum(axis=1)
-    return k, hd, hr, dg
+    cls = _CLASS[block]
+    letter = (cls & 1).astype(bool)
+    first100 = letter & (np.cumsum(letter, axis=1, dtype=np.int32) <= 100)
+    cls = np.where(first100, cls, 0)
+    return (first100.sum(axis=1), ((cls >> 1) & 1).sum(axis=1), ((cls >> 2) & 1).sum(axis=1),
+            ((cls >> 3) & 1).sum(axis=1))
 
 
 def detect_alignment_type(matrix):
@@ -58,7 +69,7 @@ def detect_alignment_type(matrix):
     k = np.zeros(m, dtype=np.int64)
     hd, hr, dg = k.copy(), k.copy(), k.copy()
     rows = np.arange(m)
-    width = min(n, 256)
+    width = min(n, 192)
     while True:
         kk, a, b, c = _first100_counts(matrix[rows, :width] if len(rows) < m else matrix[:, :width])
         k[rows], hd[rows], hr[rows], dg[rows] = kk, a, b, c
@@ -66,21 +77,15 @@ def detect_alignment_type(matrix):
         if width >= n or len(rows) == 0:
             break
         width = min(n, width * 4)
-    g_dna = g_rna = ext_dna = ext_rna = 0
-    for i in range(m):  # in row order: the first protein-looking sequence decides
-        if k[i] == 0:
-            continue
-        kf = np.float32(k[i])
-        if (np.float32(hd[i] + dg[i]) / kf) < 0.7 and (np.float32(hr[i] + dg[i]) / kf) < 0.7:
-            return 4
-        if hr[i] > hd[i] and dg[i] == 0:
-            g_rna += 1
-        elif hr[i] < hd[i] and dg[i] == 0:
-            g_dna += 1
-        elif hr[i] > hd[i] and dg[i] != 0:
-            ext_rna += 1
-        elif hr[i] < hd[i] and dg[i] != 0:
-            ext_dna += 1
+    seen = k > 0
+    kf = np.maximum(k, 1).astype(np.float32)
+    protein = seen & ((hd + dg).astype(np.float32) / kf < 0.7) & ((hr + dg).astype(np.float32) / kf < 0.7)
+    if protein.any():  # upstream returns AA at the first such sequence
+        return 4
+    g_rna = int((seen & (hr > hd) & (dg == 0)).sum())
+    g_dna = int((seen & (hr < hd) & (dg == 0)).sum())
+    ext_rna = int((seen & (hr > hd) & (dg != 0)).sum())
+    ext_dna = int((seen & (hr < hd) & (dg != 0)).sum())
     if ext_dna != 0 and ext_dna > ext_rna:
         return 1 | 8
     if ext_rna != 0 and ext_dna < ext_rna:

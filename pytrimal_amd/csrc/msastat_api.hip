@@ -498,6 +498,41 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
     return MSA_OK;
 }
 
+// Cleaner::calculateRepresentativeSeq with a fixed threshold, without moving the m*m matrix:
+// lengths to the host (m ints), trimAl's processing order back (m ints), adjacency bits + the
+// round-based independent-set kernel on the device, mask to the host (m bytes).
+int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
+    const int m = c->m;
+    if (m < 2) return MSA_E_INVALID;
+    int rc = run_pairs(c, true, false, false);
+    if (rc) return rc;
+    std::vector<int32_t> lengths;
+    rc = row_digest(c, lengths, nullptr);
+    if (rc) return rc;
+    const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
+    const size_t words = msak::cluster_adj_words(m);
+    HIPCHK(c, c->pairs.reserve((size_t)m + 64));
+    HIPCHK(c, c->col_ok.reserve((size_t)m * words + 64));
+    HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
+    HIPCHK(c, c->equal.reserve(4));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    std::memcpy(c->h_i32.p, seq_at.data(), sizeof(int32_t) * m);
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->equal.p, 0, sizeof(int32_t), c->stream));
+    {
+        ProfScope ps(c, "cluster");
+        if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, max_identity, c->col_ok.p,
+                                 c->keep_seq_d.p, c->equal.p) != 0)
+            return MSA_E_INVALID;  // too many sequences for the LDS bit sets: host path
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
+    HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(keep_seq, c->h_u8.p, m);
+    return MSA_OK;
+}
+
 int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of the identity matrix
     int rc = run_pairs(c, true, false, false);
     if (rc) return rc;
@@ -729,8 +764,12 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         rc = remove_duplicates(c, keep_seq);
         if (rc) return rc;
         seq_mode = true;
+    } else if (p->max_identity != -1 && p->clusters == -1 && device_representatives(c, p->max_identity, keep_seq) == MSA_OK) {
+        // RepresentativeTrimmer(identity_threshold): clustered on the device, only the mask comes back
+        seq_mode = true;
     } else if (p->clusters != -1 || p->max_identity != -1) {
-        // RepresentativeTrimmer: the m*m identities come to the host for the greedy clustering
+        // clusters=K (bisection over thresholds) or very large m: the m*m identities come to the
+        // host for the greedy clustering
         std::vector<float> ident;
         rc = fetch_ident(c, ident);
         if (rc) return rc;
@@ -811,7 +850,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
 
 int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
     if (!c || !kernel) return MSA_E_INVALID;
-    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap"};
+    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster"};
     bool known = false;
     for (const char *nm : names) known |= (std::strcmp(nm, kernel) == 0);
     if (!known) return MSA_E_INVALID;

@@ -326,6 +326,14 @@ std::vector<LenIdx> by_length(const int32_t *lengths, int m) {
 
 }  // namespace
 
+// processing order of calculateRepresentativeSeq: longest first, ties in trimAl's quicksort order
+std::vector<int32_t> processing_order(const int32_t *lengths, int m) {
+    const std::vector<LenIdx> order = by_length(lengths, m);
+    std::vector<int32_t> seq_at(m);
+    for (int t = 0; t < m; ++t) seq_at[t] = order[m - 1 - t].idx;
+    return seq_at;
+}
+
 int representatives(const float *ident, int ldi, const int32_t *lengths, int m, float max_identity,
                     uint8_t *keep_seq) {
     const std::vector<LenIdx> order = by_length(lengths, m);

@@ -25,6 +25,7 @@ float comb_similarity_cut(const int32_t *gw, const float *mdkw, int n, int gap_c
 void clean_strict(const int32_t *gw, const float *mdkw, int n, int gap_cut, float sim_cut, bool variable,
                   uint8_t *keep);
 int select_method(float avg_seq, float max_seq, int m);
+std::vector<int32_t> processing_order(const int32_t *lengths, int m);
 int representatives(const float *ident, int ldi, const int32_t *lengths, int m, float max_identity,
                     uint8_t *keep_seq);
 float cutpoint_clusters(const float *ident, int ldi, const int32_t *lengths, int m, int clusters);

@@ -741,6 +741,88 @@ __global__ __launch_bounds__(64) void rows_equal_kernel(const uint8_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Representative sequences on the device (Cleaner::calculateRepresentativeSeq with a fixed
+// identity threshold).  The reference walks the sequences from the longest down and makes one a
+// new representative iff no EARLIER representative has identity > thr with it: that is the
+// lexicographically-first maximal independent set of the graph {identity > thr} in processing
+// order, which is unique, so it can be computed by rounds instead of one-by-one:
+//   a vertex becomes REP once all its earlier neighbours are decided non-representatives,
+//   and NON-REP as soon as one earlier neighbour is a REP.
+// Each round reads a snapshot of the two bit sets and writes the next one (no torn reads).
+// adjacency bits: bit u of row t  <=>  ident[seq_at[t]][seq_at[u]] > thr, only u < t kept.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cluster_adjacency_kernel(const float *__restrict__ ident, int ldw,
+                                                                const int32_t *__restrict__ seq_at, int m, float thr,
+                                                                uint32_t *__restrict__ adj, int words) {
+    const int t = blockIdx.y;                              // processing index of the row vertex
+    const int w = blockIdx.x * 256 + threadIdx.x;          // word of earlier vertices
+    if (w >= words) return;
+    const float *row = ident + (size_t)seq_at[t] * ldw;
+    uint32_t bits = 0;
+#pragma unroll 4
+    for (int b = 0; b < 32; ++b) {
+        const int u = w * 32 + b;
+        if (u < t) bits |= (row[seq_at[u]] > thr ? 1u : 0u) << b;
+    }
+    adj[(size_t)t * words + w] = bits;
+}
+
+__global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__restrict__ adj, int m, int words,
+                                                           const int32_t *__restrict__ seq_at,
+                                                           uint8_t *__restrict__ keep_seq, int32_t *__restrict__ count) {
+    extern __shared__ uint32_t sets[];  // rep[2][words], undec[2][words]
+    uint32_t *rep = sets, *undec = sets + 2 * words;
+    __shared__ int remaining;
+    for (int w = threadIdx.x; w < 2 * words; w += 1024) rep[w] = 0;
+    for (int w = threadIdx.x; w < words; w += 1024) {
+        const int base = w * 32;
+        const uint32_t u = (base + 32 <= m) ? 0xFFFFFFFFu : (base < m ? ((1u << (m - base)) - 1u) : 0u);
+        undec[w] = u;
+        undec[words + w] = u;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round <= m; ++round) {
+        const uint32_t *rc = rep + cur * words, *uc = undec + cur * words;
+        uint32_t *rn = rep + (cur ^ 1) * words, *un = undec + (cur ^ 1) * words;
+        if (threadIdx.x == 0) remaining = 0;
+        for (int w = threadIdx.x; w < words; w += 1024) {  // next = current, then decisions are OR/AND-ed in
+            rn[w] = rc[w];
+            un[w] = uc[w];
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int t = threadIdx.x; t < m; t += 1024) {
+            if (!((uc[t >> 5] >> (t & 31)) & 1u)) continue;
+            const uint32_t *row = adj + (size_t)t * words;
+            int verdict = 1;  // 1 = REP, 0 = NON-REP, -1 = blocked by an undecided earlier neighbour
+            for (int w = 0; w <= (t >> 5); ++w) {
+                const uint32_t a = row[w];
+                if (!a) continue;
+                if (a & rc[w]) { verdict = 0; break; }
+                if (a & uc[w]) verdict = -1;
+            }
+            if (verdict == 1) atomicOr(&rn[t >> 5], 1u << (t & 31));
+            if (verdict >= 0) atomicAnd(&un[t >> 5], ~(1u << (t & 31)));
+            else mine = 1;
+        }
+        if (mine) remaining = 1;
+        __syncthreads();
+        cur ^= 1;
+        if (!remaining) break;
+        __syncthreads();
+    }
+    const uint32_t *rf = rep + cur * words;
+    int local = 0;
+    for (int t = threadIdx.x; t < m; t += 1024) {
+        const int r = (rf[t >> 5] >> (t & 31)) & 1u;
+        keep_seq[seq_at[t]] = (uint8_t)r;
+        local += r;
+    }
+    if (local) atomicAdd(count, local);
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 static inline uint32_t rep4(uint8_t b) { return 0x01010101u * b; }
@@ -1082,6 +1164,19 @@ void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, int32_t *lengths,
                        unsigned long long *hashes) {
     row_digest_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, lengths, hashes);
+}
+
+size_t cluster_adj_words(int m) { return (size_t)((m + 31) / 32); }
+
+int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *seq_at, int m, float thr, uint32_t *adj,
+                   uint8_t *keep_seq, int32_t *count) {
+    const int words = (int)cluster_adj_words(m);
+    const size_t lds = (size_t)4 * words * sizeof(uint32_t);
+    if (lds > 60 * 1024) return -1;  // caller falls back to the host path
+    dim3 grid((words + 255) / 256, m);
+    cluster_adjacency_kernel<<<grid, 256, 0, s>>>(ident, ldw, seq_at, m, thr, adj, words);
+    cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, m, words, seq_at, keep_seq, count);
+    return 0;
 }
 
 void launch_rows_equal(hipStream_t s, const uint8_t *raw, int n, int64_t ld, const int32_t *pairs, int npairs,
