@@ -656,7 +656,7 @@ int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n
 }
 
 int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
-    if (!c || !c->raw) return MSA_E_INVALID;
+    if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_gaps(c, true);
     if (rc) return rc;
@@ -666,7 +666,7 @@ int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
 }
 
 int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
-    if (!c || !c->raw) return MSA_E_INVALID;
+    if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     int rc = run_pairs(c, false, false, true);
     if (rc) return rc;
@@ -678,7 +678,7 @@ int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
 }
 
 int msa_identities(msa_ctx *c, float *ident, float *w) {
-    if (!c || !c->raw) return MSA_E_INVALID;
+    if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     int rc = run_pairs(c, true, true, false);
     if (rc) return rc;
@@ -699,20 +699,20 @@ int msa_identities(msa_ctx *c, float *ident, float *w) {
 }
 
 int msa_identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
-    if (!c || !c->raw || !avg_seq || !max_seq) return MSA_E_INVALID;
+    if (!c || !c->raw || !avg_seq || !max_seq || c->m < 2 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     return identity_stats(c, avg_seq, max_seq);
 }
 
 int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t npos, const int32_t *gaps_windowed,
                    float *mdk_out, float *q_out, msa_err_detail *detail) {
-    if (!c || !c->raw || !vhash || !dist || !mdk_out) return MSA_E_INVALID;
+    if (!c || !c->raw || !vhash || !dist || !mdk_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     return similarity(c, vhash, dist, npos, gaps_windowed, mdk_out, q_out, detail);
 }
 
 int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
-    if (!c || !c->raw || !spurious_out) return MSA_E_INVALID;
+    if (!c || !c->raw || !spurious_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     return overlap(c, residue_overlap, spurious_out);
 }
