@@ -320,6 +320,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int SIM_NP = 7;    // producer waves (+1 consumer = 8 waves = 2 per SIMD)
 constexpr int SIM_OCTS = 2;  // octs per producer per round
 constexpr int SIM_ROUND_OCTS = SIM_NP * SIM_OCTS;       // 14 octs = 112 steps per round
+#ifndef SIM_SKEW_SPLIT
+#define SIM_SKEW_SPLIT 7  // producers below this index gather first and fetch while the LDS answers
+#endif
 constexpr int SIM_PAIRS = SIM_ROUND_OCTS * 4;           // float4 {x0,w0,x1,w1} per lane per round
 constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29][32] x 8 B
 constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
@@ -410,7 +413,12 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * slice_bytes);
     const int G8 = (m + 7) >> 3;
     const uint4 *col = codes16 + c;
-    const float *wbase = wmat;
+    // W is wave-uniform; it travels through the VECTOR memory path on purpose: scalar loads share
+    // lgkmcnt with the LDS traffic and return out of order, so any wait on them drains the LDS
+    // queue too.  An opaque zero in a VGPR keeps the compiler from turning these into s_load.
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const float *wbase = wmat + vzero;
 
     // 32-bit offsets (the launcher checks the arrays are < 4 GiB): 64-bit scalar multiplies would
     // dominate the fetch, and every instruction of a lone wave costs ~4.75 cycles.
@@ -426,19 +434,17 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
             const int gw = g >= G8 ? G8 - 1 : g;
             if (DIAG && (mode & 32)) gc = P;  // diagnostics: always the same few cache lines
             u[t].codes = *reinterpret_cast<const uint4 *>(codes_bytes + ((uint32_t)gc * ld16 + c16));
-            const float *wp = wbase + (wrow + 8u * (uint32_t)gw);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) u[t].w[s] = wp[s];
+            const float4 *wp = reinterpret_cast<const float4 *>(wbase + (wrow + 8u * (uint32_t)gw));
+            const float4 wa = wp[0], wb = wp[1];
+            u[t].w[0] = wa.x; u[t].w[1] = wa.y; u[t].w[2] = wa.z; u[t].w[3] = wa.w;
+            u[t].w[4] = wb.x; u[t].w[5] = wb.y; u[t].w[6] = wb.z; u[t].w[7] = wb.w;
         }
     };
     // Scalar loads and LDS traffic share lgkmcnt, and scalar data returns out of order: the
     // only cheap place to wait for the W values is where the LDS queue is empty anyway, i.e.
     // right after a barrier.  Touching them there makes the compiler put its wait there.
     auto settle = [&](const SimOct (&u)[SIM_OCTS]) {
-#pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) asm volatile("" ::"s"(u[t].w[s]));
+        (void)u;  // nothing to settle: W now arrives under vmcnt
     };
     // this lane's table row index for row jn (its residue in that row), npos when skipped
     auto load_cj = [&](int jn) -> uint32_t {
@@ -468,20 +474,24 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             f32x2 xa, xb;
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tv[2 * pp]), "s"(wp[pp]));
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tv[2 * pp + 1]), "s"(wp[pp]));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tv[2 * pp]), "v"(wp[pp]));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tv[2 * pp + 1]), "v"(wp[pp]));
             out[pp * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
         }
     };
-    auto produce = [&](const SimOct (&u)[SIM_OCTS], int j, int r) {
-        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
+    // one round of this producer = gather (16 LDS reads in flight) ... emit (16 multiplies, 8 ring
+    // stores); the next-but-one round's fetch is slotted between the two so that its scalar
+    // arithmetic and memory requests issue while the gathers wait for the LDS
+    f32x2 tvs[SIM_OCTS][8];
+    auto gather_all = [&](const SimOct (&u)[SIM_OCTS], int j) {
         const unsigned char *slice = slices + (j & 1) * slice_bytes;
-        if (DIAG && (mode & 1)) return;
-        f32x2 tv[SIM_OCTS][8];
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], slice, tv[t]);
+        for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], slice, tvs[t]);
+    };
+    auto emit_all = [&](const SimOct (&u)[SIM_OCTS], int r) {
+        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) emit(u[t], tv[t], out + t * 4 * 64);
+        for (int t = 0; t < SIM_OCTS; ++t) emit(u[t], tvs[t], out + t * 4 * 64);
     };
 
     SimPos pos = {0, 0};
@@ -502,18 +512,22 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         settle(cur);
         if (stamp) t1 = sim_now();
         const SimPos pos2 = sim_next(pos1, G8);
-        // The LDS is the shared bottleneck of the workgroup: half of the producers burst into it
-        // right after the barrier and fetch afterwards, the other half fetch first, so the two
-        // bursts do not pile up (no extra synchronisation, the skew is just instruction order).
-        if (P < SIM_NP / 2 + 1) {
-            produce(cur, pos.j, r);
-            if (stamp) t2 = sim_now();
+        // The LDS is the shared bottleneck of the workgroup: half of the producers start their
+        // burst right after the barrier, the other half fetch first, so the bursts do not pile up
+        // (no extra synchronisation, the skew is just instruction order).
+        if (DIAG && (mode & 1)) {
             fetch(far, pos2);
+        } else if (P < SIM_SKEW_SPLIT) {
+            gather_all(cur, pos.j);
+            fetch(far, pos2);
+            if (stamp) t2 = sim_now();
+            emit_all(cur, r);
             if (stamp) t3 = sim_now();
         } else {
             fetch(far, pos2);
             if (stamp) t2 = sim_now();
-            produce(cur, pos.j, r);
+            gather_all(cur, pos.j);
+            emit_all(cur, r);
             if (stamp) t3 = sim_now();
         }
         if (pos1.j != pos.j) {  // last round of row j (wave- and workgroup-uniform): stage row j+1
@@ -540,7 +554,7 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(64 * (SIM_NP + 1)) void similarity_pc_kernel(
+__global__ __launch_bounds__(512) void similarity_pc_kernel(
     const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int rounds, int mode_arg,
     float *__restrict__ q_out, float *__restrict__ mdk_out) {
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(64 * (SIM_NP + 1)) void similarity_pc_kernel(
     const int c = blockIdx.x * 64 + lane;  // < ld
     {
         f32x2 *master = reinterpret_cast<f32x2 *>(smem);
-        for (int t = threadIdx.x; t < 29 * 32; t += 64 * (SIM_NP + 1)) master[t] = tab_g[t];
+        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t];
     }
     __syncthreads();
     if (wave != 0) {
@@ -564,31 +578,59 @@ __global__ __launch_bounds__(64 * (SIM_NP + 1)) void similarity_pc_kernel(
         sim_barrier();             // round 0 produced
         const bool stamp = DIAG && (mode & 64) && blockIdx.x == 0;
         unsigned long long tw = 0, tb = 0;
-        for (int r = 1; r <= rounds; ++r) {
+        // The chain runs half a round behind the reads.  Right after a barrier the producers flood
+        // the LDS queue and reads issued then take long to return; so the consumer always keeps two
+        // quarter-rounds of ring data pending in registers across the barrier and adds those while
+        // the new round's first reads crawl through the queue.  Three register sets of one quarter
+        // (SIM_PAIRS / 4 float4) rotate; with four quarters per round the rotation repeats every
+        // three rounds, hence the unrolling.  (+0 entries before round 1 leave the sums unchanged.)
+        constexpr int QP = SIM_PAIRS / 4;
+        float4 s0[QP], s1[QP], s2[QP];
+#pragma unroll
+        for (int p = 0; p < QP; ++p) s0[p] = s1[p] = s2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto rd = [&](float4 (&v)[QP], const float4 *in, int quarter) {
+#pragma unroll
+            for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto add = [&](const float4 (&v)[QP]) {
+#pragma unroll
+            for (int p = 0; p < QP; ++p) {
+                acc += f32x2{v[p].x, v[p].y};
+                acc += f32x2{v[p].z, v[p].w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // one round: pending on entry = (x, y) holding quarters 2, 3 of the previous round, z free;
+        // pending on exit = (y, z) holding quarters 2, 3 of this round, x free
+        auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
             unsigned long long t0 = 0, t1 = 0;
             if (stamp) t0 = sim_now();
             const float4 *in = ring + ((r - 1) & 1) * SIM_PAIRS * 64 + lane;
             if (!(DIAG && (mode & 2))) {
-                // All reads of the round are issued up front: right after a barrier the producers
-                // flood the LDS queue, and a shallow prefetch would leave the chain starving.
-                // (Slotting half of them between the adds measured 2 % slower.)
-                float4 v[SIM_PAIRS];
-#pragma unroll
-                for (int p = 0; p < SIM_PAIRS; ++p) v[p] = in[p * 64];
-                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from re-serialising them
-#pragma unroll
-                for (int p = 0; p < SIM_PAIRS; ++p) {
-                    acc += f32x2{v[p].x, v[p].y};
-                    acc += f32x2{v[p].z, v[p].w};
-                }
+                rd(z, in, 0);
+                add(x);
+                rd(x, in, 1);
+                add(y);
+                rd(y, in, 2);
+                add(z);
+                rd(z, in, 3);
+                add(x);
             }
             if (stamp) t1 = sim_now();
-            sim_barrier();
+            sim_barrier();  // also waits for the y / z reads: their buffer is rewritten two rounds on
             if (stamp) {
                 tw += t1 - t0;
                 tb += sim_now() - t1;
             }
+        };
+        for (int r = 1; r + 2 <= rounds; r += 3) {  // the launcher makes `rounds` a multiple of 3
+            one_round(s0, s1, s2, r);
+            one_round(s1, s2, s0, r + 1);
+            one_round(s2, s0, s1, r + 2);
         }
+        add(s0);  // the two quarters still pending
+        add(s1);
         if (stamp && lane == 0) {
             g_sim_stamps[0] = tw;
             g_sim_stamps[1] = tb;
@@ -1133,12 +1175,13 @@ int launch_similarity_pc(hipStream_t s, const void *codes16, int m, int n, int64
     const int G8 = (m + 7) / 8;
     long long rounds = 0;  // row-aligned: every row j takes ceil(octs_j / ROUND_OCTS) rounds
     for (int j = 0; j + 1 < m; ++j) rounds += (G8 - ((j + 1) >> 3) + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
+    rounds = (rounds + 2) / 3 * 3;  // the consumer's register sets rotate with period 3; extra rounds are null
     const int lds = sim_lds_bytes(npos);
     const int mode = sim_debug_mode();
     auto kern = mode ? similarity_pc_kernel<true> : similarity_pc_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    kern<<<(n + 63) / 64, 64 * (SIM_NP + 1), lds, s>>>(reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw,
+    kern<<<(n + 63) / 64, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw,
                                                        reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds,
                                                        mode, q_out, mdk_out);
     return 0;
