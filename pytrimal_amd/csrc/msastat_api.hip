@@ -337,12 +337,17 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         gw_dev = c->gaps_w.p;
     }
     const int G8 = (m + 7) / 8;
-    HIPCHK(c, c->codes16.reserve((size_t)4 * (G8 + 1) * c->ld + 64));  // [G8 + 1][ld] x 16 B
+    const char *which = getenv("MSA_SIM_KERNEL");
+    const bool ring_kernel = which && which[0] == 'r';
+    HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     {
         ProfScope ps(c, "encode");
-        msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
+        if (ring_kernel)
+            msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
+        else
+            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->q.reserve((size_t)n + 64));
@@ -351,9 +356,8 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         ProfScope ps(c, "sim");
         // MSA_SIM_KERNEL=ring selects the barrier-free variant (parity-tested, but measured slower:
         // 19.2 ms vs 15.6 ms at 2000 x 10000)
-        const char *which = getenv("MSA_SIM_KERNEL");
         int e;
-        if (!(which && which[0] == 'r')) {
+        if (!ring_kernel) {
             e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                            gw_dev, c->q.p, c->mdk.p);
         } else {

@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "msastat_kernels.h"
 
 namespace msak {
@@ -326,9 +328,10 @@ constexpr int SIM_ROUND_OCTS = SIM_NP * SIM_OCTS;       // 14 octs = 112 steps p
 constexpr int SIM_PAIRS = SIM_ROUND_OCTS * 4;           // float4 {x0,w0,x1,w1} per lane per round
 constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29][32] x 8 B
 constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
-__host__ __device__ constexpr int sim_slice_bytes(int npos) { return (npos + 1) * 512; }
-__host__ __device__ constexpr int sim_lds_bytes(int npos) {
-    return SIM_MASTER_BYTES + 2 * sim_slice_bytes(npos) + SIM_RING_BYTES;  // 151808 at npos = 28
+constexpr int SIM_SLICE_STRIDE = 29 * 512;              // table slice [entry][lane] x 8 B, fixed size
+__host__ __device__ constexpr int sim_slice_bytes(int npos) { return (npos + 1) * 512; }  // ring kernel only
+__host__ __device__ constexpr int sim_lds_bytes(int) {
+    return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES;  // 151808
 }
 
 __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
@@ -368,6 +371,44 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
                                              half[4] | (half[5] << 16), half[6] | (half[7] << 16));
 }
 
+__global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                           const uint8_t *__restrict__ lut_g, int npos,
+                                                           const int32_t *__restrict__ gaps_w,
+                                                           uint4 *__restrict__ codes32,
+                                                           unsigned long long *__restrict__ err_key) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ld) return;
+    const int g = blockIdx.y;  // 0 .. G8: the extra row G8 lies past row m-1 => all skipped
+    bool skipcol = true;
+    if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+    uint32_t half[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = g * 8 + r;
+        uint32_t idx = (uint32_t)npos;
+        if (row < m && c < n) {
+            const uint32_t byte = raw[(size_t)row * ld + c];
+            const uint32_t code = lut[byte];  // idx * 8, 224 = skipped, 0xFE / 0xFF = bad symbol
+            if (code >= 0xFEu) {
+                if (!skipcol) {
+                    const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
+                                                   ((unsigned long long)(code & 1u) << 8) | byte;
+                    atomicMin(err_key, key);
+                }
+            } else if (code != 224u) {
+                idx = code >> 3;
+            }
+        }
+        half[r] = idx * 512u + (uint32_t)(c & 63) * 8u;
+    }
+    // [oct][half][column]: each half is one coalesced 16-B load per lane
+    codes32[((size_t)g * 2 + 0) * ld + c] = make_uint4(half[0], half[1], half[2], half[3]);
+    codes32[((size_t)g * 2 + 1) * ld + c] = make_uint4(half[4], half[5], half[6], half[7]);
+}
+
 __device__ __forceinline__ void sim_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Diagnostics (MSA_SIM_MODE bit 6): per-phase cycle sums of workgroup 0, [wave][phase].
@@ -380,7 +421,8 @@ __device__ __forceinline__ unsigned long long sim_now() {
 
 // everything a producer needs for one oct, fetched one round ahead
 struct SimOct {
-    uint4 codes;  // codes16 of rows 8g..8g+7 (the all-skipped row G8 for a null oct): VMEM
+    uint4 c0, c1;  // codes32 of rows 8g..8g+7 (the all-skipped row G8 for a null oct): byte offsets
+                   // into a table slice, one dword per step so that a gather needs no address op
     float w[8];   // W[j][8g..8g+7], wave-uniform: scalar loads into SGPRs (a 64-lane broadcast
                   // load of 16 B costs the vector memory pipe as much as a full 1-KiB load)
 };
@@ -403,16 +445,16 @@ __device__ __forceinline__ SimPos sim_next(SimPos p, int G8) {
 // production instantiation has none of these branches: the compiler's s_waitcnt placement in
 // this loop is sensitive to every extra control-flow edge.
 template <bool DIAG>
-__device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16,
+__device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes32,
                                              int m, int64_t ld, const float *__restrict__ wmat, int ldw, int npos,
                                              int lane, int c, int rounds, int mode_arg) {
     const int mode = DIAG ? mode_arg : 0;
     const f32x2 *master = reinterpret_cast<const f32x2 *>(smem);
     unsigned char *slices = smem + SIM_MASTER_BYTES;
-    const int slice_bytes = sim_slice_bytes(npos);
+    constexpr int slice_bytes = SIM_SLICE_STRIDE;
     float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * slice_bytes);
     const int G8 = (m + 7) >> 3;
-    const uint4 *col = codes16 + c;
+    const uint4 *col = codes32 + c;
     // W is wave-uniform; it travels through the VECTOR memory path on purpose: scalar loads share
     // lgkmcnt with the LDS traffic and return out of order, so any wait on them drains the LDS
     // queue too.  An opaque zero in a VGPR keeps the compiler from turning these into s_load.
@@ -422,7 +464,7 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
 
     // 32-bit offsets (the launcher checks the arrays are < 4 GiB): 64-bit scalar multiplies would
     // dominate the fetch, and every instruction of a lone wave costs ~4.75 cycles.
-    const unsigned char *codes_bytes = reinterpret_cast<const unsigned char *>(codes16);
+    const unsigned char *codes_bytes = reinterpret_cast<const unsigned char *>(codes32);
     const uint32_t ld16 = (uint32_t)ld * 16u, c16 = (uint32_t)c * 16u;
     auto fetch = [&](SimOct (&u)[SIM_OCTS], SimPos p) {  // branch-free: null octs read the skipped row
         const bool past = p.j >= m - 1;
@@ -433,7 +475,9 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
             int gc = (past || g >= G8) ? G8 : g;
             const int gw = g >= G8 ? G8 - 1 : g;
             if (DIAG && (mode & 32)) gc = P;  // diagnostics: always the same few cache lines
-            u[t].codes = *reinterpret_cast<const uint4 *>(codes_bytes + ((uint32_t)gc * ld16 + c16));
+            const uint32_t off = (uint32_t)gc * 2u * ld16 + c16;
+            u[t].c0 = *reinterpret_cast<const uint4 *>(codes_bytes + off);
+            u[t].c1 = *reinterpret_cast<const uint4 *>(codes_bytes + (off + ld16));
             const float4 *wp = reinterpret_cast<const float4 *>(wbase + (wrow + 8u * (uint32_t)gw));
             const float4 wa = wp[0], wb = wp[1];
             u[t].w[0] = wa.x; u[t].w[1] = wa.y; u[t].w[2] = wa.z; u[t].w[3] = wa.w;
@@ -449,8 +493,8 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     // this lane's table row index for row jn (its residue in that row), npos when skipped
     auto load_cj = [&](int jn) -> uint32_t {
         if (jn >= m - 1) return (uint32_t)npos << 9;
-        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
-        return cj[jn & 7];
+        const uint32_t *cj = reinterpret_cast<const uint32_t *>(col + ((size_t)(jn >> 3) * 2 + ((jn & 7) >> 2)) * ld);
+        return cj[jn & 3];
     };
     // producers share the copy of table row idx into slice[jn & 1]: entry e -> [e][lane]
     auto refresh = [&](int jn, uint32_t cjcode) {
@@ -459,13 +503,18 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         const f32x2 *mrow = master + idx * 32;
         for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
     };
-    auto gather = [&](const SimOct &o, const unsigned char *slice, f32x2 (&tv)[8]) {
-        const uint32_t cw[4] = {o.codes.x, o.codes.y, o.codes.z, o.codes.w};
+    // The gather address is the code itself: the slice base is a literal LDS address (this kernel
+    // has no static __shared__, so the dynamic segment starts at LDS address 0 -- checked at kernel
+    // entry) carried in the ds_read offset field, so a gather costs no address instruction.  Inline
+    // asm because the compiler would merge the two parities into one path with a selected base and
+    // an add per gather; its lgkmcnt bookkeeping does not see these reads, hence the explicit
+    // s_waitcnt at the top of emit_all.
+    auto gather = [&](const SimOct &o, auto base, f32x2 (&tv)[8]) {
+        constexpr uint32_t BASE = decltype(base)::value;
+        const uint32_t cw[8] = {o.c0.x, o.c0.y, o.c0.z, o.c0.w, o.c1.x, o.c1.y, o.c1.z, o.c1.w};
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            tv[2 * pp] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] & 0xFFFFu));
-            tv[2 * pp + 1] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] >> 16));
-        }
+        for (int s = 0; s < 8; ++s)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tv[s]) : "v"(cw[s]), "i"(BASE));
     };
     auto emit = [&](const SimOct &o, const f32x2 (&tv)[8], float4 *out) {
         // {x, w_eff} = {D, valid} * {W, W}: one v_pk_mul_f32 per step, W broadcast from the low or
@@ -484,12 +533,19 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     // arithmetic and memory requests issue while the gathers wait for the LDS
     f32x2 tvs[SIM_OCTS][8];
     auto gather_all = [&](const SimOct (&u)[SIM_OCTS], int j) {
-        const unsigned char *slice = slices + (j & 1) * slice_bytes;
+        // constant slice bases, so that the base folds into the ds_read offset field
+        if (j & 1) {
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], slice, tvs[t]);
+            for (int t = 0; t < SIM_OCTS; ++t)
+                gather(u[t], std::integral_constant<uint32_t, SIM_MASTER_BYTES + SIM_SLICE_STRIDE>{}, tvs[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], std::integral_constant<uint32_t, SIM_MASTER_BYTES>{}, tvs[t]);
+        }
     };
     auto emit_all = [&](const SimOct (&u)[SIM_OCTS], int r) {
         float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm gathers above
 #pragma unroll
         for (int t = 0; t < SIM_OCTS; ++t) emit(u[t], tvs[t], out + t * 4 * 64);
     };
@@ -555,11 +611,13 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
 
 template <bool DIAG>
 __global__ __launch_bounds__(512) void similarity_pc_kernel(
-    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
+    const uint4 *__restrict__ codes32, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int rounds, int mode_arg,
     float *__restrict__ q_out, float *__restrict__ mdk_out) {
     const int mode = DIAG ? mode_arg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the producers address the table slices by literal LDS addresses (see `gather`)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + lane;  // < ld
@@ -569,10 +627,10 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
     }
     __syncthreads();
     if (wave != 0) {
-        sim_producer<DIAG>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, rounds, mode);
+        sim_producer<DIAG>(wave - 1, smem, codes32, m, ld, wmat, ldw, npos, lane, c, rounds, mode);
     } else {
         __builtin_amdgcn_s_setprio(3);  // the chain wave wins every issue arbitration on its SIMD
-        const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * sim_slice_bytes(npos));
+        const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
         f32x2 acc = {0.0f, 0.0f};  // {num, den}
         sim_barrier();             // slice[0] staged
         sim_barrier();             // round 0 produced
@@ -905,6 +963,13 @@ void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_
                                              err_key);
 }
 
+void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
+                         const int32_t *gaps_w, void *codes32, unsigned long long *err_key) {
+    dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
+    sim_encode32_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes32),
+                                             err_key);
+}
+
 // MSA_SIM_MODE (diagnostics only, never set in production): bit0 producers skip gather/emit,
 // bit1 consumer skips the chain
 static int sim_debug_mode() {
@@ -1170,7 +1235,7 @@ extern "C" int msa_debug_sim_stamps(unsigned long long *out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sim_stamps), sizeof(unsigned long long) * 64);
 }
 
-int launch_similarity_pc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
+int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64_t ld, const float *wmat, int ldw,
                          const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out) {
     const int G8 = (m + 7) / 8;
     long long rounds = 0;  // row-aligned: every row j takes ceil(octs_j / ROUND_OCTS) rounds
@@ -1181,7 +1246,7 @@ int launch_similarity_pc(hipStream_t s, const void *codes16, int m, int n, int64
     auto kern = mode ? similarity_pc_kernel<true> : similarity_pc_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    kern<<<(n + 63) / 64, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw,
+    kern<<<(n + 63) / 64, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes32), m, n, ld, wmat, ldw,
                                                        reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds,
                                                        mode, q_out, mdk_out);
     return 0;
