@@ -71,6 +71,7 @@ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 struct msa_ctx {
     int device = 0;
+    int cus = 256;  // compute units of the device
     hipStream_t stream = nullptr;
     char hip_err[256] = {0};
 
@@ -339,6 +340,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     const int G8 = (m + 7) / 8;
     const char *which = getenv("MSA_SIM_KERNEL");
     const bool ring_kernel = which && which[0] == 'r';
+    const int tcols = msak::sim_tile_cols(n, c->cus);
     HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
@@ -347,7 +349,8 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         if (ring_kernel)
             msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
         else
-            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
+            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
+                                      tcols);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->q.reserve((size_t)n + 64));
@@ -359,7 +362,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         int e;
         if (!ring_kernel) {
             e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                           gw_dev, c->q.p, c->mdk.p);
+                                           gw_dev, c->q.p, c->mdk.p, tcols);
         } else {
             HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
             e = msak::launch_similarity_ring(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
@@ -584,6 +587,10 @@ int msa_ctx_create(int device, msa_ctx **out) {
     msa_ctx *c = new (std::nothrow) msa_ctx();
     if (!c) return MSA_E_NOMEM;
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return MSA_E_HIP;

@@ -18,10 +18,11 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
                            float *out2);
 void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                          const int32_t *gaps_w, void *codes16, unsigned long long *err_key);
+int sim_tile_cols(int n, int cus);
 void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                         const int32_t *gaps_w, void *codes32, unsigned long long *err_key);
+                         const int32_t *gaps_w, void *codes32, unsigned long long *err_key, int tcols);
 int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64_t ld, const float *wmat, int ldw,
-                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out);
+                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols);
 int launch_similarity_ring(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
                            const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out,
                            int *hang_flag);

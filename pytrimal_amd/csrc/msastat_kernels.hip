@@ -330,8 +330,9 @@ constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29
 constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
 constexpr int SIM_SLICE_STRIDE = 29 * 512;              // table slice [entry][lane] x 8 B, fixed size
 __host__ __device__ constexpr int sim_slice_bytes(int npos) { return (npos + 1) * 512; }  // ring kernel only
+constexpr int SIM_WSTAGE_BYTES = 256;                   // per producer: the 16 W values of its round, [lane] x 4 B
 __host__ __device__ constexpr int sim_lds_bytes(int) {
-    return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES;  // 151808
+    return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + SIM_NP * SIM_WSTAGE_BYTES;  // 153600
 }
 
 __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__rest
                                                            const uint8_t *__restrict__ lut_g, int npos,
                                                            const int32_t *__restrict__ gaps_w,
                                                            uint4 *__restrict__ codes32,
-                                                           unsigned long long *__restrict__ err_key) {
+                                                           unsigned long long *__restrict__ err_key, int tcols) {
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__rest
     bool skipcol = true;
     if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
     uint32_t half[8];
+    const uint32_t lane8 = (uint32_t)(c % tcols) * 8u;  // the column's lane in its similarity workgroup
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = g * 8 + r;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__rest
                 idx = code >> 3;
             }
         }
-        half[r] = idx * 512u + (uint32_t)(c & 63) * 8u;
+        half[r] = idx * 512u + lane8;
     }
     // [oct][half][column]: each half is one coalesced 16-B load per lane
     codes32[((size_t)g * 2 + 0) * ld + c] = make_uint4(half[0], half[1], half[2], half[3]);
@@ -419,13 +421,12 @@ __device__ __forceinline__ unsigned long long sim_now() {
     return t;
 }
 
-// everything a producer needs for one oct, fetched one round ahead
+// everything a producer needs for one oct, fetched two rounds ahead
 struct SimOct {
     uint4 c0, c1;  // codes32 of rows 8g..8g+7 (the all-skipped row G8 for a null oct): byte offsets
                    // into a table slice, one dword per step so that a gather needs no address op
-    float w[8];   // W[j][8g..8g+7], wave-uniform: scalar loads into SGPRs (a 64-lane broadcast
-                  // load of 16 B costs the vector memory pipe as much as a full 1-KiB load)
 };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // round position: row j and first oct gb of the round; rows own the octs (j+1)>>3 .. G8-1
 struct SimPos {
@@ -455,41 +456,39 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * slice_bytes);
     const int G8 = (m + 7) >> 3;
     const uint4 *col = codes32 + c;
-    // W is wave-uniform; it travels through the VECTOR memory path on purpose: scalar loads share
-    // lgkmcnt with the LDS traffic and return out of order, so any wait on them drains the LDS
-    // queue too.  An opaque zero in a VGPR keeps the compiler from turning these into s_load.
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    const float *wbase = wmat + vzero;
+    // W[j][k..k+15] of a round is wave-uniform.  Lanes load it as 16 consecutive floats with ONE vector
+    // load (a 64-lane broadcast load of 16 B costs the vector memory pipe as much as a full 1-KiB load,
+    // and that pipe is what bounds this kernel), park them in a private LDS line and read them back
+    // as four broadcast ds_read_b128 (same address in every lane) right behind the gathers.  Scalar
+    // loads would share lgkmcnt with the LDS traffic and return out of order.
+    const float *wlane = wmat + (lane & 15);
+    float *wstage = reinterpret_cast<float *>(smem + SIM_MASTER_BYTES + 2 * slice_bytes + SIM_RING_BYTES +
+                                              P * SIM_WSTAGE_BYTES);
+    const uint32_t wstage_addr = (uint32_t)(SIM_MASTER_BYTES + 2 * slice_bytes + SIM_RING_BYTES + P * SIM_WSTAGE_BYTES);
 
     // 32-bit offsets (the launcher checks the arrays are < 4 GiB): 64-bit scalar multiplies would
     // dominate the fetch, and every instruction of a lone wave costs ~4.75 cycles.
     const unsigned char *codes_bytes = reinterpret_cast<const unsigned char *>(codes32);
     const uint32_t ld16 = (uint32_t)ld * 16u, c16 = (uint32_t)c * 16u;
-    auto fetch = [&](SimOct (&u)[SIM_OCTS], SimPos p) {  // branch-free: null octs read the skipped row
+    auto fetch = [&](SimOct (&u)[SIM_OCTS], float &wv, SimPos p) {  // branch-free: null octs read the skipped row
         const bool past = p.j >= m - 1;
         const uint32_t wrow = (uint32_t)(past ? 0 : p.j) * (uint32_t)ldw;
 #pragma unroll
         for (int t = 0; t < SIM_OCTS; ++t) {
             const int g = p.gb + P * SIM_OCTS + t;
             int gc = (past || g >= G8) ? G8 : g;
-            const int gw = g >= G8 ? G8 - 1 : g;
             if (DIAG && (mode & 32)) gc = P;  // diagnostics: always the same few cache lines
             const uint32_t off = (uint32_t)gc * 2u * ld16 + c16;
             u[t].c0 = *reinterpret_cast<const uint4 *>(codes_bytes + off);
             u[t].c1 = *reinterpret_cast<const uint4 *>(codes_bytes + (off + ld16));
-            const float4 *wp = reinterpret_cast<const float4 *>(wbase + (wrow + 8u * (uint32_t)gw));
-            const float4 wa = wp[0], wb = wp[1];
-            u[t].w[0] = wa.x; u[t].w[1] = wa.y; u[t].w[2] = wa.z; u[t].w[3] = wa.w;
-            u[t].w[4] = wb.x; u[t].w[5] = wb.y; u[t].w[6] = wb.z; u[t].w[7] = wb.w;
         }
+        // a null oct multiplies zero table entries: any finite W does (padding columns of W are zero,
+        // a read that runs past the row end lands in the next row)
+        const int g0 = p.gb + P * SIM_OCTS;
+        const int gw = g0 >= G8 ? G8 - 1 : g0;
+        wv = wlane[wrow + 8u * (uint32_t)gw];
     };
-    // Scalar loads and LDS traffic share lgkmcnt, and scalar data returns out of order: the
-    // only cheap place to wait for the W values is where the LDS queue is empty anyway, i.e.
-    // right after a barrier.  Touching them there makes the compiler put its wait there.
-    auto settle = [&](const SimOct (&u)[SIM_OCTS]) {
-        (void)u;  // nothing to settle: W now arrives under vmcnt
-    };
+    auto settle = [&](const SimOct (&u)[SIM_OCTS]) { (void)u; };
     // this lane's table row index for row jn (its residue in that row), npos when skipped
     auto load_cj = [&](int jn) -> uint32_t {
         if (jn >= m - 1) return (uint32_t)npos << 9;
@@ -516,10 +515,10 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         for (int s = 0; s < 8; ++s)
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(tv[s]) : "v"(cw[s]), "i"(BASE));
     };
-    auto emit = [&](const SimOct &o, const f32x2 (&tv)[8], float4 *out) {
+    auto emit = [&](const f32x4 &w03, const f32x4 &w47, const f32x2 (&tv)[8], float4 *out) {
         // {x, w_eff} = {D, valid} * {W, W}: one v_pk_mul_f32 per step, W broadcast from the low or
         // the high half of an aligned register pair through op_sel (no moves, no scratch)
-        const f32x2 wp[4] = {{o.w[0], o.w[1]}, {o.w[2], o.w[3]}, {o.w[4], o.w[5]}, {o.w[6], o.w[7]}};
+        const f32x2 wp[4] = {{w03.x, w03.y}, {w03.z, w03.w}, {w47.x, w47.y}, {w47.z, w47.w}};
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             f32x2 xa, xb;
@@ -532,7 +531,10 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     // stores); the next-but-one round's fetch is slotted between the two so that its scalar
     // arithmetic and memory requests issue while the gathers wait for the LDS
     f32x2 tvs[SIM_OCTS][8];
-    auto gather_all = [&](const SimOct (&u)[SIM_OCTS], int j) {
+    f32x4 wq[2 * SIM_OCTS];
+    auto gather_all = [&](const SimOct (&u)[SIM_OCTS], float wv, int j) {
+        wstage[lane] = wv;  // lanes 16.. hold copies; the LDS executes a wave's operations in order
+        asm volatile("" ::: "memory");
         // constant slice bases, so that the base folds into the ds_read offset field
         if (j & 1) {
 #pragma unroll
@@ -542,12 +544,24 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
 #pragma unroll
             for (int t = 0; t < SIM_OCTS; ++t) gather(u[t], std::integral_constant<uint32_t, SIM_MASTER_BYTES>{}, tvs[t]);
         }
-    };
-    auto emit_all = [&](const SimOct (&u)[SIM_OCTS], int r) {
-        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm gathers above
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) emit(u[t], tvs[t], out + t * 4 * 64);
+        for (int i = 0; i < 2 * SIM_OCTS; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[i]) : "v"(wstage_addr), "i"(16 * i));
+    };
+    auto emit_all = [&](int r) {
+        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
+        // the asm reads above: the registers are tied to the wait so that no use (not even a copy)
+        // can be scheduled ahead of it
+        static_assert(SIM_OCTS == 2, "operand list below");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(tvs[0][0]), "+v"(tvs[0][1]),
+                       "+v"(tvs[0][2]), "+v"(tvs[0][3]), "+v"(tvs[0][4]), "+v"(tvs[0][5]), "+v"(tvs[0][6]),
+                       "+v"(tvs[0][7]), "+v"(tvs[1][0]), "+v"(tvs[1][1]), "+v"(tvs[1][2]), "+v"(tvs[1][3]),
+                       "+v"(tvs[1][4]), "+v"(tvs[1][5]), "+v"(tvs[1][6]), "+v"(tvs[1][7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) emit(wq[2 * t], wq[2 * t + 1], tvs[t], out + t * 4 * 64);
     };
 
     SimPos pos = {0, 0};
@@ -557,33 +571,25 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     // Loads run TWO rounds ahead of their use (three register sets): under load an L2 hit takes
     // about as long as a whole round, so one round of distance leaves the latency exposed.
     SimOct a[SIM_OCTS], b[SIM_OCTS], d[SIM_OCTS];
+    float wa, wb, wd;
     SimPos pos1 = sim_next(pos, G8);
-    fetch(a, pos);
-    fetch(b, pos1);
+    fetch(a, wa, pos);
+    fetch(b, wb, pos1);
     const bool stamp = DIAG && (mode & 64) && blockIdx.x == 0;
     unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
-    auto round = [&](SimOct (&cur)[SIM_OCTS], SimOct (&far)[SIM_OCTS], int r) {
+    auto round = [&](SimOct (&cur)[SIM_OCTS], float wcur, SimOct (&far)[SIM_OCTS], float &wfar, int r) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (stamp) t0 = sim_now();
         settle(cur);
         if (stamp) t1 = sim_now();
         const SimPos pos2 = sim_next(pos1, G8);
-        // The LDS is the shared bottleneck of the workgroup: half of the producers start their
-        // burst right after the barrier, the other half fetch first, so the bursts do not pile up
-        // (no extra synchronisation, the skew is just instruction order).
         if (DIAG && (mode & 1)) {
-            fetch(far, pos2);
-        } else if (P < SIM_SKEW_SPLIT) {
-            gather_all(cur, pos.j);
-            fetch(far, pos2);
-            if (stamp) t2 = sim_now();
-            emit_all(cur, r);
-            if (stamp) t3 = sim_now();
+            fetch(far, wfar, pos2);
         } else {
-            fetch(far, pos2);
+            gather_all(cur, wcur, pos.j);
+            fetch(far, wfar, pos2);
             if (stamp) t2 = sim_now();
-            gather_all(cur, pos.j);
-            emit_all(cur, r);
+            emit_all(r);
             if (stamp) t3 = sim_now();
         }
         if (pos1.j != pos.j) {  // last round of row j (wave- and workgroup-uniform): stage row j+1
@@ -600,9 +606,9 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         pos1 = pos2;
     };
     for (int r = 0; r < rounds; r += 3) {
-        round(a, d, r);
-        if (r + 1 < rounds) round(b, a, r + 1);
-        if (r + 2 < rounds) round(d, b, r + 2);
+        round(a, wa, d, wd, r);
+        if (r + 1 < rounds) round(b, wb, a, wa, r + 1);
+        if (r + 2 < rounds) round(d, wd, b, wb, r + 2);
     }
     if (stamp && lane == 0)
         for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
@@ -613,22 +619,25 @@ template <bool DIAG>
 __global__ __launch_bounds__(512) void similarity_pc_kernel(
     const uint4 *__restrict__ codes32, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int rounds, int mode_arg,
-    float *__restrict__ q_out, float *__restrict__ mdk_out) {
+    float *__restrict__ q_out, float *__restrict__ mdk_out, int tcols) {
     const int mode = DIAG ? mode_arg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the producers address the table slices by literal LDS addresses (see `gather`)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + lane;  // < ld
+    const int c = blockIdx.x * tcols + lane;
+    // Only the first tcols lanes of every wave work (EXEC stays masked for the whole kernel): LDS time
+    // is per active lane, and the columns are spread over all CUs (sim_tile_cols).
+    const bool active = lane < tcols && c < ld;
     {
         f32x2 *master = reinterpret_cast<f32x2 *>(smem);
         for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t];
     }
     __syncthreads();
     if (wave != 0) {
-        sim_producer<DIAG>(wave - 1, smem, codes32, m, ld, wmat, ldw, npos, lane, c, rounds, mode);
-    } else {
+        if (active) sim_producer<DIAG>(wave - 1, smem, codes32, m, ld, wmat, ldw, npos, lane, c, rounds, mode);
+    } else if (active) {
         __builtin_amdgcn_s_setprio(3);  // the chain wave wins every issue arbitration on its SIMD
         const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
         f32x2 acc = {0.0f, 0.0f};  // {num, den}
@@ -963,11 +972,25 @@ void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_
                                              err_key);
 }
 
+// Columns per similarity workgroup.  The kernel's time is (pair steps) x (cycles per step) whatever the
+// column count, and the cycles per step are mostly LDS time, which scales with the active lanes: so the
+// columns are spread over as many CUs as there are (one workgroup per CU), down to 16 lanes per wave.
+int sim_tile_cols(int n, int cus) {
+    if (const char *e = getenv("MSA_SIM_TCOLS")) {
+        const int t = atoi(e);
+        if (t >= 16 && t <= 64) return t;
+    }
+    if (cus < 1) cus = 256;
+    int t = (n + cus - 1) / cus;
+    t = (t + 7) / 8 * 8;
+    return t < 16 ? 16 : (t > 64 ? 64 : t);  // >= 16: the lanes of a producer fetch its 16 W values
+}
+
 void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                         const int32_t *gaps_w, void *codes32, unsigned long long *err_key) {
+                         const int32_t *gaps_w, void *codes32, unsigned long long *err_key, int tcols) {
     dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
     sim_encode32_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes32),
-                                             err_key);
+                                             err_key, tcols);
 }
 
 // MSA_SIM_MODE (diagnostics only, never set in production): bit0 producers skip gather/emit,
@@ -1236,7 +1259,7 @@ extern "C" int msa_debug_sim_stamps(unsigned long long *out64) {
 }
 
 int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64_t ld, const float *wmat, int ldw,
-                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out) {
+                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols) {
     const int G8 = (m + 7) / 8;
     long long rounds = 0;  // row-aligned: every row j takes ceil(octs_j / ROUND_OCTS) rounds
     for (int j = 0; j + 1 < m; ++j) rounds += (G8 - ((j + 1) >> 3) + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
@@ -1246,9 +1269,9 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
     auto kern = mode ? similarity_pc_kernel<true> : similarity_pc_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    kern<<<(n + 63) / 64, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes32), m, n, ld, wmat, ldw,
-                                                       reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds,
-                                                       mode, q_out, mdk_out);
+    kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes32), m, n, ld, wmat, ldw,
+                                                   reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds, mode,
+                                                   q_out, mdk_out, tcols);
     return 0;
 }
 
