@@ -73,6 +73,8 @@ struct msa_ctx {
     int device = 0;
     int cus = 256;  // compute units of the device
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // the similarity denominators run beside the numerator kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char hip_err[256] = {0};
 
     // alignment
@@ -96,7 +98,7 @@ struct msa_ctx {
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
     DevBuf<int32_t> gaps_w;
-    DevBuf<float> q, mdk;
+    DevBuf<float> q, mdk, simnum, simden;
     DevBuf<unsigned long long> errkey;
     DevBuf<int> errflag;
     DevBuf<uint32_t> col_ok;
@@ -135,15 +137,16 @@ struct ProfScope {  // records an event pair around a launch sequence when profi
     msa_ctx *c;
     const char *name;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(msa_ctx *ctx, const char *nm) : c(ctx), name(nm) {
+    hipStream_t st;
+    ProfScope(msa_ctx *ctx, const char *nm, hipStream_t on = nullptr) : c(ctx), name(nm), st(on ? on : ctx->stream) {
         if (!c->prof_on) return;
         a = take();
         b = take();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~ProfScope() {
         if (!c->prof_on) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         ProfEntry &e = c->prof[name];
         e.pending.emplace_back(a, b);
         e.launches++;
@@ -338,29 +341,75 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         gw_dev = c->gaps_w.p;
     }
     const int G8 = (m + 7) / 8;
+    // kernel choice: register-resident codes when the rows fit (m <= 2016), else the streaming
+    // producer/consumer kernel; MSA_SIM_KERNEL=pc|ring force the other variants (parity-tested)
     const char *which = getenv("MSA_SIM_KERNEL");
     const bool ring_kernel = which && which[0] == 'r';
-    const int tcols = msak::sim_tile_cols(n, c->cus);
+    const bool fits = msak::similarity_rc_fits(m);
+    const bool forced_rc = which && which[0] == 'c';  // "codes resident", one kernel for both sums
+    const bool rc_kernel = !ring_kernel && forced_rc && fits;
+    const bool split = !ring_kernel && !rc_kernel && !(which && which[0] == 'p') && fits;
+    // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
+    const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32), c->cus / 2) : c->cus;
+    const int tcols = ring_kernel ? 64 : msak::sim_tile_cols(n, cus_num);
     HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
-    {
-        ProfScope ps(c, "encode");
-        if (ring_kernel)
-            msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
-        else
-            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
-                                      tcols);
-    }
-    HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->q.reserve((size_t)n + 64));
     HIPCHK(c, c->mdk.reserve((size_t)n + 64));
-    {
+    if (split) {
+        // numerators and denominators are independent sequential sums: two kernels, two streams
+        rc = ensure_planes(c);
+        if (rc) return rc;
+        HIPCHK(c, c->simnum.reserve((size_t)n + 64));
+        HIPCHK(c, c->simden.reserve((size_t)c->nchunk * 32 + 64));
+        if (!c->stream2) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
         ProfScope ps(c, "sim");
-        // MSA_SIM_KERNEL=ring selects the barrier-free variant (parity-tested, but measured slower:
-        // 19.2 ms vs 15.6 ms at 2000 x 10000)
+        const bool serial = getenv("MSA_SIM_SERIAL") != nullptr;  // diagnostics: both kernels on one stream
+        hipStream_t sden = serial ? c->stream : c->stream2;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(sden, c->ev_fork, 0));
+        {
+            ProfScope pd(c, "simden", sden);
+            const int e = msak::launch_sim_den(sden, c->planes.p, c->nchunk, c->m_pad, m, n, c->wmat.p, c->ldw,
+                                               c->simden.p);
+            if (e) return fail_hip(c, (hipError_t)e, "launch_sim_den");
+        }
+        HIPCHK(c, hipEventRecord(c->ev_join, sden));
+        {
+            ProfScope pe(c, "encode");
+            msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
+                                      tcols, true);
+        }
+        {
+            ProfScope pn(c, "simnum");
+            const int e = msak::launch_similarity_num(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p,
+                                                      npos, c->simnum.p, tcols);
+            if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_num");
+        }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
+    } else {
+        {
+            ProfScope ps(c, "encode");
+            if (ring_kernel || rc_kernel)
+                msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p,
+                                          c->errkey.p, tcols, false);
+            else
+                msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p,
+                                          c->errkey.p, tcols);
+        }
+        HIPCHK(c, hipGetLastError());
+        ProfScope ps(c, "sim");
         int e;
-        if (!ring_kernel) {
+        if (rc_kernel) {
+            e = msak::launch_similarity_rc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
+                                           gw_dev, c->q.p, c->mdk.p, tcols);
+        } else if (!ring_kernel) {
             e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                            gw_dev, c->q.p, c->mdk.p, tcols);
         } else {
@@ -608,10 +657,16 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release();
     c->stats2.release(); c->codes16.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
-    c->q.release(); c->mdk.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
+    c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release();
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipEventDestroy(c->ev_fork);
+        (void)hipEventDestroy(c->ev_join);
+        (void)hipStreamDestroy(c->stream2);
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -861,7 +916,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
 
 int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
     if (!c || !kernel) return MSA_E_INVALID;
-    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster"};
+    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "simnum", "simden", "overlap", "cluster"};
     bool known = false;
     for (const char *nm : names) known |= (std::strcmp(nm, kernel) == 0);
     if (!known) return MSA_E_INVALID;

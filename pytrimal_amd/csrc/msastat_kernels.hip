@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
                                                            const uint8_t *__restrict__ lut_g, int npos,
                                                            const int32_t *__restrict__ gaps_w,
                                                            uint4 *__restrict__ codes16,
-                                                           unsigned long long *__restrict__ err_key) {
+                                                           unsigned long long *__restrict__ err_key, int tcols,
+                                                           int eshift, int lshift) {
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
     bool skipcol = true;
     if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
     uint32_t half[8];
+    const uint32_t lane8 = (uint32_t)(c % tcols) << lshift;  // the column's lane in its similarity workgroup
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = g * 8 + r;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
                 idx = code >> 3;
             }
         }
-        half[r] = idx * 512u + (uint32_t)(c & 63) * 8u;
+        half[r] = (idx << eshift) + lane8;
     }
     codes16[(size_t)g * ld + c] = make_uint4(half[0] | (half[1] << 16), half[2] | (half[3] << 16),
                                              half[4] | (half[5] << 16), half[6] | (half[7] << 16));
@@ -413,8 +415,31 @@ __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__rest
 
 __device__ __forceinline__ void sim_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The chain itself: 28 dependent v_pk_add_f32 {num, den} += {x, w_eff} in pair order, as ONE asm block.
+// Left to the compiler, every dependent pair of packed-fp32 adds gets an s_nop between them (its
+// dst-sel forwarding hazard rule, which does not apply to full-dword packed adds; parity is bit-exact
+// without it) and a lone wave pays a whole issue slot for each: 8.3 instead of 4.7 cycles per step
+// (profiles/r01_ubench_chain_forms.txt).
+__device__ __forceinline__ void sim_chain(f32x2 &acc, const float4 (&v)[SIM_PAIRS / 4]) {
+    static_assert(SIM_PAIRS / 4 == 14, "operand list below");
+#define SIM_XY(p) "v"(f32x2{v[p].x, v[p].y}), "v"(f32x2{v[p].z, v[p].w})
+    asm volatile(
+        "v_pk_add_f32 %0, %1, %0\n\tv_pk_add_f32 %0, %2, %0\n\tv_pk_add_f32 %0, %3, %0\n\tv_pk_add_f32 %0, %4, %0\n\t"
+        "v_pk_add_f32 %0, %5, %0\n\tv_pk_add_f32 %0, %6, %0\n\tv_pk_add_f32 %0, %7, %0\n\tv_pk_add_f32 %0, %8, %0\n\t"
+        "v_pk_add_f32 %0, %9, %0\n\tv_pk_add_f32 %0, %10, %0\n\tv_pk_add_f32 %0, %11, %0\n\tv_pk_add_f32 %0, %12, %0\n\t"
+        "v_pk_add_f32 %0, %13, %0\n\tv_pk_add_f32 %0, %14, %0\n\tv_pk_add_f32 %0, %15, %0\n\tv_pk_add_f32 %0, %16, %0\n\t"
+        "v_pk_add_f32 %0, %17, %0\n\tv_pk_add_f32 %0, %18, %0\n\tv_pk_add_f32 %0, %19, %0\n\tv_pk_add_f32 %0, %20, %0\n\t"
+        "v_pk_add_f32 %0, %21, %0\n\tv_pk_add_f32 %0, %22, %0\n\tv_pk_add_f32 %0, %23, %0\n\tv_pk_add_f32 %0, %24, %0\n\t"
+        "v_pk_add_f32 %0, %25, %0\n\tv_pk_add_f32 %0, %26, %0\n\tv_pk_add_f32 %0, %27, %0\n\tv_pk_add_f32 %0, %28, %0"
+        : "+v"(acc)
+        : SIM_XY(0), SIM_XY(1), SIM_XY(2), SIM_XY(3), SIM_XY(4), SIM_XY(5), SIM_XY(6), SIM_XY(7), SIM_XY(8), SIM_XY(9),
+          SIM_XY(10), SIM_XY(11), SIM_XY(12), SIM_XY(13));
+#undef SIM_XY
+}
+
 // Diagnostics (MSA_SIM_MODE bit 6): per-phase cycle sums of workgroup 0, [wave][phase].
 __device__ unsigned long long g_sim_stamps[8 * 8];
+__device__ int g_sim_diag;  // diagnostics switches of the DIAG instantiations (MSA_SIM_DIAG)
 __device__ __forceinline__ unsigned long long sim_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -660,14 +685,7 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
             for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto add = [&](const float4 (&v)[QP]) {
-#pragma unroll
-            for (int p = 0; p < QP; ++p) {
-                acc += f32x2{v[p].x, v[p].y};
-                acc += f32x2{v[p].z, v[p].w};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
+        auto add = [&](const float4 (&v)[QP]) { sim_chain(acc, v); };
         // one round: pending on entry = (x, y) holding quarters 2, 3 of the previous round, z free;
         // pending on exit = (y, z) holding quarters 2, 3 of this round, x free
         auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
@@ -715,6 +733,627 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
             mdk_out[c] = v;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity_mdk with REGISTER-RESIDENT codes (m <= 8 * 14 * RC_RMAX rows): the production kernel.
+//
+// In similarity_pc_kernel every workgroup re-reads its column tile of codes once per row j: at
+// 2000 x 10000 that is 85 GB through the vector memory pipe per launch, and the kernel's skeleton
+// (fetch + barriers, no LDS work, no chain) already takes 10.7 of its 13.7 ms.  The codes of a
+// producer do not depend on j, so here they live in its registers for the whole kernel:
+//   * rounds are aligned to ABSOLUTE oct positions (round q = octs 14q .. 14q+13), so producer P
+//     always works on octs 14q + 2P, 14q + 2P + 1 and the register holding them is a compile-time
+//     function of q: the row loop is unrolled over q.  Row j starts at round q0 = ((j+1)>>3) / 14;
+//     the octs of that round that lie at or before j contribute W = 0 (W is strictly upper
+//     triangular) -- exact no-ops, like the null octs past the last row;
+//   * 16-bit codes (byte offset into the table slice), two per dword: 8 VGPRs per oct, 144 for
+//     RC_RMAX = 18; a gather costs one SDWA add (slice base + halfword) and one ds_read_b64;
+//   * the only global traffic left in the loop is W: 16 consecutive floats per producer and
+//     round, DMA'd straight into LDS (global_load_lds_dword, no VGPR in flight) two rounds ahead,
+//     read back as four broadcast ds_read_b128.
+// The ring, the table slices, the consumer and the barrier protocol are those of
+// similarity_pc_kernel.  Rounds are padded to a multiple of 3 with pseudo-rows j = m-1, whose W
+// row is all zero.
+// ------------------------------------------------------------------------------------------
+constexpr int RC_RMAX = 18;
+constexpr int RC_WSTAGE_BYTES = 3 * 256;  // per producer: three rounds of 16 W values (x4 lane copies)
+__host__ __device__ constexpr int rc_lds_bytes() {
+    return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + SIM_NP * RC_WSTAGE_BYTES;  // 157184
+}
+
+template <int Q, class F>
+__device__ __forceinline__ void rc_unroll(F &&f) {
+    if constexpr (Q < RC_RMAX) {
+        f(std::integral_constant<int, Q>{});
+        rc_unroll<Q + 1>(f);
+    }
+}
+
+// the chain wave (shared protocol: 2 + rounds barriers, ring buffer = round parity)
+template <bool DIAG = false>
+__device__ __forceinline__ void sim_consumer(unsigned char *smem, int rounds, int lane, int c, int m, int n,
+                                             const int32_t *__restrict__ gaps_w, float *__restrict__ q_out,
+                                             float *__restrict__ mdk_out) {
+    if (DIAG && (g_sim_diag & 1)) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+    const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
+    f32x2 acc = {0.0f, 0.0f};  // {num, den}
+    sim_barrier();             // slice[0] staged
+    sim_barrier();             // round 0 produced
+    constexpr int QP = SIM_PAIRS / 4;
+    float4 s0[QP], s1[QP], s2[QP];
+#pragma unroll
+    for (int p = 0; p < QP; ++p) s0[p] = s1[p] = s2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto rd = [&](float4 (&v)[QP], const float4 *in, int quarter) {
+#pragma unroll
+        for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto add = [&](const float4 (&v)[QP]) { sim_chain(acc, v); };
+    const bool stamp = DIAG && blockIdx.x == 0;
+    unsigned long long tw = 0, tb = 0;
+    auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
+        unsigned long long t0 = 0, t1 = 0;
+        if (stamp) t0 = sim_now();
+        const float4 *in = ring + ((r - 1) & 1) * SIM_PAIRS * 64 + lane;
+        rd(z, in, 0);
+        add(x);
+        rd(x, in, 1);
+        add(y);
+        rd(y, in, 2);
+        add(z);
+        rd(z, in, 3);
+        add(x);
+        if (stamp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t1 = sim_now();
+        }
+        sim_barrier();
+        if (stamp) {
+            tw += t1 - t0;
+            tb += sim_now() - t1;
+        }
+    };
+    for (int r = 1; r + 2 <= rounds; r += 3) {
+        one_round(s0, s1, s2, r);
+        one_round(s1, s2, s0, r + 1);
+        one_round(s2, s0, s1, r + 2);
+    }
+    add(s0);
+    add(s1);
+    if (stamp && lane == 0) {
+        g_sim_stamps[0] = tw;
+        g_sim_stamps[1] = tb;
+        g_sim_stamps[2] = (unsigned long long)rounds;
+    }
+    if (c < n) {
+        const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+        float q = 0.0f, v = 0.0f;
+        if (!skip && acc.y != 0.0f) {
+            q = acc.x / acc.y;
+            v = (float)exp(-(double)q);
+            v = v > 1.0f ? 1.0f : v;
+        }
+        if (q_out) q_out[c] = q;
+        mdk_out[c] = v;
+    }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void rc_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
+                                            int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
+                                            int c, int R, int pad) {
+    const f32x2 *master = reinterpret_cast<const f32x2 *>(smem);
+    unsigned char *slices = smem + SIM_MASTER_BYTES;
+    float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
+    const uint32_t wstage_base =
+        (uint32_t)(SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + P * RC_WSTAGE_BYTES);
+    const int G8 = (m + 7) >> 3;
+    const uint4 *col = codes16 + c;
+
+    // this producer's codes, for the whole kernel
+    uint4 cod[RC_RMAX][SIM_OCTS];
+#pragma unroll
+    for (int q = 0; q < RC_RMAX; ++q)
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const int g = q * SIM_ROUND_OCTS + P * SIM_OCTS + t;
+            cod[q][t] = col[(size_t)(g >= G8 ? G8 : g) * ld];  // row G8 of the array is all-skipped
+        }
+
+    auto load_cj = [&](int jn) -> uint32_t {
+        if (jn >= m - 1) return (uint32_t)npos << 9;
+        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
+        return cj[jn & 7];
+    };
+    auto refresh = [&](int jn, uint32_t cjcode) {
+        const uint32_t idx = cjcode >> 9;
+        f32x2 *sl = reinterpret_cast<f32x2 *>(slices + (jn & 1) * SIM_SLICE_STRIDE) + lane;
+        const f32x2 *mrow = master + idx * 32;
+        for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
+    };
+
+    // round positions (row, absolute round); rows past m-2 are the zero-weight pseudo-rows
+    struct Pos {
+        int j, q;
+    };
+    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / SIM_ROUND_OCTS : R - 1; };
+    auto next = [&](Pos p) {
+        if (p.q + 1 < R) return Pos{p.j, p.q + 1};
+        return Pos{p.j + 1, q0_of(p.j + 1)};
+    };
+    // W[j][8 g0 .. 8 g0 + 15] -> LDS, 64 lanes x 4 B (lane i carries element i & 15).  A round whose
+    // octs are both null multiplies zero table entries: any finite W does.
+    const uint32_t lane15x4 = (uint32_t)(lane & 15) * 4u;
+    auto wdma = [&](Pos p, int buf) {
+        const int g0 = p.q * SIM_ROUND_OCTS + P * SIM_OCTS;
+        const int gw = g0 >= G8 ? G8 - 1 : g0;
+        const int jr = p.j < m - 1 ? p.j : m - 1;
+        const float *src = wmat + ((size_t)jr * (size_t)ldw + (size_t)(8 * gw));
+        const uint32_t dst = wstage_base + (uint32_t)buf * 256u;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(lane15x4), "s"(src) : "m0", "memory");
+    };
+
+    Pos pos2 = {0, 0};
+    wdma(pos2, 0);
+    pos2 = next(pos2);
+    wdma(pos2, 1);
+    pos2 = next(pos2);
+    int buf = 0;  // stage buffer of the current round (r % 3)
+    int r = 0;
+
+    refresh(0, load_cj(0));
+    uint32_t cj_next = load_cj(1);
+    sim_barrier();  // slice[0] complete
+
+    f32x2 tvs[SIM_OCTS][8];
+    f32x4 wq[2 * SIM_OCTS];
+    const bool stamp = DIAG && blockIdx.x == 0;
+    if (DIAG && (g_sim_diag & 2)) __builtin_amdgcn_s_setprio(3);
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tg = 0;
+    if (stamp) tg = sim_now();
+    auto body = [&](auto qc, int j) __attribute__((always_inline)) {
+        constexpr int Q = decltype(qc)::value;
+        // W of this round has landed (DMA'd two rounds ago; the one of the next round may be in flight)
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        const int bfar = buf == 0 ? 2 : buf - 1;  // (r + 2) % 3
+        wdma(pos2, bfar);
+        pos2 = next(pos2);
+        const uint32_t vbase = (uint32_t)(SIM_MASTER_BYTES + (j & 1) * SIM_SLICE_STRIDE);
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const uint32_t cw[4] = {cod[Q][t].x, cod[Q][t].y, cod[Q][t].z, cod[Q][t].w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                uint32_t a0, a1;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                    : "=v"(a0) : "v"(vbase), "v"(cw[s4]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                    : "=v"(a1) : "v"(vbase), "v"(cw[s4]));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(tvs[t][2 * s4]) : "v"(a0));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(tvs[t][2 * s4 + 1]) : "v"(a1));
+            }
+        }
+        const uint32_t waddr = wstage_base + (uint32_t)buf * 256u;
+#pragma unroll
+        for (int i = 0; i < 2 * SIM_OCTS; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[i]) : "v"(waddr), "i"(16 * i));
+        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
+        static_assert(SIM_OCTS == 2, "operand list below");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(tvs[0][0]), "+v"(tvs[0][1]),
+                       "+v"(tvs[0][2]), "+v"(tvs[0][3]), "+v"(tvs[0][4]), "+v"(tvs[0][5]), "+v"(tvs[0][6]),
+                       "+v"(tvs[0][7]), "+v"(tvs[1][0]), "+v"(tvs[1][1]), "+v"(tvs[1][2]), "+v"(tvs[1][3]),
+                       "+v"(tvs[1][4]), "+v"(tvs[1][5]), "+v"(tvs[1][6]), "+v"(tvs[1][7])
+                     :
+                     : "memory");
+        unsigned long long td = 0;
+        if (stamp) td = sim_now();
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const f32x4 w03 = wq[2 * t], w47 = wq[2 * t + 1];
+            const f32x2 wp[4] = {{w03.x, w03.y}, {w03.z, w03.w}, {w47.x, w47.y}, {w47.z, w47.w}};
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                f32x2 xa, xb;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tvs[t][2 * pp]), "v"(wp[pp]));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tvs[t][2 * pp + 1]), "v"(wp[pp]));
+                out[(t * 4 + pp) * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
+            }
+        }
+        if (Q == R - 1) {  // last round of row j (workgroup-uniform): stage the table slice of row j+1
+            refresh(j + 1, cj_next);
+            cj_next = load_cj(j + 2);
+        }
+        if (stamp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tf = sim_now();
+            sim_barrier();
+            const unsigned long long tn = sim_now();
+            acc_t[0] += td - tg;  // barrier exit -> gathers and W landed
+            acc_t[1] += tf - td;  // multiplies, ring stores (drained), slice refresh
+            acc_t[2] += tn - tf;  // barrier wait
+            tg = tn;
+        } else {
+            sim_barrier();
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+        ++r;
+    };
+    const int nrows = m - 1 + pad;
+    for (int jj = 0; jj < nrows; ++jj) {
+        const int q0 = q0_of(jj);
+        rc_unroll<0>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int Q = decltype(qc)::value;
+            if (Q >= q0 && Q < R) body(qc, jj);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two W prefetches past the end
+    if (stamp && lane == 0)
+        for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
+    sim_barrier();  // the consumer's drain round
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(512) void similarity_rc_kernel(
+    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
+    const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int R, int pad, int rounds,
+    float *__restrict__ q_out, float *__restrict__ mdk_out, int tcols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the table slices and the W stage are addressed by literal LDS addresses
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * tcols + lane;
+    const bool active = lane < tcols && c < ld;  // EXEC stays masked for the whole kernel
+    {
+        f32x2 *master = reinterpret_cast<f32x2 *>(smem);
+        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t];
+    }
+    __syncthreads();
+    if (wave != 0) {
+        if (active) rc_producer<DIAG>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
+    } else if (active) {
+        sim_consumer<DIAG>(smem, rounds, lane, c, m, n, gaps_w, q_out, mdk_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity denominators as their own kernel.  den[c] = sum over valid pairs (j < k) of W[j][k] in
+// pair order (float32, sequential): it depends only on W and on which residues are valid, so it needs
+// no table, no codes and no LDS.  One wave = one 32-column chunk of the validity plane (plane 7 of
+// `planes`, [chunk][row] u32): the pair's lane mask is Vj & Vk, a scalar AND into EXEC, and the add
+// is one v_add_f32 with the wave-uniform W[j][k] under that mask -- lanes whose pair is not valid
+// keep their sum, which is what adding +0 would do.  Two instructions per pair step for a lone wave
+// (10.8 cycles measured, profiles/r01_ubench_den_wave.txt); it runs beside the numerator kernel on
+// CUs that one leaves idle.  Masks and W stream through the scalar cache (16 steps per buffer, two buffers,
+// lgkmcnt(0) discipline: scalar loads return out of order) and feed the adds as SGPR operands.
+// Rows start at the 16-aligned k below j+1 and end at the 16-aligned k above m: W is strictly upper
+// triangular and zero-padded, so the extra steps add +0.
+// ------------------------------------------------------------------------------------------
+constexpr int DEN_WAVES = 4;             // chunks per workgroup, one per SIMD
+constexpr int DEN_LDS_BYTES = 96 * 1024;  // never touched: keeps a numerator workgroup off this CU (see below)
+__global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t *__restrict__ planes, int nchunk,
+                                                                 int m_pad, int m, int n,
+                                                                 const float *__restrict__ wmat, int ldw,
+                                                                 float *__restrict__ den_out) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x * DEN_WAVES + wave;
+    if (chunk >= nchunk) return;
+    const uint32_t *masks = planes + ((size_t)7 * nchunk + chunk) * (size_t)m_pad;
+    const int lane = threadIdx.x & 63;
+    const int mend = (m + 15) & ~15;
+    float den = 0.0f;
+    uint32_t vnext = __builtin_amdgcn_readfirstlane(masks[0]);
+    for (int j = 0; j + 1 < m; ++j) {
+        const uint32_t vj = vnext;
+        vnext = __builtin_amdgcn_readfirstlane(masks[j + 1]);
+        if (vj == 0u) continue;  // no column of this chunk has a residue in row j
+        const int k0 = (j + 1) & ~15;
+        const int ng = (mend - k0) >> 4;  // >= 1 groups of 16 steps
+        const uint32_t *mp = masks + k0;
+        const float *wp = wmat + ((size_t)j * (size_t)ldw + (size_t)k0);
+        // buffers: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99]
+        asm volatile(
+            "s_mov_b64 s[10:11], exec\n\t"
+            "s_mov_b32 exec_hi, 0\n\t"
+            "s_mov_b32 s8, %1\n\ts_mov_b32 s9, %2\n\ts_mov_b64 s[12:13], %3\n\ts_mov_b64 s[14:15], %4\n\t"
+            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\ts_load_dwordx16 s[52:67], s[14:15], 0x0\n\t"
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_load_dwordx16 s[68:83], s[12:13], 0x40\n\ts_load_dwordx16 s[84:99], s[14:15], 0x40\n\t"
+            "s_and_b32 exec_lo, s8, s36\n\tv_add_f32 %0, s52, %0\n\t"
+            "s_and_b32 exec_lo, s8, s37\n\tv_add_f32 %0, s53, %0\n\t"
+            "s_and_b32 exec_lo, s8, s38\n\tv_add_f32 %0, s54, %0\n\t"
+            "s_and_b32 exec_lo, s8, s39\n\tv_add_f32 %0, s55, %0\n\t"
+            "s_and_b32 exec_lo, s8, s40\n\tv_add_f32 %0, s56, %0\n\t"
+            "s_and_b32 exec_lo, s8, s41\n\tv_add_f32 %0, s57, %0\n\t"
+            "s_and_b32 exec_lo, s8, s42\n\tv_add_f32 %0, s58, %0\n\t"
+            "s_and_b32 exec_lo, s8, s43\n\tv_add_f32 %0, s59, %0\n\t"
+            "s_and_b32 exec_lo, s8, s44\n\tv_add_f32 %0, s60, %0\n\t"
+            "s_and_b32 exec_lo, s8, s45\n\tv_add_f32 %0, s61, %0\n\t"
+            "s_and_b32 exec_lo, s8, s46\n\tv_add_f32 %0, s62, %0\n\t"
+            "s_and_b32 exec_lo, s8, s47\n\tv_add_f32 %0, s63, %0\n\t"
+            "s_and_b32 exec_lo, s8, s48\n\tv_add_f32 %0, s64, %0\n\t"
+            "s_and_b32 exec_lo, s8, s49\n\tv_add_f32 %0, s65, %0\n\t"
+            "s_and_b32 exec_lo, s8, s50\n\tv_add_f32 %0, s66, %0\n\t"
+            "s_and_b32 exec_lo, s8, s51\n\tv_add_f32 %0, s67, %0\n\t"
+            "s_sub_u32 s9, s9, 1\n\ts_cmp_eq_u32 s9, 0\n\ts_cbranch_scc1 2f\n\t"
+            "s_add_u32 s12, s12, 0x80\n\ts_addc_u32 s13, s13, 0\n\ts_add_u32 s14, s14, 0x80\n\ts_addc_u32 s15, s15, 0\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\ts_load_dwordx16 s[52:67], s[14:15], 0x0\n\t"
+            "s_and_b32 exec_lo, s8, s68\n\tv_add_f32 %0, s84, %0\n\t"
+            "s_and_b32 exec_lo, s8, s69\n\tv_add_f32 %0, s85, %0\n\t"
+            "s_and_b32 exec_lo, s8, s70\n\tv_add_f32 %0, s86, %0\n\t"
+            "s_and_b32 exec_lo, s8, s71\n\tv_add_f32 %0, s87, %0\n\t"
+            "s_and_b32 exec_lo, s8, s72\n\tv_add_f32 %0, s88, %0\n\t"
+            "s_and_b32 exec_lo, s8, s73\n\tv_add_f32 %0, s89, %0\n\t"
+            "s_and_b32 exec_lo, s8, s74\n\tv_add_f32 %0, s90, %0\n\t"
+            "s_and_b32 exec_lo, s8, s75\n\tv_add_f32 %0, s91, %0\n\t"
+            "s_and_b32 exec_lo, s8, s76\n\tv_add_f32 %0, s92, %0\n\t"
+            "s_and_b32 exec_lo, s8, s77\n\tv_add_f32 %0, s93, %0\n\t"
+            "s_and_b32 exec_lo, s8, s78\n\tv_add_f32 %0, s94, %0\n\t"
+            "s_and_b32 exec_lo, s8, s79\n\tv_add_f32 %0, s95, %0\n\t"
+            "s_and_b32 exec_lo, s8, s80\n\tv_add_f32 %0, s96, %0\n\t"
+            "s_and_b32 exec_lo, s8, s81\n\tv_add_f32 %0, s97, %0\n\t"
+            "s_and_b32 exec_lo, s8, s82\n\tv_add_f32 %0, s98, %0\n\t"
+            "s_and_b32 exec_lo, s8, s83\n\tv_add_f32 %0, s99, %0\n\t"
+            "s_sub_u32 s9, s9, 1\n\ts_cmp_lg_u32 s9, 0\n\ts_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, s[10:11]"
+            : "+v"(den)
+            : "s"(vj), "s"(ng), "s"(mp), "s"(wp)
+            : "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
+    }
+    const int c = chunk * 32 + lane;
+    if (lane < 32 && c < n) den_out[c] = den;
+}
+
+int sim_den_workgroups(int nchunk) { return (nchunk + DEN_WAVES - 1) / DEN_WAVES; }
+
+int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
+                   int ldw, float *den_out) {
+    // The dynamic LDS request is a placement device: with it a CU cannot hold this workgroup and a numerator
+    // workgroup (81 KB) at once -- sharing a SIMD with the chain waves of the other kernel slows both by ~1.7x.
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DEN_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    sim_den_kernel<<<sim_den_workgroups(nchunk), 64 * DEN_WAVES, DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n, wmat,
+                                                                                  ldw, den_out);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// similarity NUMERATORS only (the denominators come from sim_den_kernel): the register-resident
+// producer/consumer kernel with half the LDS traffic per pair step -- the table slices hold D alone
+// ([entry][lane] x 4 B), the ring carries x = W * D (4 B per lane and step, one float4 = 4 steps),
+// the chain is one v_add_f32 per step.  A skipped pair contributes W * 0 = +0.
+// LDS: master D [29][32] f32 | 2 slices [29][64] f32 | ring 2 x [28][64] float4 | W stage.
+// ------------------------------------------------------------------------------------------
+constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712
+constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424
+constexpr int NK_QUADS = SIM_ROUND_OCTS * 2;   // float4 (4 steps) per lane per round
+constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 57344
+constexpr int NK_SLICES_OFF = NK_MASTER_BYTES;
+constexpr int NK_RING_OFF = NK_SLICES_OFF + 2 * NK_SLICE_STRIDE;  // 18560
+constexpr int NK_WSTAGE_OFF = NK_RING_OFF + NK_RING_BYTES;        // 75904
+__host__ __device__ constexpr int nk_lds_bytes() { return NK_WSTAGE_OFF + SIM_NP * RC_WSTAGE_BYTES; }  // 81280
+
+__device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS / 4]) {
+    static_assert(NK_QUADS / 4 == 7, "operand list below");
+#define NK_Q(p) "v"(v[p].x), "v"(v[p].y), "v"(v[p].z), "v"(v[p].w)
+    asm volatile(
+        "v_add_f32 %0, %1, %0\n\tv_add_f32 %0, %2, %0\n\tv_add_f32 %0, %3, %0\n\tv_add_f32 %0, %4, %0\n\t"
+        "v_add_f32 %0, %5, %0\n\tv_add_f32 %0, %6, %0\n\tv_add_f32 %0, %7, %0\n\tv_add_f32 %0, %8, %0\n\t"
+        "v_add_f32 %0, %9, %0\n\tv_add_f32 %0, %10, %0\n\tv_add_f32 %0, %11, %0\n\tv_add_f32 %0, %12, %0\n\t"
+        "v_add_f32 %0, %13, %0\n\tv_add_f32 %0, %14, %0\n\tv_add_f32 %0, %15, %0\n\tv_add_f32 %0, %16, %0\n\t"
+        "v_add_f32 %0, %17, %0\n\tv_add_f32 %0, %18, %0\n\tv_add_f32 %0, %19, %0\n\tv_add_f32 %0, %20, %0\n\t"
+        "v_add_f32 %0, %21, %0\n\tv_add_f32 %0, %22, %0\n\tv_add_f32 %0, %23, %0\n\tv_add_f32 %0, %24, %0\n\t"
+        "v_add_f32 %0, %25, %0\n\tv_add_f32 %0, %26, %0\n\tv_add_f32 %0, %27, %0\n\tv_add_f32 %0, %28, %0"
+        : "+v"(acc)
+        : NK_Q(0), NK_Q(1), NK_Q(2), NK_Q(3), NK_Q(4), NK_Q(5), NK_Q(6));
+#undef NK_Q
+}
+
+__device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int lane, int c, int n,
+                                            float *__restrict__ num_out) {
+    const float4 *ring = reinterpret_cast<const float4 *>(smem + NK_RING_OFF);
+    float acc = 0.0f;
+    sim_barrier();  // slice[0] staged
+    sim_barrier();  // round 0 produced
+    constexpr int QP = NK_QUADS / 4;
+    float4 s0[QP], s1[QP], s2[QP];
+#pragma unroll
+    for (int p = 0; p < QP; ++p) s0[p] = s1[p] = s2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto rd = [&](float4 (&v)[QP], const float4 *in, int quarter) {
+#pragma unroll
+        for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto add = [&](const float4 (&v)[QP]) { nk_chain(acc, v); };
+    // same rotation as sim_consumer: two quarter-rounds stay pending in registers across the barrier
+    auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
+        const float4 *in = ring + ((r - 1) & 1) * NK_QUADS * 64 + lane;
+        rd(z, in, 0);
+        add(x);
+        rd(x, in, 1);
+        add(y);
+        rd(y, in, 2);
+        add(z);
+        rd(z, in, 3);
+        add(x);
+        sim_barrier();
+    };
+    for (int r = 1; r + 2 <= rounds; r += 3) {
+        one_round(s0, s1, s2, r);
+        one_round(s1, s2, s0, r + 1);
+        one_round(s2, s0, s1, r + 2);
+    }
+    add(s0);
+    add(s1);
+    if (c < n) num_out[c] = acc;
+}
+
+__device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
+                                            int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
+                                            int c, int R, int pad) {
+    const float *master = reinterpret_cast<const float *>(smem);
+    unsigned char *slices = smem + NK_SLICES_OFF;
+    float4 *ring = reinterpret_cast<float4 *>(smem + NK_RING_OFF);
+    const uint32_t wstage_base = (uint32_t)(NK_WSTAGE_OFF + P * RC_WSTAGE_BYTES);
+    const int G8 = (m + 7) >> 3;
+    const uint4 *col = codes16 + c;
+
+    uint4 cod[RC_RMAX][SIM_OCTS];  // this producer's codes, for the whole kernel
+#pragma unroll
+    for (int q = 0; q < RC_RMAX; ++q)
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const int g = q * SIM_ROUND_OCTS + P * SIM_OCTS + t;
+            cod[q][t] = col[(size_t)(g >= G8 ? G8 : g) * ld];
+        }
+    auto load_cj = [&](int jn) -> uint32_t {
+        if (jn >= m - 1) return (uint32_t)npos << 8;
+        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
+        return cj[jn & 7];
+    };
+    auto refresh = [&](int jn, uint32_t cjcode) {
+        const uint32_t idx = cjcode >> 8;
+        float *sl = reinterpret_cast<float *>(slices + (jn & 1) * NK_SLICE_STRIDE) + lane;
+        const float *mrow = master + idx * 32;
+        for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
+    };
+    struct Pos {
+        int j, q;
+    };
+    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / SIM_ROUND_OCTS : R - 1; };
+    auto next = [&](Pos p) {
+        if (p.q + 1 < R) return Pos{p.j, p.q + 1};
+        return Pos{p.j + 1, q0_of(p.j + 1)};
+    };
+    const uint32_t lane15x4 = (uint32_t)(lane & 15) * 4u;
+    auto wdma = [&](Pos p, int buf) {
+        const int g0 = p.q * SIM_ROUND_OCTS + P * SIM_OCTS;
+        const int gw = g0 >= G8 ? G8 - 1 : g0;
+        const int jr = p.j < m - 1 ? p.j : m - 1;
+        const float *src = wmat + ((size_t)jr * (size_t)ldw + (size_t)(8 * gw));
+        const uint32_t dst = wstage_base + (uint32_t)buf * 256u;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(lane15x4), "s"(src) : "m0", "memory");
+    };
+    Pos pos2 = {0, 0};
+    wdma(pos2, 0);
+    pos2 = next(pos2);
+    wdma(pos2, 1);
+    pos2 = next(pos2);
+    int buf = 0, r = 0;
+    refresh(0, load_cj(0));
+    uint32_t cj_next = load_cj(1);
+    sim_barrier();  // slice[0] complete
+
+    float tv[SIM_OCTS][8];
+    f32x4 wq[2 * SIM_OCTS];
+    auto body = [&](auto qc, int j) __attribute__((always_inline)) {
+        constexpr int Q = decltype(qc)::value;
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // this round's W has landed (see rc_producer)
+        const int bfar = buf == 0 ? 2 : buf - 1;
+        wdma(pos2, bfar);
+        pos2 = next(pos2);
+        const uint32_t vbase = (uint32_t)(NK_SLICES_OFF + (j & 1) * NK_SLICE_STRIDE);
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t) {
+            const uint32_t cw[4] = {cod[Q][t].x, cod[Q][t].y, cod[Q][t].z, cod[Q][t].w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                uint32_t a0, a1;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                    : "=v"(a0) : "v"(vbase), "v"(cw[s4]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                    : "=v"(a1) : "v"(vbase), "v"(cw[s4]));
+                asm volatile("ds_read_b32 %0, %1" : "=v"(tv[t][2 * s4]) : "v"(a0));
+                asm volatile("ds_read_b32 %0, %1" : "=v"(tv[t][2 * s4 + 1]) : "v"(a1));
+            }
+        }
+        const uint32_t waddr = wstage_base + (uint32_t)buf * 256u;
+#pragma unroll
+        for (int i = 0; i < 2 * SIM_OCTS; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[i]) : "v"(waddr), "i"(16 * i));
+        float4 *out = ring + ((r & 1) * NK_QUADS + P * SIM_OCTS * 2) * 64 + lane;
+        static_assert(SIM_OCTS == 2, "operand list below");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(tv[0][0]), "+v"(tv[0][1]),
+                       "+v"(tv[0][2]), "+v"(tv[0][3]), "+v"(tv[0][4]), "+v"(tv[0][5]), "+v"(tv[0][6]),
+                       "+v"(tv[0][7]), "+v"(tv[1][0]), "+v"(tv[1][1]), "+v"(tv[1][2]), "+v"(tv[1][3]),
+                       "+v"(tv[1][4]), "+v"(tv[1][5]), "+v"(tv[1][6]), "+v"(tv[1][7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int t = 0; t < SIM_OCTS; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // 4 steps: two packed multiplies (separate rounding), one 16-B ring store
+                const f32x4 w = wq[2 * t + h];
+                const f32x2 xa = f32x2{tv[t][4 * h], tv[t][4 * h + 1]} * f32x2{w.x, w.y};
+                const f32x2 xb = f32x2{tv[t][4 * h + 2], tv[t][4 * h + 3]} * f32x2{w.z, w.w};
+                out[(t * 2 + h) * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
+            }
+        if (Q == R - 1) {  // last round of row j: stage the table slice of row j+1
+            refresh(j + 1, cj_next);
+            cj_next = load_cj(j + 2);
+        }
+        sim_barrier();
+        buf = buf == 2 ? 0 : buf + 1;
+        ++r;
+    };
+    const int nrows = m - 1 + pad;
+    for (int jj = 0; jj < nrows; ++jj) {
+        const int q0 = q0_of(jj);
+        rc_unroll<0>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int Q = decltype(qc)::value;
+            if (Q >= q0 && Q < R) body(qc, jj);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sim_barrier();  // the consumer's drain round
+}
+
+__global__ __launch_bounds__(512) void similarity_num_kernel(
+    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
+    const f32x2 *__restrict__ tab_g, int npos, int R, int pad, int rounds, float *__restrict__ num_out, int tcols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * tcols + lane;
+    const bool active = lane < tcols && c < ld;
+    {
+        float *master = reinterpret_cast<float *>(smem);
+        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t].x;
+    }
+    __syncthreads();
+    if (wave != 0) {
+        if (active) nk_producer(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
+    } else if (active) {
+        __builtin_amdgcn_s_setprio(3);
+        nk_consumer(smem, rounds, lane, c, n, num_out);
+    }
+}
+
+// MDK from the two sums (Similarity::calculateVectors tail): 0 for >= 80 % gaps or an empty denominator
+__global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict__ num, const float *__restrict__ den,
+                                                         const int32_t *__restrict__ gaps_w, int m, int n,
+                                                         float *__restrict__ q_out, float *__restrict__ mdk_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+    float q = 0.0f, v = 0.0f;
+    const float d = den[c];
+    if (!skip && d != 0.0f) {
+        q = num[c] / d;
+        v = (float)exp(-(double)q);
+        v = v > 1.0f ? 1.0f : v;
+    }
+    if (q_out) q_out[c] = q;
+    mdk_out[c] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -966,10 +1605,11 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
 }
 
 void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                         const int32_t *gaps_w, void *codes16, unsigned long long *err_key) {
+                         const int32_t *gaps_w, void *codes16, unsigned long long *err_key, int tcols, bool num_only) {
     dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
+    // table slice entry stride / lane stride: 512 / 8 B for {D, valid} pairs, 256 / 4 B for the D-only slices
     sim_encode16_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes16),
-                                             err_key);
+                                             err_key, tcols, num_only ? 8 : 9, num_only ? 2 : 3);
 }
 
 // Columns per similarity workgroup.  The kernel's time is (pair steps) x (cycles per step) whatever the
@@ -1273,6 +1913,55 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
                                                    reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds, mode,
                                                    q_out, mdk_out, tcols);
     return 0;
+}
+
+// register-resident variant: usable when every producer's codes fit its registers
+bool similarity_rc_fits(int m) { return (m + 7) / 8 <= RC_RMAX * SIM_ROUND_OCTS; }
+
+int launch_similarity_rc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
+                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols) {
+    const int G8 = (m + 7) / 8;
+    const int R = (G8 + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
+    long long rounds = 0;
+    for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / SIM_ROUND_OCTS;
+    const int pad = (int)((3 - rounds % 3) % 3);  // the consumer's register sets rotate with period 3
+    rounds += pad;
+    const int lds = rc_lds_bytes();
+    auto kern = (sim_debug_mode() & 64) ? similarity_rc_kernel<true> : similarity_rc_kernel<false>;
+    if (sim_debug_mode() & 64) {
+        const char *d = getenv("MSA_SIM_DIAG");
+        const int dv = d ? atoi(d) : 0;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sim_diag), &dv, sizeof(int), 0, hipMemcpyHostToDevice, s);
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
+        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, gaps_w,
+        R, pad, (int)rounds, q_out, mdk_out, tcols);
+    return 0;
+}
+
+int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
+                          const void *tab, int npos, float *num_out, int tcols) {
+    const int G8 = (m + 7) / 8;
+    const int R = (G8 + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
+    long long rounds = 0;
+    for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / SIM_ROUND_OCTS;
+    const int pad = (int)((3 - rounds % 3) % 3);
+    rounds += pad;
+    const int lds = nk_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_num_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    similarity_num_kernel<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
+        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, R, pad,
+        (int)rounds, num_out, tcols);
+    return 0;
+}
+
+void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,
+                       float *q_out, float *mdk_out) {
+    sim_finish_kernel<<<(n + 255) / 256, 256, 0, s>>>(num, den, gaps_w, m, n, q_out, mdk_out);
 }
 
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,

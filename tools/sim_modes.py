@@ -14,7 +14,8 @@ if len(sys.argv) > 1:
     ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(3): ctx.similarity(mx._vhash, mx._dist)
     ms, k = ctx.prof_get("sim")
-    print("mode", os.environ.get("MSA_SIM_MODE", "0"), "sim ms", round(ms / k, 3))
+    print("mode", os.environ.get("MSA_SIM_MODE", "0"), "kernel", os.environ.get("MSA_SIM_KERNEL", "default"), "sim ms", round(ms / k, 3),
+          " ".join("%s %.3f" % (nm, ctx.prof_get(nm)[0] / max(1, ctx.prof_get(nm)[1])) for nm in ("simnum", "simden", "encode")))
     if int(os.environ.get("MSA_SIM_MODE", "0")) & 64:
         import ctypes
         buf = (ctypes.c_uint64 * 64)()
@@ -23,7 +24,10 @@ if len(sys.argv) > 1:
         print(" consumer: work %.0f  barrier %.0f cycles/round (rounds %d)" % (buf[0] / r, buf[1] / r, r))
         for p in range(1, 8):
             v = [buf[p * 8 + k] / r for k in range(5)]
-            print(" producer %d: settle %.0f fetch %.0f produce %.0f refresh %.0f barrier %.0f" % (p - 1, *v))
+            if os.environ.get("MSA_SIM_KERNEL", "") == "pc":
+                print(" producer %d: settle %.0f fetch %.0f produce %.0f refresh %.0f barrier %.0f" % (p - 1, *v))
+            else:
+                print(" producer %d: gather %.0f emit+refresh %.0f barrier %.0f" % (p - 1, *v[:3]))
 else:
     for mode in (0, 64):
         env = dict(os.environ, MSA_SIM_MODE=str(mode))
