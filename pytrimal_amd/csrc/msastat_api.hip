@@ -244,7 +244,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
     if (rc) return rc;
     const bool need_ident = want_ident && !c->have_ident, need_w = want_w && !c->have_w;
     if (!need_ident && !need_w && !want_counts) return MSA_OK;
-    const size_t fsz = (size_t)c->m * c->ldw + 64;
+    const size_t fsz = (size_t)c->m * c->ldw + 512;  // slack: the similarity kernels read W a round past a row end
     if (need_ident) {
         HIPCHK(c, c->ident.reserve(fsz));
         HIPCHK(c, hipMemsetAsync(c->ident.p, 0, fsz * sizeof(float), c->stream));
@@ -351,7 +351,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     const bool split = !ring_kernel && !rc_kernel && !(which && which[0] == 'p') && fits;
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32), c->cus / 2) : c->cus;
-    const int tcols = ring_kernel ? 64 : msak::sim_tile_cols(n, cus_num);
+    const int tcols = ring_kernel ? 64 : msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));

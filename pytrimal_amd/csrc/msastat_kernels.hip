@@ -319,6 +319,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // is padded with null octs that read the all-skipped codes row -- so every producer is always on
 // the same row, positions are a function of the round alone, and ONE double-buffered table slice
 // (row parity) serves the whole workgroup.  The padding costs ~ROUND_OCTS/2 octs per row.
+#ifndef NK_OCTS
+#define NK_OCTS 2  // numerator kernel: octs per producer per round
+#endif
 constexpr int SIM_NP = 7;    // producer waves (+1 consumer = 8 waves = 2 per SIMD)
 constexpr int SIM_OCTS = 2;  // octs per producer per round
 constexpr int SIM_ROUND_OCTS = SIM_NP * SIM_OCTS;       // 14 octs = 112 steps per round
@@ -439,6 +442,7 @@ __device__ __forceinline__ void sim_chain(f32x2 &acc, const float4 (&v)[SIM_PAIR
 
 // Diagnostics (MSA_SIM_MODE bit 6): per-phase cycle sums of workgroup 0, [wave][phase].
 __device__ unsigned long long g_sim_stamps[8 * 8];
+__device__ unsigned long long g_den_ticks[1024];  // diagnostics: cycles of every denominator wave (first 1024 chunks)
 __device__ int g_sim_diag;  // diagnostics switches of the DIAG instantiations (MSA_SIM_DIAG)
 __device__ __forceinline__ unsigned long long sim_now() {
     unsigned long long t;
@@ -1027,9 +1031,10 @@ __global__ __launch_bounds__(512) void similarity_rc_kernel(
 // keep their sum, which is what adding +0 would do.  Two instructions per pair step for a lone wave
 // (10.8 cycles measured, profiles/r01_ubench_den_wave.txt); it runs beside the numerator kernel on
 // CUs that one leaves idle.  Masks and W stream through the scalar cache (16 steps per buffer, two buffers,
-// lgkmcnt(0) discipline: scalar loads return out of order) and feed the adds as SGPR operands.
-// Rows start at the 16-aligned k below j+1 and end at the 16-aligned k above m: W is strictly upper
-// triangular and zero-padded, so the extra steps add +0.
+// lgkmcnt(0) discipline: scalar loads return out of order) and feed the adds as SGPR operands; 16-B
+// broadcast vector loads for W were measured slower (17.7 vs 12.9 cycles per step: each costs the wave
+// ~24 cycles of issue).  Rows start at the 16-aligned k below j+1 and end at the 16-aligned k above m:
+// W is strictly upper triangular and zero-padded, so the extra steps add +0.
 // ------------------------------------------------------------------------------------------
 constexpr int DEN_WAVES = 4;             // chunks per workgroup, one per SIMD
 constexpr int DEN_LDS_BYTES = 96 * 1024;  // never touched: keeps a numerator workgroup off this CU (see below)
@@ -1044,6 +1049,8 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
     const int lane = threadIdx.x & 63;
     const int mend = (m + 15) & ~15;
     float den = 0.0f;
+    const unsigned long long t_start = sim_now();
+    unsigned long long n_steps = 0;
     uint32_t vnext = __builtin_amdgcn_readfirstlane(masks[0]);
     for (int j = 0; j + 1 < m; ++j) {
         const uint32_t vj = vnext;
@@ -1051,6 +1058,7 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
         if (vj == 0u) continue;  // no column of this chunk has a residue in row j
         const int k0 = (j + 1) & ~15;
         const int ng = (mend - k0) >> 4;  // >= 1 groups of 16 steps
+        n_steps += (unsigned long long)ng * 16;
         const uint32_t *mp = masks + k0;
         const float *wp = wmat + ((size_t)j * (size_t)ldw + (size_t)k0);
         // buffers: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99]
@@ -1106,6 +1114,14 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             : "s"(vj), "s"(ng), "s"(mp), "s"(wp)
             : "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
     }
+    if (lane == 0) {  // diagnostics (tools/sim_modes.py)
+        const unsigned long long dt = sim_now() - t_start;
+        if (chunk < 1024) g_den_ticks[chunk] = dt;
+        if (chunk == 0) {
+            g_sim_stamps[56] = dt;
+            g_sim_stamps[57] = n_steps;
+        }
+    }
     const int c = chunk * 32 + lane;
     if (lane < 32 && c < n) den_out[c] = den;
 }
@@ -1133,16 +1149,18 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
 // ------------------------------------------------------------------------------------------
 constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712
 constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424
-constexpr int NK_QUADS = SIM_ROUND_OCTS * 2;   // float4 (4 steps) per lane per round
-constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 57344
+constexpr int NK_ROUND_OCTS = SIM_NP * NK_OCTS;  // 28 octs = 224 steps per round
+constexpr int NK_RMAX = RC_RMAX * SIM_OCTS / NK_OCTS;  // rounds per row at most (the codes fill the same registers)
+constexpr int NK_QUADS = NK_ROUND_OCTS * 2;      // float4 (4 steps) per lane per round
+constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 114688
 constexpr int NK_SLICES_OFF = NK_MASTER_BYTES;
 constexpr int NK_RING_OFF = NK_SLICES_OFF + 2 * NK_SLICE_STRIDE;  // 18560
-constexpr int NK_WSTAGE_OFF = NK_RING_OFF + NK_RING_BYTES;        // 75904
-__host__ __device__ constexpr int nk_lds_bytes() { return NK_WSTAGE_OFF + SIM_NP * RC_WSTAGE_BYTES; }  // 81280
+constexpr int NK_WSTAGE_OFF = NK_RING_OFF + NK_RING_BYTES;  // per producer 2 x 256 B: the W values of this and the next round
+__host__ __device__ constexpr int nk_lds_bytes() { return NK_WSTAGE_OFF + SIM_NP * 512; }  // 79488
 
-__device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS / 4]) {
-    static_assert(NK_QUADS / 4 == 7, "operand list below");
-#define NK_Q(p) "v"(v[p].x), "v"(v[p].y), "v"(v[p].z), "v"(v[p].w)
+template <int B>
+__device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS / 4]) {  // quads B .. B+6: 28 steps
+#define NK_Q(p) "v"(v[B + p].x), "v"(v[B + p].y), "v"(v[B + p].z), "v"(v[B + p].w)
     asm volatile(
         "v_add_f32 %0, %1, %0\n\tv_add_f32 %0, %2, %0\n\tv_add_f32 %0, %3, %0\n\tv_add_f32 %0, %4, %0\n\t"
         "v_add_f32 %0, %5, %0\n\tv_add_f32 %0, %6, %0\n\tv_add_f32 %0, %7, %0\n\tv_add_f32 %0, %8, %0\n\t"
@@ -1156,6 +1174,15 @@ __device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS 
 #undef NK_Q
 }
 
+template <int Q, class F>
+__device__ __forceinline__ void nk_unroll(F &&f) {
+    if constexpr (Q < NK_RMAX) {
+        f(std::integral_constant<int, Q>{});
+        nk_unroll<Q + 1>(f);
+    }
+}
+
+template <bool DIAG>
 __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int lane, int c, int n,
                                             float *__restrict__ num_out) {
     const float4 *ring = reinterpret_cast<const float4 *>(smem + NK_RING_OFF);
@@ -1171,9 +1198,17 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
         for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto add = [&](const float4 (&v)[QP]) { nk_chain(acc, v); };
+    static_assert(QP % 7 == 0, "the chain is issued in blocks of 7 quads");
+    auto add = [&](const float4 (&v)[QP]) {
+        nk_chain<0>(acc, v);
+        if constexpr (QP > 7) nk_chain<7>(acc, v);
+    };
     // same rotation as sim_consumer: two quarter-rounds stay pending in registers across the barrier
+    const bool stamp = DIAG && blockIdx.x == 0;
+    unsigned long long tw = 0, tb = 0;
     auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
+        unsigned long long t0 = 0, t1 = 0;
+        if (stamp) t0 = sim_now();
         const float4 *in = ring + ((r - 1) & 1) * NK_QUADS * 64 + lane;
         rd(z, in, 0);
         add(x);
@@ -1183,7 +1218,15 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
         add(z);
         rd(z, in, 3);
         add(x);
+        if (stamp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t1 = sim_now();
+        }
         sim_barrier();
+        if (stamp) {
+            tw += t1 - t0;
+            tb += sim_now() - t1;
+        }
     };
     for (int r = 1; r + 2 <= rounds; r += 3) {
         one_round(s0, s1, s2, r);
@@ -1192,25 +1235,30 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
     }
     add(s0);
     add(s1);
+    if (stamp && lane == 0) {
+        g_sim_stamps[0] = tw;
+        g_sim_stamps[1] = tb;
+        g_sim_stamps[2] = (unsigned long long)rounds;
+    }
     if (c < n) num_out[c] = acc;
 }
 
+template <bool DIAG>
 __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
                                             int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
                                             int c, int R, int pad) {
     const float *master = reinterpret_cast<const float *>(smem);
     unsigned char *slices = smem + NK_SLICES_OFF;
     float4 *ring = reinterpret_cast<float4 *>(smem + NK_RING_OFF);
-    const uint32_t wstage_base = (uint32_t)(NK_WSTAGE_OFF + P * RC_WSTAGE_BYTES);
     const int G8 = (m + 7) >> 3;
     const uint4 *col = codes16 + c;
 
-    uint4 cod[RC_RMAX][SIM_OCTS];  // this producer's codes, for the whole kernel
+    uint4 cod[NK_RMAX][NK_OCTS];  // this producer's codes, for the whole kernel
 #pragma unroll
-    for (int q = 0; q < RC_RMAX; ++q)
+    for (int q = 0; q < NK_RMAX; ++q)
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) {
-            const int g = q * SIM_ROUND_OCTS + P * SIM_OCTS + t;
+        for (int t = 0; t < NK_OCTS; ++t) {
+            const int g = q * NK_ROUND_OCTS + P * NK_OCTS + t;
             cod[q][t] = col[(size_t)(g >= G8 ? G8 : g) * ld];
         }
     auto load_cj = [&](int jn) -> uint32_t {
@@ -1224,44 +1272,48 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         const float *mrow = master + idx * 32;
         for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
     };
-    struct Pos {
-        int j, q;
-    };
-    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / SIM_ROUND_OCTS : R - 1; };
-    auto next = [&](Pos p) {
-        if (p.q + 1 < R) return Pos{p.j, p.q + 1};
-        return Pos{p.j + 1, q0_of(p.j + 1)};
-    };
-    const uint32_t lane15x4 = (uint32_t)(lane & 15) * 4u;
-    auto wdma = [&](Pos p, int buf) {
-        const int g0 = p.q * SIM_ROUND_OCTS + P * SIM_OCTS;
-        const int gw = g0 >= G8 ? G8 - 1 : g0;
-        const int jr = p.j < m - 1 ? p.j : m - 1;
-        const float *src = wmat + ((size_t)jr * (size_t)ldw + (size_t)(8 * gw));
-        const uint32_t dst = wstage_base + (uint32_t)buf * 256u;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(lane15x4), "s"(src) : "m0", "memory");
-    };
-    Pos pos2 = {0, 0};
-    wdma(pos2, 0);
-    pos2 = next(pos2);
-    wdma(pos2, 1);
-    pos2 = next(pos2);
-    int buf = 0, r = 0;
+    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / NK_ROUND_OCTS : R - 1; };
+    int r = 0;
     refresh(0, load_cj(0));
     uint32_t cj_next = load_cj(1);
     sim_barrier();  // slice[0] complete
 
-    float tv[SIM_OCTS][8];
-    f32x4 wq[2 * SIM_OCTS];
-    auto body = [&](auto qc, int j) __attribute__((always_inline)) {
+    float tv[NK_OCTS][8];
+    static_assert(NK_OCTS == 2, "16 W values per producer and round");
+    f32x4 wq[4];
+    const bool stamp = DIAG && blockIdx.x == 0;
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tg = 0;
+    if (stamp) tg = sim_now();
+    // W[j][8 g .. 8 g + 15] of this producer's round is wave-uniform.  It is DMA'd into a private LDS line
+    // (global_load_lds_dword: lane i carries element i & 15, no VGPR in flight) ONE round ahead -- within a
+    // row the source is the row base plus a compile-time offset -- and read back as four broadcast
+    // ds_read_b128 behind the gathers.  (Scalar loads would be cheaper here, but they thrash the scalar
+    // cache that the denominator kernel on the neighbouring CUs lives on: measured 10.5 -> 15 ms there.)
+    // Reads past the row end (null octs) land in the zero padding or the next row: finite, and multiplied
+    // by zero table entries.
+    const uint32_t wstage_base = (uint32_t)(NK_WSTAGE_OFF + P * 512);
+    const uint32_t lane15x4 = (uint32_t)(lane & 15) * 4u;
+    auto wrow_of = [&](int jj) {
+        const int jr = jj < m - 1 ? jj : m - 1;  // the pseudo-rows use the all-zero W row m-1
+        return wmat + ((size_t)jr * (size_t)ldw + (size_t)(P * NK_OCTS * 8));
+    };
+    {
+        const float *src = wrow_of(0) + q0_of(0) * (NK_ROUND_OCTS * 8);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(lane15x4), "s"(src) : "m0", "memory");
+    }
+    auto body = [&](auto qc, int j, const float *wrow) __attribute__((always_inline)) {
         constexpr int Q = decltype(qc)::value;
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // this round's W has landed (see rc_producer)
-        const int bfar = buf == 0 ? 2 : buf - 1;
-        wdma(pos2, bfar);
-        pos2 = next(pos2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this round's W has landed (issued a round ago)
+        const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
+        {
+            // (the instruction's immediate offset would also move the LDS address: scalar adds instead)
+            const float *src = Q == R - 1 ? wrow_of(j + 1) + q0_of(j + 1) * (NK_ROUND_OCTS * 8)  // opens row j+1
+                                          : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(src) : "m0", "memory");
+        }
         const uint32_t vbase = (uint32_t)(NK_SLICES_OFF + (j & 1) * NK_SLICE_STRIDE);
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) {
+        for (int t = 0; t < NK_OCTS; ++t) {
             const uint32_t cw[4] = {cod[Q][t].x, cod[Q][t].y, cod[Q][t].z, cod[Q][t].w};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -1274,12 +1326,12 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
                 asm volatile("ds_read_b32 %0, %1" : "=v"(tv[t][2 * s4 + 1]) : "v"(a1));
             }
         }
-        const uint32_t waddr = wstage_base + (uint32_t)buf * 256u;
+        const uint32_t waddr = wstage_base + (uint32_t)(r & 1) * 256u;
 #pragma unroll
-        for (int i = 0; i < 2 * SIM_OCTS; ++i)
+        for (int i = 0; i < 4; ++i)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[i]) : "v"(waddr), "i"(16 * i));
-        float4 *out = ring + ((r & 1) * NK_QUADS + P * SIM_OCTS * 2) * 64 + lane;
-        static_assert(SIM_OCTS == 2, "operand list below");
+        float4 *out = ring + ((r & 1) * NK_QUADS + P * NK_OCTS * 2) * 64 + lane;
+        // the asm reads above are tied to the wait so that no use (not even a copy) is scheduled ahead of it
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(tv[0][0]), "+v"(tv[0][1]),
                        "+v"(tv[0][2]), "+v"(tv[0][3]), "+v"(tv[0][4]), "+v"(tv[0][5]), "+v"(tv[0][6]),
@@ -1287,8 +1339,10 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
                        "+v"(tv[1][4]), "+v"(tv[1][5]), "+v"(tv[1][6]), "+v"(tv[1][7])
                      :
                      : "memory");
+        unsigned long long td = 0;
+        if (stamp) td = sim_now();
 #pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t)
+        for (int t = 0; t < NK_OCTS; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {  // 4 steps: two packed multiplies (separate rounding), one 16-B ring store
                 const f32x4 w = wq[2 * t + h];
@@ -1300,22 +1354,36 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
             refresh(j + 1, cj_next);
             cj_next = load_cj(j + 2);
         }
-        sim_barrier();
-        buf = buf == 2 ? 0 : buf + 1;
+        if (stamp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tf = sim_now();
+            sim_barrier();
+            const unsigned long long tn = sim_now();
+            acc_t[0] += td - tg;  // barrier exit -> gathers and W landed
+            acc_t[1] += tf - td;  // multiplies, ring stores (drained), slice refresh
+            acc_t[2] += tn - tf;  // barrier wait
+            tg = tn;
+        } else {
+            sim_barrier();
+        }
         ++r;
     };
     const int nrows = m - 1 + pad;
     for (int jj = 0; jj < nrows; ++jj) {
         const int q0 = q0_of(jj);
-        rc_unroll<0>([&](auto qc) __attribute__((always_inline)) {
+        const float *wrow = wrow_of(jj);
+        nk_unroll<0>([&](auto qc) __attribute__((always_inline)) {
             constexpr int Q = decltype(qc)::value;
-            if (Q >= q0 && Q < R) body(qc, jj);
+            if (Q >= q0 && Q < R) body(qc, jj, wrow);
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the W prefetch past the end
+    if (stamp && lane == 0)
+        for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
     sim_barrier();  // the consumer's drain round
 }
 
+template <bool DIAG>
 __global__ __launch_bounds__(512) void similarity_num_kernel(
     const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, int R, int pad, int rounds, float *__restrict__ num_out, int tcols) {
@@ -1331,10 +1399,11 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
     }
     __syncthreads();
     if (wave != 0) {
-        if (active) nk_producer(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
+        // the chain wave has slack every round; the producer that shares its SIMD does not
+        __builtin_amdgcn_s_setprio(2);
+        if (active) nk_producer<DIAG>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
     } else if (active) {
-        __builtin_amdgcn_s_setprio(3);
-        nk_consumer(smem, rounds, lane, c, n, num_out);
+        nk_consumer<DIAG>(smem, rounds, lane, c, n, num_out);
     }
 }
 
@@ -1615,16 +1684,17 @@ void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_
 // Columns per similarity workgroup.  The kernel's time is (pair steps) x (cycles per step) whatever the
 // column count, and the cycles per step are mostly LDS time, which scales with the active lanes: so the
 // columns are spread over as many CUs as there are (one workgroup per CU), down to 16 lanes per wave.
-int sim_tile_cols(int n, int cus) {
+int sim_tile_cols(int n, int cus, int min_cols) {
     if (const char *e = getenv("MSA_SIM_TCOLS")) {
         const int t = atoi(e);
-        if (t >= 16 && t <= 64) return t;
+        if (t >= min_cols && t <= 64) return t;
     }
     if (cus < 1) cus = 256;
     int t = (n + cus - 1) / cus;
     t = (t + 7) / 8 * 8;
-    return t < 16 ? 16 : (t > 64 ? 64 : t);  // >= 16: the lanes of a producer fetch its 16 W values
+    return t < min_cols ? min_cols : (t > 64 ? 64 : t);  // the lanes of a producer fetch the W values of its round
 }
+int sim_num_min_cols() { return 16; }
 
 void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                          const int32_t *gaps_w, void *codes32, unsigned long long *err_key, int tcols) {
@@ -1894,6 +1964,10 @@ int launch_similarity_ring(hipStream_t s, const void *codes16, int m, int n, int
     return 0;
 }
 
+extern "C" int msa_debug_den_ticks(unsigned long long *out1024) {
+    return (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_den_ticks), sizeof(unsigned long long) * 1024);
+}
+
 extern "C" int msa_debug_sim_stamps(unsigned long long *out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sim_stamps), sizeof(unsigned long long) * 64);
 }
@@ -1944,16 +2018,16 @@ int launch_similarity_rc(hipStream_t s, const void *codes16, int m, int n, int64
 int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
                           const void *tab, int npos, float *num_out, int tcols) {
     const int G8 = (m + 7) / 8;
-    const int R = (G8 + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
+    const int R = (G8 + NK_ROUND_OCTS - 1) / NK_ROUND_OCTS;
     long long rounds = 0;
-    for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / SIM_ROUND_OCTS;
+    for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / NK_ROUND_OCTS;
     const int pad = (int)((3 - rounds % 3) % 3);
     rounds += pad;
     const int lds = nk_lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_num_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    auto kern = (sim_debug_mode() & 64) ? similarity_num_kernel<true> : similarity_num_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    similarity_num_kernel<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
+    kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
         reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, R, pad,
         (int)rounds, num_out, tcols);
     return 0;

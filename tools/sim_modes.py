@@ -16,6 +16,16 @@ if len(sys.argv) > 1:
     ms, k = ctx.prof_get("sim")
     print("mode", os.environ.get("MSA_SIM_MODE", "0"), "kernel", os.environ.get("MSA_SIM_KERNEL", "default"), "sim ms", round(ms / k, 3),
           " ".join("%s %.3f" % (nm, ctx.prof_get(nm)[0] / max(1, ctx.prof_get(nm)[1])) for nm in ("simnum", "simden", "encode")))
+    import ctypes
+    buf = (ctypes.c_uint64 * 64)()
+    ctx.lib.msa_debug_sim_stamps(buf)
+    if buf[57]:
+        print(" den wave 0: %.2f ticks/step over %d steps, %.0f ticks total" % (buf[56] / buf[57], buf[57], buf[56]))
+        dt = (ctypes.c_uint64 * 1024)()
+        ctx.lib.msa_debug_den_ticks(dt)
+        v = np.array(dt[: (n + 31) // 32], dtype=np.float64) / 1e6
+        print(" den waves Mticks: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % (v.min(), np.percentile(v, 10), np.median(v), np.percentile(v, 90), v.max()))
+        print(" per WG (4 waves) max:", " ".join("%.0f" % x for x in v[: len(v) // 4 * 4].reshape(-1, 4).max(axis=1)[:80]))
     if int(os.environ.get("MSA_SIM_MODE", "0")) & 64:
         import ctypes
         buf = (ctypes.c_uint64 * 64)()
