@@ -341,17 +341,16 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         gw_dev = c->gaps_w.p;
     }
     const int G8 = (m + 7) / 8;
-    // kernel choice: register-resident codes when the rows fit (m <= 2016), else the streaming
-    // producer/consumer kernel; MSA_SIM_KERNEL=pc|ring force the other variants (parity-tested)
+    // kernel choice: numerator + denominator kernels with register-resident codes when the rows fit
+    // (m <= 2016), else the streaming producer/consumer kernel.  MSA_SIM_KERNEL=pc forces the latter,
+    // MSA_SIM_KERNEL=codes the single-kernel register-resident variant (all parity-tested).
     const char *which = getenv("MSA_SIM_KERNEL");
-    const bool ring_kernel = which && which[0] == 'r';
     const bool fits = msak::similarity_rc_fits(m);
-    const bool forced_rc = which && which[0] == 'c';  // "codes resident", one kernel for both sums
-    const bool rc_kernel = !ring_kernel && forced_rc && fits;
-    const bool split = !ring_kernel && !rc_kernel && !(which && which[0] == 'p') && fits;
+    const bool rc_kernel = which && which[0] == 'c' && fits;
+    const bool split = !rc_kernel && !(which && which[0] == 'p') && fits;
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32), c->cus / 2) : c->cus;
-    const int tcols = ring_kernel ? 64 : msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
+    const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
@@ -396,7 +395,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     } else {
         {
             ProfScope ps(c, "encode");
-            if (ring_kernel || rc_kernel)
+            if (rc_kernel)
                 msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p,
                                           c->errkey.p, tcols, false);
             else
@@ -409,28 +408,18 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         if (rc_kernel) {
             e = msak::launch_similarity_rc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                            gw_dev, c->q.p, c->mdk.p, tcols);
-        } else if (!ring_kernel) {
+        } else {
             e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                            gw_dev, c->q.p, c->mdk.p, tcols);
-        } else {
-            HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
-            e = msak::launch_similarity_ring(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                             gw_dev, c->q.p, c->mdk.p, c->errflag.p);
         }
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_u64.reserve(1));
     HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, c->h_i32.reserve((size_t)2 * n + 4));
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->h_i32.p[0]) {  // a bounded spin of the ring kernel ran out: never trust the numbers
-        std::snprintf(c->hip_err, sizeof(c->hip_err), "similarity ring kernel timed out waiting on its LDS counters");
-        return MSA_E_HIP;
-    }
     const unsigned long long key = c->h_u64.p[0];
     if (key != ~0ull) {
         if (detail) {

@@ -34,9 +34,6 @@ void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_
                          const int32_t *gaps_w, void *codes32, unsigned long long *err_key, int tcols);
 int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64_t ld, const float *wmat, int ldw,
                          const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols);
-int launch_similarity_ring(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
-                           const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out,
-                           int *hang_flag);
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
                     const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good);
 void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,

@@ -332,7 +332,6 @@ constexpr int SIM_PAIRS = SIM_ROUND_OCTS * 4;           // float4 {x0,w0,x1,w1} 
 constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29][32] x 8 B
 constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
 constexpr int SIM_SLICE_STRIDE = 29 * 512;              // table slice [entry][lane] x 8 B, fixed size
-__host__ __device__ constexpr int sim_slice_bytes(int npos) { return (npos + 1) * 512; }  // ring kernel only
 constexpr int SIM_WSTAGE_BYTES = 256;                   // per producer: the 16 W values of its round, [lane] x 4 B
 __host__ __device__ constexpr int sim_lds_bytes(int) {
     return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + SIM_NP * SIM_WSTAGE_BYTES;  // 153600
@@ -1708,260 +1707,6 @@ void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_
 static int sim_debug_mode() {
     const char *e = getenv("MSA_SIM_MODE");
     return e ? atoi(e) : 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// similarity_mdk, free-running ring (no workgroup barrier in steady state).
-//
-// Same roles and data path as similarity_pc_kernel, but producers and consumer are decoupled by
-// counters in LDS instead of a barrier per round, so the LDS -- the shared bottleneck -- never
-// idles while a wave finishes its scalar bookkeeping:
-//   slot q (RING_OCTS octs of one row j, row-aligned like the rounds above) lives in ring
-//   buffer q % RING_SLOTS; producer p writes oct p of it once `consumed > q - RING_SLOTS`, then
-//   bumps done[q % RING_SLOTS]; the consumer reads slot q once done[..] == NP * (q / SLOTS + 1)
-//   and publishes consumed = q + 1 when its reads have landed.
-// LDS operations of one wave execute in order, so a counter update is visible only after the
-// data it covers.  Row changes: the table slice of row j+1 is staged (all producers, disjoint
-// entries) while the last slot of row j is produced; a producer enters row j+1 only after every
-// producer has signalled that slot.  Every spin is bounded: on timeout the kernel sets
-// `*hang_flag` and bails out (wrong numbers, but no hung GPU).
-// ------------------------------------------------------------------------------------------
-constexpr int RING_NP = 7;
-constexpr int RING_OCTS = RING_NP;           // one oct per producer per slot
-constexpr int RING_SLOTS = 4;
-constexpr int RING_PAIRS = RING_OCTS * 4;    // float4 per lane per slot
-constexpr int RING_SLOT_BYTES = RING_PAIRS * 64 * 16;  // 28672
-constexpr int RING_CTRL_BYTES = 64;          // done[4], consumed, pad
-constexpr unsigned RING_SPIN_LIMIT = 1u << 22;
-__host__ __device__ constexpr int ring_lds_bytes(int npos) {
-    return SIM_MASTER_BYTES + RING_CTRL_BYTES + 2 * sim_slice_bytes(npos) + RING_SLOTS * RING_SLOT_BYTES;
-}
-
-struct RingPos {
-    int j, gb;
-};
-__device__ __forceinline__ RingPos ring_next(RingPos p, int G8) {
-    p.gb += RING_OCTS;
-    if (p.gb >= G8) {
-        ++p.j;
-        p.gb = (p.j + 1) >> 3;
-    }
-    return p;
-}
-
-// wave-uniform wait until *word >= target (volatile LDS read by every lane, same address)
-__device__ __forceinline__ bool ring_wait(const volatile unsigned *word, unsigned target) {
-    for (unsigned spin = 0; spin < RING_SPIN_LIMIT; ++spin) {
-        const unsigned v = __builtin_amdgcn_readfirstlane(*word);
-        if ((int)(v - target) >= 0) {
-            asm volatile("" ::: "memory");  // acquire side: nothing below may be hoisted above the wait
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(64 * (RING_NP + 1)) void similarity_ring_kernel(
-    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
-    const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int nslots,
-    float *__restrict__ q_out, float *__restrict__ mdk_out, int *__restrict__ hang_flag) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 64 + lane;  // < ld
-    f32x2 *master = reinterpret_cast<f32x2 *>(smem);
-    volatile unsigned *done = reinterpret_cast<volatile unsigned *>(smem + SIM_MASTER_BYTES);
-    volatile unsigned *consumed = done + 8;
-    unsigned char *slices = smem + SIM_MASTER_BYTES + RING_CTRL_BYTES;
-    const int slice_bytes = sim_slice_bytes(npos);
-    float4 *ring = reinterpret_cast<float4 *>(slices + 2 * slice_bytes);
-    const int G8 = (m + 7) >> 3;
-    for (int t = threadIdx.x; t < 29 * 32; t += 64 * (RING_NP + 1)) master[t] = tab_g[t];
-    if (threadIdx.x < 16) done[threadIdx.x] = 0;
-    __syncthreads();
-
-    if (wave != 0) {
-        // ---------------------------------------------------------------- producer P
-        const int P = wave - 1;
-        const uint4 *col = codes16 + c;
-        const unsigned char *codes_bytes = reinterpret_cast<const unsigned char *>(codes16);
-        const uint32_t ld16 = (uint32_t)ld * 16u, c16 = (uint32_t)c * 16u;
-        auto load_cj = [&](int jn) -> uint32_t {
-            if (jn >= m - 1) return (uint32_t)npos << 9;
-            const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
-            return cj[jn & 7];
-        };
-        auto refresh = [&](int jn, uint32_t cjcode) {
-            const uint32_t idx = cjcode >> 9;
-            f32x2 *sl = reinterpret_cast<f32x2 *>(slices + (jn & 1) * slice_bytes) + lane;
-            const f32x2 *mrow = master + idx * 32;
-            for (int e = P; e <= npos; e += RING_NP) sl[e * 64] = mrow[e];
-        };
-        struct Oct {
-            uint4 codes;
-            float w[8];
-        };
-        auto fetch = [&](Oct &o, RingPos p) {
-            const bool past = p.j >= m - 1;
-            const uint32_t wrow = (uint32_t)(past ? 0 : p.j) * (uint32_t)ldw;
-            const int g = p.gb + P;
-            const int gc = (past || g >= G8) ? G8 : g;
-            const int gw = g >= G8 ? G8 - 1 : g;
-            o.codes = *reinterpret_cast<const uint4 *>(codes_bytes + ((uint32_t)gc * ld16 + c16));
-            const float *wp = wmat + (wrow + 8u * (uint32_t)gw);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) o.w[s] = wp[s];
-        };
-        auto settle = [&](const Oct &o) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) asm volatile("" ::"s"(o.w[s]));
-        };
-        auto produce = [&](const Oct &o, int j, int q) {
-            const unsigned char *slice = slices + (j & 1) * slice_bytes;
-            float4 *out = ring + ((q % RING_SLOTS) * RING_PAIRS + P * 4) * 64 + lane;
-            const uint32_t cw[4] = {o.codes.x, o.codes.y, o.codes.z, o.codes.w};
-            f32x2 tv[8];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                tv[2 * pp] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] & 0xFFFFu));
-                tv[2 * pp + 1] = *reinterpret_cast<const f32x2 *>(slice + (cw[pp] >> 16));
-            }
-            const f32x2 wp[4] = {{o.w[0], o.w[1]}, {o.w[2], o.w[3]}, {o.w[4], o.w[5]}, {o.w[6], o.w[7]}};
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                f32x2 xa, xb;
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tv[2 * pp]), "s"(wp[pp]));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tv[2 * pp + 1]), "s"(wp[pp]));
-                out[pp * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
-            }
-        };
-
-        RingPos pos = {0, 0};
-        refresh(0, load_cj(0));
-        uint32_t cj_next = load_cj(1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();  // slice[0] complete (the consumer joins this one barrier)
-        Oct a, b, d;
-        RingPos pos1 = ring_next(pos, G8);
-        fetch(a, pos);
-        fetch(b, pos1);
-        bool ok = true;
-        int prev_row_last_slot = -1;  // slot that closed the previous row (entry gate of the current row)
-        unsigned seen_consumed = 0;   // last polled value; polled one step ahead so the LDS read
-                                      // latency hides under the previous slot's work
-        auto step = [&](Oct &cur, Oct &far, int q) {
-            const RingPos pos2 = ring_next(pos1, G8);
-            // room in the ring?  (slot q reuses the buffer of slot q - RING_SLOTS)
-            if (q >= RING_SLOTS && (int)(seen_consumed - (unsigned)(q - RING_SLOTS + 1)) < 0)
-                ok = ok && ring_wait(consumed, (unsigned)(q - RING_SLOTS + 1));
-            // entering a new row: every producer must have closed the previous one (slice staged)
-            if (prev_row_last_slot >= 0) {
-                ok = ok && ring_wait(&done[prev_row_last_slot % RING_SLOTS],
-                                     (unsigned)(RING_NP * (prev_row_last_slot / RING_SLOTS + 1)));
-                prev_row_last_slot = -1;
-            }
-            settle(cur);
-            fetch(far, pos2);
-            produce(cur, pos.j, q);
-            if (pos1.j != pos.j) {  // last slot of row j: stage row j+1's slice, then close the row
-                refresh(pos1.j, cj_next);
-                cj_next = load_cj(pos1.j + 1);
-                prev_row_last_slot = q;
-            }
-            asm volatile("" ::: "memory");  // release side: the ring / slice stores stay above the signal
-            if (lane == 0) atomicAdd(const_cast<unsigned *>(&done[q % RING_SLOTS]), 1u);  // LDS executes a wave's ops in order
-            seen_consumed = __builtin_amdgcn_readfirstlane(*consumed);
-            pos = pos1;
-            pos1 = pos2;
-        };
-        for (int q = 0; q < nslots && ok; q += 3) {
-            step(a, d, q);
-            if (q + 1 < nslots) step(b, a, q + 1);
-            if (q + 2 < nslots) step(d, b, q + 2);
-        }
-        if (!ok && lane == 0) atomicOr(hang_flag, 1);
-    } else {
-        // ---------------------------------------------------------------- consumer
-        __builtin_amdgcn_s_setprio(3);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
-        f32x2 acc = {0.0f, 0.0f};
-        bool ok = true;
-        // Two register sets: while the chain eats slot q, the reads of slot q+1 are already in
-        // flight (if its producers are done, which the 4-slot ring makes the common case).
-        float4 va[RING_PAIRS], vb[RING_PAIRS];
-        auto issue = [&](float4 (&v)[RING_PAIRS], int q) {
-            const float4 *in = ring + (q % RING_SLOTS) * RING_PAIRS * 64 + lane;
-#pragma unroll
-            for (int p = 0; p < RING_PAIRS; ++p) v[p] = in[p * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto chain = [&](const float4 (&v)[RING_PAIRS]) {
-#pragma unroll
-            for (int p = 0; p < RING_PAIRS; ++p) {
-                acc += f32x2{v[p].x, v[p].y};
-                acc += f32x2{v[p].z, v[p].w};
-            }
-        };
-        // `poll` = done[(q+1) % SLOTS] as read (ds_read issued) during the previous slot: by the
-        // time it is looked at, the read has long returned, so the look costs no LDS latency.
-        unsigned poll = 0;
-        auto slot = [&](float4 (&cur)[RING_PAIRS], float4 (&nxt)[RING_PAIRS], int q) {
-            const unsigned want = (unsigned)(RING_NP * ((q + 1) / RING_SLOTS + 1));
-            bool early = false;
-            if (q + 1 < nslots && (int)(__builtin_amdgcn_readfirstlane(poll) - want) >= 0) {
-                asm volatile("" ::: "memory");
-                issue(nxt, q + 1);
-                early = true;
-            }
-            if (q + 2 < nslots) poll = done[(q + 2) % RING_SLOTS];  // for the next call
-            chain(cur);
-            asm volatile("" ::: "memory");
-            if (lane == 0) *consumed = (unsigned)(q + 1);  // slot q's data is in registers
-            if (q + 1 < nslots && !early) {
-                ok = ok && ring_wait(&done[(q + 1) % RING_SLOTS], want);
-                issue(nxt, q + 1);
-            }
-        };
-        if (nslots > 0) {
-            ok = ring_wait(&done[0], (unsigned)RING_NP);
-            issue(va, 0);
-            if (nslots > 1) poll = done[1 % RING_SLOTS];
-        }
-        for (int q = 0; q < nslots && ok; q += 2) {
-            slot(va, vb, q);
-            if (q + 1 < nslots && ok) slot(vb, va, q + 1);
-        }
-        if (!ok && lane == 0) atomicOr(hang_flag, 1);
-        if (c < n) {
-            const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
-            float q = 0.0f, v = 0.0f;
-            if (!skip && acc.y != 0.0f) {
-                q = acc.x / acc.y;
-                v = (float)exp(-(double)q);
-                v = v > 1.0f ? 1.0f : v;
-            }
-            if (q_out) q_out[c] = q;
-            mdk_out[c] = v;
-        }
-    }
-}
-
-int launch_similarity_ring(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
-                           const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out,
-                           int *hang_flag) {
-    const int G8 = (m + 7) / 8;
-    long long nslots = 0;
-    for (int j = 0; j + 1 < m; ++j) nslots += (G8 - ((j + 1) >> 3) + RING_OCTS - 1) / RING_OCTS;
-    const int lds = ring_lds_bytes(npos);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(similarity_ring_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    similarity_ring_kernel<<<(n + 63) / 64, 64 * (RING_NP + 1), lds, s>>>(
-        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, gaps_w,
-        (int)nslots, q_out, mdk_out, hang_flag);
-    return 0;
 }
 
 extern "C" int msa_debug_den_ticks(unsigned long long *out1024) {

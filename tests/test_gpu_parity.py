@@ -246,3 +246,40 @@ def test_c4_full_size_pair_counts(ctx):
     hits = np.where(is_gap, ng[None, :] - 1, np.where(is_x, nx[None, :] - 1, (m - ng - nx)[None, :] - 1))
     want = (hits >= need).sum(axis=1).astype(np.float32) / np.float32(n)
     assert np.array_equal(bits(ov), bits(want))
+
+
+def _sim_parity(ctx, a, indet=ord("X")):
+    ctx.upload(a, indet)
+    og, _, _, _ = oracle.gaps(a)
+    ohit, odst = oracle.pair_counts(a, indet)
+    ow = oracle.weights(ohit, odst)
+    vhash, dist = oracle.aa_matrix()
+    omdk, oq = oracle.similarity(a, ow, og, vhash, dist, indet)
+    mdk, q = ctx.similarity(vhash, dist)
+    assert np.array_equal(bits(q), bits(oq)), "similarity quotient must be bit-exact (reference order)"
+    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
+
+
+@pytest.mark.parametrize("kernel", ["", "pc", "codes"])
+@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (113, 200), (225, 96), (337, 130), (640, 257)])
+def test_similarity_kernel_variants(ctx, monkeypatch, kernel, shape):
+    """Every similarity kernel (default numerator + denominator pair, the streaming producer/consumer kernel
+    that serves m > 2016, the single-kernel register-resident variant) against the oracle, at row counts on
+    both sides of the round boundaries (112 rows per round) and with ragged column tiles."""
+    if kernel:
+        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    m, n = shape
+    _sim_parity(ctx, synth_msa(m, n, 4242 + m))
+
+
+def test_similarity_above_resident_limit(ctx, monkeypatch):
+    """m > 2016: the codes no longer fit the producers' registers, the streaming kernel takes over."""
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(2100, 72, 77))
+
+
+def test_similarity_at_resident_limit(ctx, monkeypatch):
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(2016, 40, 78))
