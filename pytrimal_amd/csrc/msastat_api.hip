@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -188,7 +190,8 @@ int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
     c->n = n;
     c->indet = indet;
     c->nchunk = (n + 31) / 32;
-    c->m_pad = round_up(std::max(m, 1), 64 * msak::PAIR_TJ);
+    // + 20: the denominator kernel reads the validity plane one 20-row group past the last row (zeros)
+    c->m_pad = round_up(std::max(m, 1) + 20, 64 * msak::PAIR_TJ);
     c->ldw = round_up(std::max(m, 1), 64);
     invalidate(c);
     return MSA_OK;
@@ -471,8 +474,17 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < m; ++i)
+    bool all_rows = true;
+    for (int i = 0; i < m; ++i) {
         if (keep_seq[i] && c->h_i32.p[i] == 0) keep_seq[i] = 0;
+        all_rows &= keep_seq[i] != 0;
+    }
+    if (all_rows && (int)c->h_gaps.size() == n) {
+        // every sequence stays: a column is all-gap exactly when its gap count is m (already on the host)
+        for (int j = 0; j < n; ++j)
+            if (keep_res[j] && c->h_gaps[j] == m) keep_res[j] = 0;
+        return MSA_OK;
+    }
     std::memcpy(c->h_u8.p, keep_seq, m);
     HIPCHK(c, hipMemcpyAsync(c->keep_seq_d.p, c->h_u8.p, m, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
@@ -772,9 +784,26 @@ int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
     return overlap(c, residue_overlap, spurious_out);
 }
 
+namespace {
+// MSA_TRACE=1: host-side wall-clock marks of msa_trim on stderr (diagnostics)
+struct TrimTrace {
+    bool on = getenv("MSA_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[msa_trim] %-22s +%8.1f us  (at %8.1f us)\n", what,
+                     std::chrono::duration<double, std::micro>(now - last).count(),
+                     std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
+}  // namespace
+
 int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    TrimTrace trace;
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
@@ -850,8 +879,10 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             // one pair pass produces both float matrices when strict is likely to follow
             rc = run_pairs(c, true, true, false);
             if (rc) return rc;
+            trace.mark("pairs enqueued");
             rc = identity_stats(c, &info->avg_seq, &info->max_seq);
             if (rc) return rc;
+            trace.mark("identity stats");
             info->selected_method = msah::select_method(info->avg_seq, info->max_seq, m);
             method = info->selected_method == 1 ? MSA_METHOD_GAPPYOUT : MSA_METHOD_STRICT;
         }
@@ -862,11 +893,15 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             msah::clean_gaps(gaps_w.data(), n, info->gap_cut, 0, keep_res);
         } else if (method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS) {
             if ((rc = need_gaps())) return rc;
+            trace.mark("gaps");
             info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            trace.mark("gap cut");
             if ((rc = need_sim())) return rc;
+            trace.mark("similarity");
             info->sim_cut = msah::comb_similarity_cut(gaps_w.data(), mdk_w.data(), n, info->gap_cut);
             msah::clean_strict(gaps_w.data(), mdk_w.data(), n, info->gap_cut, info->sim_cut,
                                method == MSA_METHOD_STRICTPLUS, keep_res);
+            trace.mark("strict selection");
         } else if (method == MSA_METHOD_NOGAPS) {
             if ((rc = need_gaps())) return rc;
             msah::clean_gaps(gaps_w.data(), n, msah::GapHistogram(c->h_gaps.data(), m, n).cut_point(0, 0), 0, keep_res);
@@ -898,6 +933,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     }
     rc = remove_all_gaps(c, keep_res, keep_seq);
     if (rc) return rc;
+    trace.mark("remove all-gap");
     info->kept_residues = static_cast<int32_t>(std::count(keep_res, keep_res + n, 1));
     info->kept_sequences = static_cast<int32_t>(std::count(keep_seq, keep_seq + m, 1));
     return MSA_OK;

@@ -236,15 +236,23 @@ float comb_similarity_cut(const int32_t *gw, const float *mdkw, int n, int gap_c
     pool.reserve(n);
     for (int c = 0; c < n; ++c)
         if (gw[c] <= gap_cut) pool.push_back(mdkw[c]);
-    std::sort(pool.begin(), pool.end());
     const int size = static_cast<int>(pool.size());
-    float p20 = 0.0f, p80 = 0.0f;
-    for (int rank = 1; rank <= size; ++rank) {  // rank 1 = largest value
-        const float v = pool[size - rank];
+    // p20 / p80: the value of the LAST descending rank whose percentage (float division, as upstream) is
+    // <= 20 / <= 80; 0 when no rank qualifies.  The percentage grows with the rank, so the two ranks
+    // come from a scan over ranks alone and the values from two selections instead of a full sort.
+    int r20 = 0, r80 = 0;
+    for (int rank = 1; rank <= size; ++rank) {
         const double pct = (static_cast<float>(rank) / size) * 100.0;
-        if (pct <= 20.0) p20 = v;
-        if (pct <= 80.0) p80 = v;
+        if (pct <= 20.0) r20 = rank;
+        if (pct <= 80.0) r80 = rank;
     }
+    auto by_rank = [&](int rank) -> float {  // rank 1 = largest value
+        if (rank == 0) return 0.0f;
+        auto nth = pool.begin() + (size - rank);
+        std::nth_element(pool.begin(), nth, pool.end());
+        return *nth;
+    };
+    const float p20 = by_rank(r20), p80 = by_rank(r80);
     const double hi = std::log10(static_cast<double>(p20)), lo = std::log10(static_cast<double>(p80));
     return static_cast<float>(std::pow(10, ((hi - lo) / 10) + lo));
 }

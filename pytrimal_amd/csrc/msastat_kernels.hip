@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(512) void similarity_rc_kernel(
 // W is strictly upper triangular and zero-padded, so the extra steps add +0.
 // ------------------------------------------------------------------------------------------
 constexpr int DEN_WAVES = 4;             // chunks per workgroup, one per SIMD
+constexpr int DEN_GROUP = 16;            // pair steps per SGPR buffer of the denominator loop
 constexpr int DEN_LDS_BYTES = 96 * 1024;  // never touched: keeps a numerator workgroup off this CU (see below)
 __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t *__restrict__ planes, int nchunk,
                                                                  int m_pad, int m, int n,
@@ -1046,7 +1047,8 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
     if (chunk >= nchunk) return;
     const uint32_t *masks = planes + ((size_t)7 * nchunk + chunk) * (size_t)m_pad;
     const int lane = threadIdx.x & 63;
-    const int mend = (m + 15) & ~15;
+    constexpr int G = DEN_GROUP;  // pair steps per buffer
+    const int mend = (m + G - 1) / G * G;
     float den = 0.0f;
     const unsigned long long t_start = sim_now();
     unsigned long long n_steps = 0;
@@ -1055,20 +1057,23 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
         const uint32_t vj = vnext;
         vnext = __builtin_amdgcn_readfirstlane(masks[j + 1]);
         if (vj == 0u) continue;  // no column of this chunk has a residue in row j
-        const int k0 = (j + 1) & ~15;
-        const int ng = (mend - k0) >> 4;  // >= 1 groups of 16 steps
-        n_steps += (unsigned long long)ng * 16;
+        const int k0 = (j + 1) / G * G;
+        const int ng = (mend - k0) / G;  // >= 1 groups
+        n_steps += (unsigned long long)ng * G;
         const uint32_t *mp = masks + k0;
         const float *wp = wmat + ((size_t)j * (size_t)ldw + (size_t)k0);
-        // buffers: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99]
+        // Two SGPR buffers of 16 steps: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99].
+        // The loop is ISSUE-bound (a lone wave issues one instruction per ~4.3 cycles whatever its type: 2
+        // instructions per step + the loop's own), so the bookkeeping is pared down: one byte offset (s30)
+        // serves both streams, the group counter exits on the borrow of its decrement.
         asm volatile(
             "s_mov_b64 s[10:11], exec\n\t"
             "s_mov_b32 exec_hi, 0\n\t"
-            "s_mov_b32 s8, %1\n\ts_mov_b32 s9, %2\n\ts_mov_b64 s[12:13], %3\n\ts_mov_b64 s[14:15], %4\n\t"
-            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\ts_load_dwordx16 s[52:67], s[14:15], 0x0\n\t"
+            "s_mov_b32 s8, %1\n\ts_sub_u32 s9, %2, 1\n\ts_mov_b64 s[12:13], %3\n\ts_mov_b64 s[14:15], %4\n\ts_mov_b32 s30, 0\n\t"
+            "s_load_dwordx16 s[36:51], s[12:13], s30\n\ts_load_dwordx16 s[52:67], s[14:15], s30\n\t"
             "1:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "s_load_dwordx16 s[68:83], s[12:13], 0x40\n\ts_load_dwordx16 s[84:99], s[14:15], 0x40\n\t"
+            "s_load_dwordx16 s[68:83], s[12:13], s30 offset:0x40\n\ts_load_dwordx16 s[84:99], s[14:15], s30 offset:0x40\n\t"
             "s_and_b32 exec_lo, s8, s36\n\tv_add_f32 %0, s52, %0\n\t"
             "s_and_b32 exec_lo, s8, s37\n\tv_add_f32 %0, s53, %0\n\t"
             "s_and_b32 exec_lo, s8, s38\n\tv_add_f32 %0, s54, %0\n\t"
@@ -1085,10 +1090,10 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             "s_and_b32 exec_lo, s8, s49\n\tv_add_f32 %0, s65, %0\n\t"
             "s_and_b32 exec_lo, s8, s50\n\tv_add_f32 %0, s66, %0\n\t"
             "s_and_b32 exec_lo, s8, s51\n\tv_add_f32 %0, s67, %0\n\t"
-            "s_sub_u32 s9, s9, 1\n\ts_cmp_eq_u32 s9, 0\n\ts_cbranch_scc1 2f\n\t"
-            "s_add_u32 s12, s12, 0x80\n\ts_addc_u32 s13, s13, 0\n\ts_add_u32 s14, s14, 0x80\n\ts_addc_u32 s15, s15, 0\n\t"
+            "s_sub_u32 s9, s9, 1\n\ts_cbranch_scc1 2f\n\t"
+            "s_add_u32 s30, s30, 0x80\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\ts_load_dwordx16 s[52:67], s[14:15], 0x0\n\t"
+            "s_load_dwordx16 s[36:51], s[12:13], s30\n\ts_load_dwordx16 s[52:67], s[14:15], s30\n\t"
             "s_and_b32 exec_lo, s8, s68\n\tv_add_f32 %0, s84, %0\n\t"
             "s_and_b32 exec_lo, s8, s69\n\tv_add_f32 %0, s85, %0\n\t"
             "s_and_b32 exec_lo, s8, s70\n\tv_add_f32 %0, s86, %0\n\t"
@@ -1105,13 +1110,13 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             "s_and_b32 exec_lo, s8, s81\n\tv_add_f32 %0, s97, %0\n\t"
             "s_and_b32 exec_lo, s8, s82\n\tv_add_f32 %0, s98, %0\n\t"
             "s_and_b32 exec_lo, s8, s83\n\tv_add_f32 %0, s99, %0\n\t"
-            "s_sub_u32 s9, s9, 1\n\ts_cmp_lg_u32 s9, 0\n\ts_cbranch_scc1 1b\n\t"
+            "s_sub_u32 s9, s9, 1\n\ts_cbranch_scc0 1b\n\t"
             "2:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 exec, s[10:11]"
             : "+v"(den)
             : "s"(vj), "s"(ng), "s"(mp), "s"(wp)
-            : "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
+            : "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s30", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
     }
     if (lane == 0) {  // diagnostics (tools/sim_modes.py)
         const unsigned long long dt = sim_now() - t_start;
