@@ -7,12 +7,22 @@ Mirror of ``pytrimal.BaseTrimmer`` and its four subclasses
 instead; the only compute platform of this package is ``"hip"``.
 """
 import ctypes
+import functools
 
 import numpy as np
 
 from . import _lib
 from .alignment import Alignment, TrimmedAlignment
 from .matrix import SimilarityMatrix
+
+
+@functools.lru_cache(maxsize=None)
+def _default_matrix(kind):
+    """The built-in matrices `trim` falls back to (immutable here; building one costs ~1 ms)."""
+    if kind == "aa":
+        return SimilarityMatrix.aa()
+    return SimilarityMatrix.nt(degenerated=(kind == "ntdeg"))
+
 
 _HIP_RUNTIME_SUPPORT = _lib.device_count() > 0
 _BEST_PLATFORM = "hip" if _HIP_RUNTIME_SUPPORT else None
@@ -100,9 +110,9 @@ class BaseTrimmer:
         if matrix is None:
             # create_or_use_similarity_matrix; an undetected type falls back to the AA matrix (:1342-1352)
             if ty & 4 or ty == 0:
-                matrix = SimilarityMatrix.aa()
+                matrix = _default_matrix("aa")
             else:
-                matrix = SimilarityMatrix.nt(degenerated=bool(ty & 8))
+                matrix = _default_matrix("ntdeg" if ty & 8 else "nt")
 
         params = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
         self._configure(params)
