@@ -15,6 +15,12 @@ import threading
 
 import numpy as np
 
+# Concurrent trims (one context = two HIP streams per thread) only overlap on the GPU when their streams
+# land on different hardware queues; the runtime's default is 4 queues per process, which makes batches of
+# 3+ threads serialise erratically.  Read by the HIP runtime when it initialises (first HIP call), so
+# this has no effect in a process that has already touched the GPU -- export it yourself there.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsastat_hip.so")
 

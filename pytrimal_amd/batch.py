@@ -11,6 +11,8 @@ and a gather of the kept-column / kept-sequence masks to rank 0 (`torch.distribu
 Import order matters in a process that uses PyTorch-ROCm: this module imports torch before the
 HIP library is loaded (see pytrimal_amd._lib).
 """
+from multiprocessing.pool import ThreadPool
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -41,10 +43,15 @@ def _pack_masks(results):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
 
-def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None):
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=2):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
+
+    Within a rank the shard is trimmed by `threads` threads (`trim` is re-entrant, one device context
+    per thread): the similarity kernels of one alignment leave most CUs idle, so two alignments in
+    flight double the throughput of a GPU (1000 x 4000 alignments: 1.0 -> 2.0 M columns/s; more threads
+    add nothing).
 
     `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
     which have no device).
@@ -56,10 +63,16 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     mine = shard_indices(len(alignments), world, rank)
-    local = []
-    for i in mine:
+
+    def one(i):
         t = trim_fn(alignments[i])
-        local.append((np.array(t.residues_mask, dtype=bool), np.array(t.sequences_mask, dtype=bool)))
+        return np.array(t.residues_mask, dtype=bool), np.array(t.sequences_mask, dtype=bool)
+
+    if threads > 1 and len(mine) > 1:
+        with ThreadPool(min(threads, len(mine))) as pool:
+            local = pool.map(one, mine)
+    else:
+        local = [one(i) for i in mine]
     if not distributed or world == 1:
         return [_rebuild(alignments[i], r, s) for i, (r, s) in zip(mine, local)]
 

@@ -1685,18 +1685,18 @@ void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_
                                              err_key, tcols, num_only ? 8 : 9, num_only ? 2 : 3);
 }
 
-// Columns per similarity workgroup.  The kernel's time is (pair steps) x (cycles per step) whatever the
-// column count, and the cycles per step are mostly LDS time, which scales with the active lanes: so the
-// columns are spread over as many CUs as there are (one workgroup per CU), down to 16 lanes per wave.
+// Columns per similarity workgroup: a full wave.  The kernel's time is (pair steps) x (cycles per step)
+// whatever the column count, and the LDS time per instruction does not depend on the active lanes, so
+// narrower tiles spread over more CUs buy nothing (13.8 vs 14.0 ms at 2000 x 10000) and cost a batch of
+// concurrent alignments its parallelism.  MSA_SIM_TCOLS overrides (tests exercise ragged tiles with it).
 int sim_tile_cols(int n, int cus, int min_cols) {
+    (void)n;
+    (void)cus;
     if (const char *e = getenv("MSA_SIM_TCOLS")) {
         const int t = atoi(e);
         if (t >= min_cols && t <= 64) return t;
     }
-    if (cus < 1) cus = 256;
-    int t = (n + cus - 1) / cus;
-    t = (t + 7) / 8 * 8;
-    return t < min_cols ? min_cols : (t > 64 ? 64 : t);  // the lanes of a producer fetch the W values of its round
+    return 64;
 }
 int sim_num_min_cols() { return 16; }
 
@@ -1773,7 +1773,9 @@ int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int6
     for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / NK_ROUND_OCTS;
     const int pad = (int)((3 - rounds % 3) % 3);
     rounds += pad;
-    const int lds = nk_lds_bytes();
+    // the request is rounded up to the denominator kernel's: no two chain workgroups -- of this launch, of
+    // the denominator kernel or of another context's launches -- ever share a CU (and so a SIMD)
+    const int lds = nk_lds_bytes() > DEN_LDS_BYTES ? nk_lds_bytes() : DEN_LDS_BYTES;
     auto kern = (sim_debug_mode() & 64) ? similarity_num_kernel<true> : similarity_num_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;

@@ -274,6 +274,18 @@ def test_similarity_kernel_variants(ctx, monkeypatch, kernel, shape):
     _sim_parity(ctx, synth_msa(m, n, 4242 + m))
 
 
+@pytest.mark.parametrize("kernel", ["", "pc", "codes"])
+@pytest.mark.parametrize("tcols", ["16", "24", "40"])
+def test_similarity_narrow_column_tiles(ctx, monkeypatch, kernel, tcols):
+    """MSA_SIM_TCOLS: fewer than 64 active lanes per wave (the tile width is baked into the codes)."""
+    if kernel:
+        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    monkeypatch.setenv("MSA_SIM_TCOLS", tcols)
+    _sim_parity(ctx, synth_msa(150, 211, 99))
+
+
 def test_similarity_above_resident_limit(ctx, monkeypatch):
     """m > 2016: the codes no longer fit the producers' registers, the streaming kernel takes over."""
     monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)

@@ -67,7 +67,7 @@ def main():
         batch = [synth_msa(1000, 4000, 2000 + k) for k in range(8)]  # one GPU's share of the 64
         alis = [ali_of(a) for a in batch]
         trimmer = AutomaticTrimmer("automated1", platform="hip")
-        for threads in (1, 4):
+        for threads in (1, 2, 4):
             with ThreadPool(threads) as pool:
                 pool.map(trimmer.trim, alis[:threads])
                 t = time.perf_counter()
