@@ -345,12 +345,10 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     }
     const int G8 = (m + 7) / 8;
     // kernel choice: numerator + denominator kernels with register-resident codes when the rows fit
-    // (m <= 2016), else the streaming producer/consumer kernel.  MSA_SIM_KERNEL=pc forces the latter,
-    // MSA_SIM_KERNEL=codes the single-kernel register-resident variant (all parity-tested).
+    // (m <= 2016), else the streaming producer/consumer kernel; MSA_SIM_KERNEL=pc forces the latter
+    // (parity-tested at every size).
     const char *which = getenv("MSA_SIM_KERNEL");
-    const bool fits = msak::similarity_rc_fits(m);
-    const bool rc_kernel = which && which[0] == 'c' && fits;
-    const bool split = !rc_kernel && !(which && which[0] == 'p') && fits;
+    const bool split = !(which && which[0] == 'p') && msak::similarity_rc_fits(m);
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
@@ -398,23 +396,13 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     } else {
         {
             ProfScope ps(c, "encode");
-            if (rc_kernel)
-                msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p,
-                                          c->errkey.p, tcols, false);
-            else
-                msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p,
-                                          c->errkey.p, tcols);
+            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
+                                      tcols);
         }
         HIPCHK(c, hipGetLastError());
         ProfScope ps(c, "sim");
-        int e;
-        if (rc_kernel) {
-            e = msak::launch_similarity_rc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                           gw_dev, c->q.p, c->mdk.p, tcols);
-        } else {
-            e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                           gw_dev, c->q.p, c->mdk.p, tcols);
-        }
+        const int e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
+                                                 gw_dev, c->q.p, c->mdk.p, tcols);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     HIPCHK(c, hipGetLastError());

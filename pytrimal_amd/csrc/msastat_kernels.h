@@ -26,8 +26,6 @@ int sim_den_workgroups(int nchunk);
 int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
                    int ldw, float *den_out);
 bool similarity_rc_fits(int m);
-int launch_similarity_rc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
-                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols);
 int sim_tile_cols(int n, int cus, int min_cols);
 int sim_num_min_cols();
 void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,

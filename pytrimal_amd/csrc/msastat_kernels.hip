@@ -442,7 +442,6 @@ __device__ __forceinline__ void sim_chain(f32x2 &acc, const float4 (&v)[SIM_PAIR
 // Diagnostics (MSA_SIM_MODE bit 6): per-phase cycle sums of workgroup 0, [wave][phase].
 __device__ unsigned long long g_sim_stamps[8 * 8];
 __device__ unsigned long long g_den_ticks[1024];  // diagnostics: cycles of every denominator wave (first 1024 chunks)
-__device__ int g_sim_diag;  // diagnostics switches of the DIAG instantiations (MSA_SIM_DIAG)
 __device__ __forceinline__ unsigned long long sim_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -739,289 +738,6 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// similarity_mdk with REGISTER-RESIDENT codes (m <= 8 * 14 * RC_RMAX rows): the production kernel.
-//
-// In similarity_pc_kernel every workgroup re-reads its column tile of codes once per row j: at
-// 2000 x 10000 that is 85 GB through the vector memory pipe per launch, and the kernel's skeleton
-// (fetch + barriers, no LDS work, no chain) already takes 10.7 of its 13.7 ms.  The codes of a
-// producer do not depend on j, so here they live in its registers for the whole kernel:
-//   * rounds are aligned to ABSOLUTE oct positions (round q = octs 14q .. 14q+13), so producer P
-//     always works on octs 14q + 2P, 14q + 2P + 1 and the register holding them is a compile-time
-//     function of q: the row loop is unrolled over q.  Row j starts at round q0 = ((j+1)>>3) / 14;
-//     the octs of that round that lie at or before j contribute W = 0 (W is strictly upper
-//     triangular) -- exact no-ops, like the null octs past the last row;
-//   * 16-bit codes (byte offset into the table slice), two per dword: 8 VGPRs per oct, 144 for
-//     RC_RMAX = 18; a gather costs one SDWA add (slice base + halfword) and one ds_read_b64;
-//   * the only global traffic left in the loop is W: 16 consecutive floats per producer and
-//     round, DMA'd straight into LDS (global_load_lds_dword, no VGPR in flight) two rounds ahead,
-//     read back as four broadcast ds_read_b128.
-// The ring, the table slices, the consumer and the barrier protocol are those of
-// similarity_pc_kernel.  Rounds are padded to a multiple of 3 with pseudo-rows j = m-1, whose W
-// row is all zero.
-// ------------------------------------------------------------------------------------------
-constexpr int RC_RMAX = 18;
-constexpr int RC_WSTAGE_BYTES = 3 * 256;  // per producer: three rounds of 16 W values (x4 lane copies)
-__host__ __device__ constexpr int rc_lds_bytes() {
-    return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + SIM_NP * RC_WSTAGE_BYTES;  // 157184
-}
-
-template <int Q, class F>
-__device__ __forceinline__ void rc_unroll(F &&f) {
-    if constexpr (Q < RC_RMAX) {
-        f(std::integral_constant<int, Q>{});
-        rc_unroll<Q + 1>(f);
-    }
-}
-
-// the chain wave (shared protocol: 2 + rounds barriers, ring buffer = round parity)
-template <bool DIAG = false>
-__device__ __forceinline__ void sim_consumer(unsigned char *smem, int rounds, int lane, int c, int m, int n,
-                                             const int32_t *__restrict__ gaps_w, float *__restrict__ q_out,
-                                             float *__restrict__ mdk_out) {
-    if (DIAG && (g_sim_diag & 1)) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-    const float4 *ring = reinterpret_cast<const float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
-    f32x2 acc = {0.0f, 0.0f};  // {num, den}
-    sim_barrier();             // slice[0] staged
-    sim_barrier();             // round 0 produced
-    constexpr int QP = SIM_PAIRS / 4;
-    float4 s0[QP], s1[QP], s2[QP];
-#pragma unroll
-    for (int p = 0; p < QP; ++p) s0[p] = s1[p] = s2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto rd = [&](float4 (&v)[QP], const float4 *in, int quarter) {
-#pragma unroll
-        for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto add = [&](const float4 (&v)[QP]) { sim_chain(acc, v); };
-    const bool stamp = DIAG && blockIdx.x == 0;
-    unsigned long long tw = 0, tb = 0;
-    auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
-        unsigned long long t0 = 0, t1 = 0;
-        if (stamp) t0 = sim_now();
-        const float4 *in = ring + ((r - 1) & 1) * SIM_PAIRS * 64 + lane;
-        rd(z, in, 0);
-        add(x);
-        rd(x, in, 1);
-        add(y);
-        rd(y, in, 2);
-        add(z);
-        rd(z, in, 3);
-        add(x);
-        if (stamp) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            t1 = sim_now();
-        }
-        sim_barrier();
-        if (stamp) {
-            tw += t1 - t0;
-            tb += sim_now() - t1;
-        }
-    };
-    for (int r = 1; r + 2 <= rounds; r += 3) {
-        one_round(s0, s1, s2, r);
-        one_round(s1, s2, s0, r + 1);
-        one_round(s2, s0, s1, r + 2);
-    }
-    add(s0);
-    add(s1);
-    if (stamp && lane == 0) {
-        g_sim_stamps[0] = tw;
-        g_sim_stamps[1] = tb;
-        g_sim_stamps[2] = (unsigned long long)rounds;
-    }
-    if (c < n) {
-        const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
-        float q = 0.0f, v = 0.0f;
-        if (!skip && acc.y != 0.0f) {
-            q = acc.x / acc.y;
-            v = (float)exp(-(double)q);
-            v = v > 1.0f ? 1.0f : v;
-        }
-        if (q_out) q_out[c] = q;
-        mdk_out[c] = v;
-    }
-}
-
-template <bool DIAG>
-__device__ __forceinline__ void rc_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
-                                            int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
-                                            int c, int R, int pad) {
-    const f32x2 *master = reinterpret_cast<const f32x2 *>(smem);
-    unsigned char *slices = smem + SIM_MASTER_BYTES;
-    float4 *ring = reinterpret_cast<float4 *>(smem + SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE);
-    const uint32_t wstage_base =
-        (uint32_t)(SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + P * RC_WSTAGE_BYTES);
-    const int G8 = (m + 7) >> 3;
-    const uint4 *col = codes16 + c;
-
-    // this producer's codes, for the whole kernel
-    uint4 cod[RC_RMAX][SIM_OCTS];
-#pragma unroll
-    for (int q = 0; q < RC_RMAX; ++q)
-#pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) {
-            const int g = q * SIM_ROUND_OCTS + P * SIM_OCTS + t;
-            cod[q][t] = col[(size_t)(g >= G8 ? G8 : g) * ld];  // row G8 of the array is all-skipped
-        }
-
-    auto load_cj = [&](int jn) -> uint32_t {
-        if (jn >= m - 1) return (uint32_t)npos << 9;
-        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
-        return cj[jn & 7];
-    };
-    auto refresh = [&](int jn, uint32_t cjcode) {
-        const uint32_t idx = cjcode >> 9;
-        f32x2 *sl = reinterpret_cast<f32x2 *>(slices + (jn & 1) * SIM_SLICE_STRIDE) + lane;
-        const f32x2 *mrow = master + idx * 32;
-        for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
-    };
-
-    // round positions (row, absolute round); rows past m-2 are the zero-weight pseudo-rows
-    struct Pos {
-        int j, q;
-    };
-    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / SIM_ROUND_OCTS : R - 1; };
-    auto next = [&](Pos p) {
-        if (p.q + 1 < R) return Pos{p.j, p.q + 1};
-        return Pos{p.j + 1, q0_of(p.j + 1)};
-    };
-    // W[j][8 g0 .. 8 g0 + 15] -> LDS, 64 lanes x 4 B (lane i carries element i & 15).  A round whose
-    // octs are both null multiplies zero table entries: any finite W does.
-    const uint32_t lane15x4 = (uint32_t)(lane & 15) * 4u;
-    auto wdma = [&](Pos p, int buf) {
-        const int g0 = p.q * SIM_ROUND_OCTS + P * SIM_OCTS;
-        const int gw = g0 >= G8 ? G8 - 1 : g0;
-        const int jr = p.j < m - 1 ? p.j : m - 1;
-        const float *src = wmat + ((size_t)jr * (size_t)ldw + (size_t)(8 * gw));
-        const uint32_t dst = wstage_base + (uint32_t)buf * 256u;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(lane15x4), "s"(src) : "m0", "memory");
-    };
-
-    Pos pos2 = {0, 0};
-    wdma(pos2, 0);
-    pos2 = next(pos2);
-    wdma(pos2, 1);
-    pos2 = next(pos2);
-    int buf = 0;  // stage buffer of the current round (r % 3)
-    int r = 0;
-
-    refresh(0, load_cj(0));
-    uint32_t cj_next = load_cj(1);
-    sim_barrier();  // slice[0] complete
-
-    f32x2 tvs[SIM_OCTS][8];
-    f32x4 wq[2 * SIM_OCTS];
-    const bool stamp = DIAG && blockIdx.x == 0;
-    if (DIAG && (g_sim_diag & 2)) __builtin_amdgcn_s_setprio(3);
-    unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tg = 0;
-    if (stamp) tg = sim_now();
-    auto body = [&](auto qc, int j) __attribute__((always_inline)) {
-        constexpr int Q = decltype(qc)::value;
-        // W of this round has landed (DMA'd two rounds ago; the one of the next round may be in flight)
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        const int bfar = buf == 0 ? 2 : buf - 1;  // (r + 2) % 3
-        wdma(pos2, bfar);
-        pos2 = next(pos2);
-        const uint32_t vbase = (uint32_t)(SIM_MASTER_BYTES + (j & 1) * SIM_SLICE_STRIDE);
-#pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) {
-            const uint32_t cw[4] = {cod[Q][t].x, cod[Q][t].y, cod[Q][t].z, cod[Q][t].w};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                uint32_t a0, a1;
-                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-                    : "=v"(a0) : "v"(vbase), "v"(cw[s4]));
-                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-                    : "=v"(a1) : "v"(vbase), "v"(cw[s4]));
-                asm volatile("ds_read_b64 %0, %1" : "=v"(tvs[t][2 * s4]) : "v"(a0));
-                asm volatile("ds_read_b64 %0, %1" : "=v"(tvs[t][2 * s4 + 1]) : "v"(a1));
-            }
-        }
-        const uint32_t waddr = wstage_base + (uint32_t)buf * 256u;
-#pragma unroll
-        for (int i = 0; i < 2 * SIM_OCTS; ++i)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[i]) : "v"(waddr), "i"(16 * i));
-        float4 *out = ring + ((r & 1) * SIM_PAIRS + P * SIM_OCTS * 4) * 64 + lane;
-        static_assert(SIM_OCTS == 2, "operand list below");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(tvs[0][0]), "+v"(tvs[0][1]),
-                       "+v"(tvs[0][2]), "+v"(tvs[0][3]), "+v"(tvs[0][4]), "+v"(tvs[0][5]), "+v"(tvs[0][6]),
-                       "+v"(tvs[0][7]), "+v"(tvs[1][0]), "+v"(tvs[1][1]), "+v"(tvs[1][2]), "+v"(tvs[1][3]),
-                       "+v"(tvs[1][4]), "+v"(tvs[1][5]), "+v"(tvs[1][6]), "+v"(tvs[1][7])
-                     :
-                     : "memory");
-        unsigned long long td = 0;
-        if (stamp) td = sim_now();
-#pragma unroll
-        for (int t = 0; t < SIM_OCTS; ++t) {
-            const f32x4 w03 = wq[2 * t], w47 = wq[2 * t + 1];
-            const f32x2 wp[4] = {{w03.x, w03.y}, {w03.z, w03.w}, {w47.x, w47.y}, {w47.z, w47.w}};
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                f32x2 xa, xb;
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(xa) : "v"(tvs[t][2 * pp]), "v"(wp[pp]));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(xb) : "v"(tvs[t][2 * pp + 1]), "v"(wp[pp]));
-                out[(t * 4 + pp) * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
-            }
-        }
-        if (Q == R - 1) {  // last round of row j (workgroup-uniform): stage the table slice of row j+1
-            refresh(j + 1, cj_next);
-            cj_next = load_cj(j + 2);
-        }
-        if (stamp) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tf = sim_now();
-            sim_barrier();
-            const unsigned long long tn = sim_now();
-            acc_t[0] += td - tg;  // barrier exit -> gathers and W landed
-            acc_t[1] += tf - td;  // multiplies, ring stores (drained), slice refresh
-            acc_t[2] += tn - tf;  // barrier wait
-            tg = tn;
-        } else {
-            sim_barrier();
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-        ++r;
-    };
-    const int nrows = m - 1 + pad;
-    for (int jj = 0; jj < nrows; ++jj) {
-        const int q0 = q0_of(jj);
-        rc_unroll<0>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int Q = decltype(qc)::value;
-            if (Q >= q0 && Q < R) body(qc, jj);
-        });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two W prefetches past the end
-    if (stamp && lane == 0)
-        for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
-    sim_barrier();  // the consumer's drain round
-}
-
-template <bool DIAG>
-__global__ __launch_bounds__(512) void similarity_rc_kernel(
-    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
-    const f32x2 *__restrict__ tab_g, int npos, const int32_t *__restrict__ gaps_w, int R, int pad, int rounds,
-    float *__restrict__ q_out, float *__restrict__ mdk_out, int tcols) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // the table slices and the W stage are addressed by literal LDS addresses
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * tcols + lane;
-    const bool active = lane < tcols && c < ld;  // EXEC stays masked for the whole kernel
-    {
-        f32x2 *master = reinterpret_cast<f32x2 *>(smem);
-        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t];
-    }
-    __syncthreads();
-    if (wave != 0) {
-        if (active) rc_producer<DIAG>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
-    } else if (active) {
-        sim_consumer<DIAG>(smem, rounds, lane, c, m, n, gaps_w, q_out, mdk_out);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // similarity denominators as their own kernel.  den[c] = sum over valid pairs (j < k) of W[j][k] in
 // pair order (float32, sequential): it depends only on W and on which residues are valid, so it needs
 // no table, no codes and no LDS.  One wave = one 32-column chunk of the validity plane (plane 7 of
@@ -1145,16 +861,33 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
 }
 
 // ------------------------------------------------------------------------------------------
-// similarity NUMERATORS only (the denominators come from sim_den_kernel): the register-resident
-// producer/consumer kernel with half the LDS traffic per pair step -- the table slices hold D alone
-// ([entry][lane] x 4 B), the ring carries x = W * D (4 B per lane and step, one float4 = 4 steps),
-// the chain is one v_add_f32 per step.  A skipped pair contributes W * 0 = +0.
+// similarity NUMERATORS (the denominators come from sim_den_kernel): producer/consumer like
+// similarity_pc_kernel, with REGISTER-RESIDENT codes (m <= 2016 rows) and half the LDS traffic.
+//
+// In similarity_pc_kernel every workgroup re-reads its column tile of codes once per row j: at
+// 2000 x 10000 that is 85 GB through the vector memory pipe per launch, and that kernel's skeleton
+// (fetch + barriers, no LDS work, no chain) already takes 10.7 of its 13.7 ms.  The codes of a
+// producer do not depend on j, so here they live in its registers for the whole kernel:
+//   * rounds are aligned to ABSOLUTE oct positions (round q = octs 14q .. 14q+13), so producer P
+//     always works on octs 14q + 2P, 14q + 2P + 1 and the register holding them is a compile-time
+//     function of q: the row loop is unrolled over q.  Row j starts at round q0 = ((j+1)>>3) / 14;
+//     the octs of that round that lie at or before j multiply W = 0 (W is strictly upper
+//     triangular) -- exact no-ops, like the null octs past the last row;
+//   * 16-bit codes (byte offset into the table slice), two per dword: 8 VGPRs per oct, 144 for
+//     NK_RMAX = 18 rounds; a gather costs one SDWA add (slice base + halfword) and one ds_read_b32;
+//   * the table slices hold D alone ([entry][lane] x 4 B), the ring carries x = W * D (4 B per lane
+//     and step, one float4 = 4 steps), the chain is one v_add_f32 per step; a skipped pair
+//     contributes W * 0 = +0;
+//   * the only global traffic left in the loop is W (see nk_producer).
+// Barrier protocol as in similarity_pc_kernel (2 + rounds barriers, ring buffer = round parity);
+// rounds are padded to a multiple of 3 with pseudo-rows j = m-1, whose W row is all zero.
 // LDS: master D [29][32] f32 | 2 slices [29][64] f32 | ring 2 x [28][64] float4 | W stage.
 // ------------------------------------------------------------------------------------------
+constexpr int NK_RMAX_2OCT = 18;  // rounds per row at most with 2 octs per producer and round: m <= 2016
 constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712
 constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424
 constexpr int NK_ROUND_OCTS = SIM_NP * NK_OCTS;  // 28 octs = 224 steps per round
-constexpr int NK_RMAX = RC_RMAX * SIM_OCTS / NK_OCTS;  // rounds per row at most (the codes fill the same registers)
+constexpr int NK_RMAX = NK_RMAX_2OCT * 2 / NK_OCTS;  // rounds per row at most (the codes fill the same registers)
 constexpr int NK_QUADS = NK_ROUND_OCTS * 2;      // float4 (4 steps) per lane per round
 constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 114688
 constexpr int NK_SLICES_OFF = NK_MASTER_BYTES;
@@ -1207,7 +940,8 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
         nk_chain<0>(acc, v);
         if constexpr (QP > 7) nk_chain<7>(acc, v);
     };
-    // same rotation as sim_consumer: two quarter-rounds stay pending in registers across the barrier
+    // same rotation as the consumer of similarity_pc_kernel: two quarter-rounds stay pending in registers
+    // across the barrier
     const bool stamp = DIAG && blockIdx.x == 0;
     unsigned long long tw = 0, tb = 0;
     auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
@@ -1739,31 +1473,8 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
     return 0;
 }
 
-// register-resident variant: usable when every producer's codes fit its registers
-bool similarity_rc_fits(int m) { return (m + 7) / 8 <= RC_RMAX * SIM_ROUND_OCTS; }
-
-int launch_similarity_rc(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
-                         const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols) {
-    const int G8 = (m + 7) / 8;
-    const int R = (G8 + SIM_ROUND_OCTS - 1) / SIM_ROUND_OCTS;
-    long long rounds = 0;
-    for (int j = 0; j + 1 < m; ++j) rounds += R - ((j + 1) >> 3) / SIM_ROUND_OCTS;
-    const int pad = (int)((3 - rounds % 3) % 3);  // the consumer's register sets rotate with period 3
-    rounds += pad;
-    const int lds = rc_lds_bytes();
-    auto kern = (sim_debug_mode() & 64) ? similarity_rc_kernel<true> : similarity_rc_kernel<false>;
-    if (sim_debug_mode() & 64) {
-        const char *d = getenv("MSA_SIM_DIAG");
-        const int dv = d ? atoi(d) : 0;
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sim_diag), &dv, sizeof(int), 0, hipMemcpyHostToDevice, s);
-    }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
-        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, gaps_w,
-        R, pad, (int)rounds, q_out, mdk_out, tcols);
-    return 0;
-}
+// the numerator kernel keeps every producer's codes in its registers: that bounds the row count
+bool similarity_rc_fits(int m) { return (m + 7) / 8 <= NK_RMAX * NK_ROUND_OCTS; }
 
 int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
                           const void *tab, int npos, float *num_out, int tcols) {
