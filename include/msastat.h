@@ -40,7 +40,9 @@ enum {
     MSA_E_INCORRECT_SYMBOL = -6, /* residue outside A-Z  -> ValueError (reportsystem.cpp:46-49) */
     MSA_E_UNDEFINED_SYMBOL = -7, /* residue not in the similarity matrix alphabet -> ValueError */
     MSA_E_NOT_IMPLEMENTED = -8,  /* automated2: no surviving pin in the reference checkout */
-    MSA_E_NON_ASCII = -9         /* byte >= 0x80 in the alignment */
+    MSA_E_NON_ASCII = -9,        /* byte >= 0x80 in the alignment */
+    MSA_E_LENGTH_MISMATCH = -10, /* FASTA records of different lengths: not an alignment */
+    MSA_E_BAD_RESIDUE = -11      /* FASTA ingest: byte outside the accepted residue set */
 };
 
 /* first offending residue of MSA_E_INCORRECT_SYMBOL / MSA_E_UNDEFINED_SYMBOL */
@@ -125,6 +127,18 @@ int32_t msa_select_method(float avg_seq, float max_seq, int32_t m);
 int msa_representatives(const float *ident, const int32_t *lengths, int32_t m, float max_identity,
                         uint8_t *keep_seq, int32_t *n_clusters);
 float msa_cutpoint_clusters(const float *ident, const int32_t *lengths, int32_t m, int32_t clusters);
+
+/* ---- alignment ingest: what `Alignment.load(file, "fasta")` needs from trimAl's FormatManager
+ *      (format_handling.pxd:11-32, driven by _trimal.pyx:517-601): FASTA text -> dense row-major
+ *      residue matrix, with no per-sequence host objects.  Pure host functions.
+ *      msa_fasta_scan: number of records and the residue count of the first one (whitespace removed).
+ *      msa_fasta_fill: writes matrix[m][n], the offset/length of every record's name (first field
+ *      after '>') inside `data`; `valid` is an optional 256-entry table of acceptable residue bytes.
+ *      Returns MSA_E_LENGTH_MISMATCH (detail->row = record, detail->col = its length) or
+ *      MSA_E_BAD_RESIDUE (detail->row, ->col, ->byte). */
+int msa_fasta_scan(const uint8_t *data, int64_t len, int32_t *m_out, int32_t *n_out);
+int msa_fasta_fill(const uint8_t *data, int64_t len, int32_t m, int32_t n, uint8_t *matrix, int64_t *name_off,
+                   int32_t *name_len, const uint8_t *valid, msa_err_detail *detail);
 
 /* ---- whole trim: trimAlManager::clean_alignment (manager.pxd:88) as configured by the four
  *      `_configure_manager` methods (_trimal.pyx:1479-1497,1651-1659,1766-1769,1859-1862) ------ */

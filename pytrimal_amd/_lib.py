@@ -27,6 +27,7 @@ LIB_PATH = os.path.join(_HERE, "libmsastat_hip.so")
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_WINDOW_TOO_BIG = -1, -2, -3, -4, -5
 E_INCORRECT_SYMBOL, E_UNDEFINED_SYMBOL, E_NOT_IMPLEMENTED, E_NON_ASCII = -6, -7, -8, -9
+E_LENGTH_MISMATCH, E_BAD_RESIDUE = -10, -11
 
 METHOD_CODES = {
     None: 0, "strict": 1, "strictplus": 2, "gappyout": 3, "nogaps": 4, "noallgaps": 5,
@@ -42,7 +43,7 @@ EXPORTS = [
     "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
     "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_prof_get", "msa_prof_reset",
-    "msa_prof_enable",
+    "msa_prof_enable", "msa_fasta_scan", "msa_fasta_fill",
 ]
 
 
@@ -123,6 +124,8 @@ def load():
         L.msa_identity_stats.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]
         L.msa_similarity.argtypes = [vp, vp, vp, i32, vp, vp, vp, ctypes.POINTER(ErrDetail)]
         L.msa_overlap.argtypes = [vp, f32, vp]
+        L.msa_fasta_scan.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.msa_fasta_fill.argtypes = [vp, ctypes.c_int64, i32, i32, vp, vp, vp, vp, ctypes.POINTER(ErrDetail)]
         L.msa_window_i32.argtypes = [vp, i32, i32, vp]
         L.msa_window_f32.argtypes = [vp, i32, i32, vp]
         L.msa_gaps_cutpoint.argtypes = [vp, i32, i32, f32, f32]

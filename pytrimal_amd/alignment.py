@@ -248,6 +248,9 @@ class Alignment:
             fmt = "clustal" if head.startswith(b"CLUSTAL") else "fasta"
         fmt = fmt.lower()
         if fmt == "fasta":
+            fast = _load_fasta_native(cls, data, file)
+            if fast is not None:
+                return fast
             names, seqs = _parse_fasta(data)
         elif fmt == "clustal":
             names, seqs = _parse_clustal(data)
@@ -382,6 +385,50 @@ class TrimmedAlignment(Alignment):
 
 
 # --- minimal readers --------------------------------------------------------------------------
+
+def _load_fasta_native(cls, data, file):
+    """FASTA text -> Alignment through the native ingest of libmsastat (`msa_fasta_scan` / `msa_fasta_fill`):
+    one pass to size the matrix, one to fill it and validate the residues, no per-sequence Python objects
+    except the names.  Returns None when the library is not built (the pure-Python parser takes over)."""
+    import ctypes
+
+    from . import _lib
+
+    try:
+        L = _lib.load()
+    except (RuntimeError, OSError):
+        return None
+    buf = np.frombuffer(data, dtype=np.uint8)
+    m, n = ctypes.c_int32(0), ctypes.c_int32(0)
+    if L.msa_fasta_scan(buf.ctypes.data, buf.size, ctypes.byref(m), ctypes.byref(n)) != 0:
+        return None
+    m, n = m.value, n.value
+    if m == 0:
+        raise RuntimeError(f"Failed to load alignment from {file!r}.")
+    matrix = np.empty((m, n), dtype=np.uint8)
+    off = np.empty(m, dtype=np.int64)
+    ln = np.empty(m, dtype=np.int32)
+    valid = _VALID.view(np.uint8)
+    detail = _lib.ErrDetail()
+    rc = L.msa_fasta_fill(buf.ctypes.data, buf.size, m, n, matrix.ctypes.data, off.ctypes.data, ln.ctypes.data,
+                          valid.ctypes.data, ctypes.byref(detail))
+    names = [bytes(data[o:o + k]) for o, k in zip(off.tolist(), ln.tolist())]
+    if rc == _lib.E_LENGTH_MISMATCH:
+        raise ValueError(f"Sequence length mismatch in sequence {detail.row}: {detail.col} != {n}")
+    if rc == _lib.E_BAD_RESIDUE:
+        raise ValueError(f"The sequence \"{names[detail.row].decode('ascii', 'replace')}\" has an unknown "
+                         f"({detail.byte}) character")
+    if rc != 0:
+        return None
+    out = cls.__new__(cls)
+    out._names = names
+    out._matrix = matrix
+    out._datatype = 0
+    out._seq_mask = np.ones(m, dtype=bool)
+    out._res_mask = np.ones(n, dtype=bool)
+    out._reindex()
+    return out
+
 
 def _parse_fasta(data):
     names, seqs = [], []

@@ -604,6 +604,8 @@ const char *msa_strerror(int code) {
         case MSA_E_UNDEFINED_SYMBOL: return "symbol not defined in the similarity matrix";
         case MSA_E_NOT_IMPLEMENTED: return "method not implemented";
         case MSA_E_NON_ASCII: return "non-ASCII byte in the alignment";
+        case MSA_E_LENGTH_MISMATCH: return "sequences of different lengths";
+        case MSA_E_BAD_RESIDUE: return "unknown character in a sequence";
         default: return "unknown error";
     }
 }

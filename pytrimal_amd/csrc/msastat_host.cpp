@@ -11,6 +11,7 @@
 // Everything here is pure host code and is exported through the C ABI (include/msastat.h) so
 // that it can be exercised without a device.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -411,6 +412,120 @@ float cutpoint_clusters(const float *ident, int ldi, const int32_t *lengths, int
 }  // namespace msah
 
 // ---- C ABI ----------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// FASTA ingest (Alignment.load): text -> dense residue matrix
+// --------------------------------------------------------------------------------------------
+namespace {
+inline bool fasta_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Calls rec(start_of_name_line, end) at every header line and seq(ptr, end) for every other non-blank line
+// that follows a header.  Lines are '\n'-separated; leading blanks of a line are skipped before the '>' test.
+template <class Rec, class Seq>
+void fasta_walk(const uint8_t *data, int64_t len, Rec &&rec, Seq &&seq) {
+    const uint8_t *p = data, *end = data + len;
+    bool in_record = false;
+    while (p < end) {
+        const uint8_t *eol = static_cast<const uint8_t *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!eol) eol = end;
+        const uint8_t *q = p;
+        while (q < eol && fasta_space(*q)) ++q;
+        if (q < eol) {
+            if (*q == '>') {
+                rec(q + 1, eol);
+                in_record = true;
+            } else if (in_record) {
+                seq(q, eol);
+            }
+        }
+        p = eol + 1;
+    }
+}
+}  // namespace
+
+extern "C" int msa_fasta_scan(const uint8_t *data, int64_t len, int32_t *m_out, int32_t *n_out) {
+    if (!data || len < 0 || !m_out || !n_out) return MSA_E_INVALID;
+    int64_t m = 0, n0 = 0;
+    fasta_walk(
+        data, len, [&](const uint8_t *, const uint8_t *) { ++m; },
+        [&](const uint8_t *a, const uint8_t *b) {
+            if (m != 1) return;
+            for (; a < b; ++a) n0 += !fasta_space(*a);
+        });
+    if (m > INT32_MAX || n0 > INT32_MAX) return MSA_E_INVALID;
+    *m_out = static_cast<int32_t>(m);
+    *n_out = static_cast<int32_t>(n0);
+    return MSA_OK;
+}
+
+extern "C" int msa_fasta_fill(const uint8_t *data, int64_t len, int32_t m, int32_t n, uint8_t *matrix,
+                              int64_t *name_off, int32_t *name_len, const uint8_t *valid, msa_err_detail *detail) {
+    if (!data || len < 0 || m < 0 || n < 0 || (!matrix && (int64_t)m * n > 0) || !name_off || !name_len) return MSA_E_INVALID;
+    int64_t row = -1, col = 0;
+    int rc = MSA_OK;
+    auto fail = [&](int code, int64_t r, int64_t c, int byte) {
+        if (rc != MSA_OK) return;
+        rc = code;
+        if (detail) {
+            detail->row = static_cast<int32_t>(r);
+            detail->col = static_cast<int32_t>(c);
+            detail->byte = byte;
+        }
+    };
+    auto close_row = [&]() {
+        if (row >= 0 && row < m && col != n) fail(MSA_E_LENGTH_MISMATCH, row, col, 0);
+    };
+    uint8_t cls[256];
+    for (int ch = 0; ch < 256; ++ch) cls[ch] = fasta_space(static_cast<uint8_t>(ch)) ? 1 : ((valid && !valid[ch]) ? 2 : 0);
+    fasta_walk(
+        data, len,
+        [&](const uint8_t *a, const uint8_t *b) {
+            close_row();
+            ++row;
+            col = 0;
+            if (row >= m) return;
+            while (a < b && fasta_space(*a)) ++a;  // ">  name" keeps an empty name, as bytes.split() would not:
+            const uint8_t *e = a;                   // the first field of the stripped line after '>'
+            while (e < b && !fasta_space(*e)) ++e;
+            name_off[row] = a - data;
+            name_len[row] = static_cast<int32_t>(e - a);
+        },
+        [&](const uint8_t *a, const uint8_t *b) {
+            if (row >= m || rc != MSA_OK) return;
+            uint8_t *dst = matrix + static_cast<size_t>(row) * static_cast<size_t>(n);
+            // fast path: the line fits the row; copy while classifying (0 residue, 1 blank, 2 not accepted)
+            const int64_t room = n - col;
+            if (b - a <= room) {
+                uint8_t *out = dst + col;
+                unsigned worst = 0;
+                for (const uint8_t *q = a; q < b; ++q) {
+                    const unsigned k = cls[*q];
+                    *out = *q;
+                    out += (k == 0);
+                    worst |= k;
+                }
+                if (!(worst & 2)) {
+                    col += out - (dst + col);
+                    return;
+                }
+            }
+            for (; a < b; ++a) {  // slow path: overlong row or a byte outside the accepted set
+                const uint8_t ch = *a;
+                if (cls[ch] == 1) continue;
+                if (col < n) {
+                    if (cls[ch] == 2) {
+                        fail(MSA_E_BAD_RESIDUE, row, col, ch);
+                        return;
+                    }
+                    dst[col] = ch;
+                }
+                ++col;
+            }
+        });
+    close_row();
+    if (rc == MSA_OK && row + 1 != m) return MSA_E_INVALID;
+    return rc;
+}
+
 extern "C" {
 
 int msa_window_i32(const int32_t *v, int32_t n, int32_t hw, int32_t *out) { return msah::window_i32(v, n, hw, out); }

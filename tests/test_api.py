@@ -221,3 +221,57 @@ def test_similarity_matrix():
     with open(data_path("pam70.json")) as f:
         pam70 = SimilarityMatrix(**json.load(f))  # tests/test_automatic_trimmer.py:64-72
     assert len(pam70) == 23
+
+
+# --- native FASTA ingest (include/msastat.h: msa_fasta_scan / msa_fasta_fill) against the pure-Python parser
+
+
+FASTA_CASES = [
+    b">a\nAC-GT\n>b x y\nAC\n-GT\n\n",
+    b"leading garbage\n>a\nAB\n>b\nCD",
+    b"> \nAB\n>b\nCD\n",
+    b">a\r\nA B\r\n>b\r\nCD\r\n",
+    b">a\nAB \n C\n>b\n A B C \n",
+    b">only\n" + b"ACDEFGHIKLMNPQRSTVWY-" * 40 + b"\n",
+]
+
+
+@pytest.mark.parametrize("text", FASTA_CASES)
+def test_native_fasta_ingest_matches_python_parser(text):
+    from pytrimal_amd import alignment as A
+
+    fast = A._load_fasta_native(Alignment, text, "<test>")
+    assert fast is not None, "libmsastat_hip.so must be built (host functions need no device)"
+    names, seqs = A._parse_fasta(text)
+    slow = Alignment(names, seqs)
+    assert fast.names == slow.names
+    assert list(fast.sequences) == list(slow.sequences)
+    assert Alignment.load(io.BytesIO(text), "fasta").names == slow.names
+
+
+def test_native_fasta_ingest_on_fixture():
+    from pytrimal_amd import alignment as A
+
+    with open(data_path("ENOG411BWBU.seq40.res60.fasta"), "rb") as f:
+        text = f.read()
+    fast = A._load_fasta_native(Alignment, text, "<fixture>")
+    names, seqs = A._parse_fasta(text)
+    assert fast.names == names and list(fast.sequences) == [s.decode() for s in seqs]
+    assert len(fast.sequences) == 209 and len(fast.residues) == 1227
+
+
+@pytest.mark.parametrize("text, message", [
+    (b">a\nABC\n>b\nAB\n", "Sequence length mismatch in sequence 1: 2 != 3"),
+    (b">a\nAB\n>b\nABC\n", "Sequence length mismatch in sequence 1: 3 != 2"),
+    (b">a\nAB1\n>b\nABC\n", 'The sequence "a" has an unknown (49) character'),
+])
+def test_native_fasta_ingest_errors(text, message):
+    from pytrimal_amd import alignment as A
+
+    with pytest.raises(ValueError) as fast:
+        Alignment.load(io.BytesIO(text), "fasta")
+    with pytest.raises(ValueError) as slow:
+        Alignment(*A._parse_fasta(text))
+    assert str(fast.value) == str(slow.value) == message
+    with pytest.raises(RuntimeError):
+        Alignment.load(io.BytesIO(b"no records here\n"), "fasta")
