@@ -195,6 +195,9 @@ def main():
                 "sample": f"all {m} sequences x first {ncols} columns of the same alignment, oracle.trim('{method}') "
                           f"single thread, {cpu_s:.1f} s (cost per column equals the full workload's)",
                 "seconds": round(cpu_s, 2),
+                # two pairwise passes (pair counts, similarity) over m(m-1)/2 pairs x ncols columns: the rate to
+                # hold against the reference's published SIMD numbers (2.0e9 .. 6.3e9 per core)
+                "pair_columns_per_s": round(2 * (m * (m - 1) // 2) * ncols / cpu_s, 1),
             }
             out["speedup_vs_cpu_port"] = round(value / (ncols / cpu_s), 1)
         print(json.dumps(out), flush=True)
