@@ -344,13 +344,13 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         gw_dev = c->gaps_w.p;
     }
     const int G8 = (m + 7) / 8;
-    // kernel choice: numerator + denominator kernels with register-resident codes when the rows fit
-    // (m <= 2016), else the streaming producer/consumer kernel; MSA_SIM_KERNEL=pc forces the latter
-    // (parity-tested at every size).
+    // kernel choice: numerator + denominator kernels (the numerator kernel keeps its codes in registers when
+    // the rows fit, m <= 2016, and streams them otherwise); MSA_SIM_KERNEL=pc forces the single-chain
+    // producer/consumer kernel (parity-tested at every size).
     const char *which = getenv("MSA_SIM_KERNEL");
-    const bool split = !(which && which[0] == 'p') && msak::similarity_rc_fits(m);
+    const bool split = !(which && which[0] == 'p');
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
-    const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32), c->cus / 2) : c->cus;
+    const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
     HIPCHK(c, c->errkey.reserve(1));

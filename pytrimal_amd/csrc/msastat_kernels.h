@@ -22,7 +22,7 @@ int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int6
                           const void *tab, int npos, float *num_out, int tcols);
 void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,
                        float *q_out, float *mdk_out);
-int sim_den_workgroups(int nchunk);
+int sim_den_workgroups(int nchunk, int m);
 int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
                    int ldw, float *den_out);
 bool similarity_rc_fits(int m);

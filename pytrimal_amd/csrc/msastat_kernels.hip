@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
 // ~24 cycles of issue).  Rows start at the 16-aligned k below j+1 and end at the 16-aligned k above m:
 // W is strictly upper triangular and zero-padded, so the extra steps add +0.
 // ------------------------------------------------------------------------------------------
-constexpr int DEN_WAVES = 4;             // chunks per workgroup, one per SIMD
+constexpr int DEN_WAVES = 4;             // chunks per workgroup at most, one per SIMD
 constexpr int DEN_GROUP = 16;            // pair steps per SGPR buffer of the denominator loop
 constexpr int DEN_LDS_BYTES = 96 * 1024;  // never touched: keeps a numerator workgroup off this CU (see below)
 __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t *__restrict__ planes, int nchunk,
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
                                                                  const float *__restrict__ wmat, int ldw,
                                                                  float *__restrict__ den_out) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = blockIdx.x * DEN_WAVES + wave;
+    const int chunk = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (chunk >= nchunk) return;
     const uint32_t *masks = planes + ((size_t)7 * nchunk + chunk) * (size_t)m_pad;
     const int lane = threadIdx.x & 63;
@@ -846,7 +846,22 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
     if (lane < 32 && c < n) den_out[c] = den;
 }
 
-int sim_den_workgroups(int nchunk) { return (nchunk + DEN_WAVES - 1) / DEN_WAVES; }
+// Waves (= 32-column chunks) per denominator workgroup.  Each wave cycles through its m validity words once per
+// row; they are served by the scalar cache while the waves of a CU fit it together (4 x 8 KB at m = 2000 run at
+// 12.4 cycles per step; 4 x 14 KB at m = 3583 ran at 32: every group load exposed the L2 latency).
+int sim_den_waves(int m) {
+    if (const char *e = getenv("MSA_DEN_WAVES")) {
+        const int w = atoi(e);
+        if (w >= 1 && w <= DEN_WAVES) return w;
+    }
+    const long mask_bytes = 4L * (m + 64);
+    const long w = (36 * 1024) / mask_bytes;
+    return (int)(w < 1 ? 1 : (w > DEN_WAVES ? DEN_WAVES : w));
+}
+int sim_den_workgroups(int nchunk, int m) {
+    const int w = sim_den_waves(m);
+    return (nchunk + w - 1) / w;
+}
 
 int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
                    int ldw, float *den_out) {
@@ -855,8 +870,8 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEN_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    sim_den_kernel<<<sim_den_workgroups(nchunk), 64 * DEN_WAVES, DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n, wmat,
-                                                                                  ldw, den_out);
+    sim_den_kernel<<<sim_den_workgroups(nchunk, m), 64 * sim_den_waves(m), DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n,
+                                                                                             wmat, ldw, den_out);
     return 0;
 }
 
@@ -981,24 +996,31 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
     if (c < n) num_out[c] = acc;
 }
 
-template <bool DIAG>
+// RESIDENT = true: the codes stay in registers (m <= 2016).  RESIDENT = false: any m; the codes of the next
+// round are fetched one round ahead into one of two register sets (16-bit codes: half the bytes of the
+// streaming similarity_pc_kernel), everything else is shared.
+template <bool DIAG, bool RESIDENT>
 __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
                                             int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
-                                            int c, int R, int pad) {
+                                            int c, int R, int pad, int rounds) {
     const float *master = reinterpret_cast<const float *>(smem);
     unsigned char *slices = smem + NK_SLICES_OFF;
     float4 *ring = reinterpret_cast<float4 *>(smem + NK_RING_OFF);
     const int G8 = (m + 7) >> 3;
     const uint4 *col = codes16 + c;
 
-    uint4 cod[NK_RMAX][NK_OCTS];  // this producer's codes, for the whole kernel
-#pragma unroll
-    for (int q = 0; q < NK_RMAX; ++q)
+    auto fetch_codes = [&](uint4 (&u)[NK_OCTS], int q) {  // row G8 of the array is all-skipped
 #pragma unroll
         for (int t = 0; t < NK_OCTS; ++t) {
             const int g = q * NK_ROUND_OCTS + P * NK_OCTS + t;
-            cod[q][t] = col[(size_t)(g >= G8 ? G8 : g) * ld];
+            u[t] = col[(size_t)(g >= G8 ? G8 : g) * ld];
         }
+    };
+    uint4 cod[RESIDENT ? NK_RMAX : 3][NK_OCTS];  // this producer's codes: all of them, or three rounds' worth
+    if (RESIDENT) {
+#pragma unroll
+        for (int q = 0; q < NK_RMAX; ++q) fetch_codes(cod[q], q);
+    }
     auto load_cj = [&](int jn) -> uint32_t {
         if (jn >= m - 1) return (uint32_t)npos << 8;
         const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
@@ -1039,20 +1061,22 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         const float *src = wrow_of(0) + q0_of(0) * (NK_ROUND_OCTS * 8);
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(lane15x4), "s"(src) : "m0", "memory");
     }
-    auto body = [&](auto qc, int j, const float *wrow) __attribute__((always_inline)) {
-        constexpr int Q = decltype(qc)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this round's W has landed (issued a round ago)
+    // One round: cq = this round's codes; wsrc_next = W source of the next round; last_of_row: the table slice of
+    // row j+1 is staged at the end; prefetch(): further loads for the next round, issued after the wait.
+    auto round_work = [&](const uint4 (&cq)[NK_OCTS], int j, const float *wsrc_next, bool last_of_row,
+                          auto &&prefetch) __attribute__((always_inline)) {
+        // This round's W (DMA'd a round ago) has landed.  When streaming, the two code loads of the NEXT round,
+        // issued after that DMA, may still be in flight (vmcnt counts in order).
+        if (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
-        {
-            // (the instruction's immediate offset would also move the LDS address: scalar adds instead)
-            const float *src = Q == R - 1 ? wrow_of(j + 1) + q0_of(j + 1) * (NK_ROUND_OCTS * 8)  // opens row j+1
-                                          : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(src) : "m0", "memory");
-        }
+        // (the instruction's immediate offset would also move the LDS address: the source is a full pointer)
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(wsrc_next) : "m0", "memory");
+        prefetch();
         const uint32_t vbase = (uint32_t)(NK_SLICES_OFF + (j & 1) * NK_SLICE_STRIDE);
 #pragma unroll
         for (int t = 0; t < NK_OCTS; ++t) {
-            const uint32_t cw[4] = {cod[Q][t].x, cod[Q][t].y, cod[Q][t].z, cod[Q][t].w};
+            const uint32_t cw[4] = {cq[t].x, cq[t].y, cq[t].z, cq[t].w};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 uint32_t a0, a1;
@@ -1088,7 +1112,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
                 const f32x2 xb = f32x2{tv[t][4 * h + 2], tv[t][4 * h + 3]} * f32x2{w.z, w.w};
                 out[(t * 2 + h) * 64] = make_float4(xa.x, xa.y, xb.x, xb.y);
             }
-        if (Q == R - 1) {  // last round of row j: stage the table slice of row j+1
+        if (last_of_row) {  // stage the table slice of row j+1
             refresh(j + 1, cj_next);
             cj_next = load_cj(j + 2);
         }
@@ -1107,13 +1131,46 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         ++r;
     };
     const int nrows = m - 1 + pad;
-    for (int jj = 0; jj < nrows; ++jj) {
-        const int q0 = q0_of(jj);
-        const float *wrow = wrow_of(jj);
-        nk_unroll<0>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int Q = decltype(qc)::value;
-            if (Q >= q0 && Q < R) body(qc, jj, wrow);
-        });
+    if constexpr (RESIDENT) {
+        (void)rounds;
+        for (int jj = 0; jj < nrows; ++jj) {
+            const int q0 = q0_of(jj);
+            const float *wrow = wrow_of(jj);
+            nk_unroll<0>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int Q = decltype(qc)::value;
+                if (Q >= q0 && Q < R) {
+                    const bool last = Q == R - 1;
+                    const float *wsrc_next = last ? wrow_of(jj + 1) + q0_of(jj + 1) * (NK_ROUND_OCTS * 8)
+                                                  : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
+                    round_work(cod[Q], jj, wsrc_next, last, [] {});
+                }
+            });
+        }
+    } else {
+        // (row, round) sequence: row jj runs rounds q0(jj) .. R-1.  Codes are fetched TWO rounds ahead (an L2
+        // miss takes longer than a round) into three rotating register sets.
+        static_assert(NK_OCTS == 2, "the vmcnt(2) above counts the two code loads of a round");
+        struct Pos {
+            int j, q;
+        };
+        auto next = [&](Pos p) { return p.q == R - 1 ? Pos{p.j + 1, q0_of(p.j + 1)} : Pos{p.j, p.q + 1}; };
+        Pos pos = {0, q0_of(0)};
+        Pos pos1 = next(pos);
+        fetch_codes(cod[0], pos.q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // order: [codes(0)] [W(0) DMA above] -> then codes(1) is the young pair
+        fetch_codes(cod[1], pos1.q);
+        auto step = [&](const uint4 (&cur)[NK_OCTS], uint4 (&far)[NK_OCTS]) __attribute__((always_inline)) {
+            const Pos pos2 = next(pos1);
+            const float *wsrc_next = wrow_of(pos1.j) + pos1.q * (NK_ROUND_OCTS * 8);
+            round_work(cur, pos.j, wsrc_next, pos.q == R - 1, [&] { fetch_codes(far, pos2.q); });
+            pos = pos1;
+            pos1 = pos2;
+        };
+        for (int rr = 0; rr < rounds; rr += 3) {
+            step(cod[0], cod[2]);
+            if (rr + 1 < rounds) step(cod[1], cod[0]);
+            if (rr + 2 < rounds) step(cod[2], cod[1]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the W prefetch past the end
     if (stamp && lane == 0)
@@ -1121,7 +1178,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     sim_barrier();  // the consumer's drain round
 }
 
-template <bool DIAG>
+template <bool DIAG, bool RESIDENT>
 __global__ __launch_bounds__(512) void similarity_num_kernel(
     const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, int R, int pad, int rounds, float *__restrict__ num_out, int tcols) {
@@ -1139,7 +1196,7 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
     if (wave != 0) {
         // the chain wave has slack every round; the producer that shares its SIMD does not
         __builtin_amdgcn_s_setprio(2);
-        if (active) nk_producer<DIAG>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad);
+        if (active) nk_producer<DIAG, RESIDENT>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad, rounds);
     } else if (active) {
         nk_consumer<DIAG>(smem, rounds, lane, c, n, num_out);
     }
@@ -1487,7 +1544,9 @@ int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int6
     // the request is rounded up to the denominator kernel's: no two chain workgroups -- of this launch, of
     // the denominator kernel or of another context's launches -- ever share a CU (and so a SIMD)
     const int lds = nk_lds_bytes() > DEN_LDS_BYTES ? nk_lds_bytes() : DEN_LDS_BYTES;
-    auto kern = (sim_debug_mode() & 64) ? similarity_num_kernel<true> : similarity_num_kernel<false>;
+    const bool resident = similarity_rc_fits(m);
+    auto kern = (sim_debug_mode() & 64) ? (resident ? similarity_num_kernel<true, true> : similarity_num_kernel<true, false>)
+                                        : (resident ? similarity_num_kernel<false, true> : similarity_num_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(

@@ -286,10 +286,19 @@ def test_similarity_narrow_column_tiles(ctx, monkeypatch, kernel, tcols):
     _sim_parity(ctx, synth_msa(150, 211, 99))
 
 
-def test_similarity_above_resident_limit(ctx, monkeypatch):
-    """m > 2016: the codes no longer fit the producers' registers, the streaming kernel takes over."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+@pytest.mark.parametrize("kernel", ["", "pc"])
+def test_similarity_above_resident_limit(ctx, monkeypatch, kernel):
+    """m > 2016: the codes no longer fit the producers' registers; the numerator kernel streams them."""
+    if kernel:
+        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     _sim_parity(ctx, synth_msa(2100, 72, 77))
+
+
+def test_similarity_streaming_numerator_odd_rows(ctx, monkeypatch):
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(2017, 33, 79))
 
 
 def test_similarity_at_resident_limit(ctx, monkeypatch):
