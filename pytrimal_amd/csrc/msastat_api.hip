@@ -382,8 +382,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipEventRecord(c->ev_join, sden));
         {
             ProfScope pe(c, "encode");
-            msak::launch_sim_encode16(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
-                                      tcols, true);
+            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
         }
         {
             ProfScope pn(c, "simnum");

@@ -337,12 +337,12 @@ __host__ __device__ constexpr int sim_lds_bytes(int) {
     return SIM_MASTER_BYTES + 2 * SIM_SLICE_STRIDE + SIM_RING_BYTES + SIM_NP * SIM_WSTAGE_BYTES;  // 153600
 }
 
-__global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                           const uint8_t *__restrict__ lut_g, int npos,
-                                                           const int32_t *__restrict__ gaps_w,
-                                                           uint4 *__restrict__ codes16,
-                                                           unsigned long long *__restrict__ err_key, int tcols,
-                                                           int eshift, int lshift) {
+// numerator-kernel codes: one byte per residue, NK_K + table row (row `npos` = skipped), 8 rows per uint2
+__global__ __launch_bounds__(256) void sim_encode8_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                          const uint8_t *__restrict__ lut_g, int npos,
+                                                          const int32_t *__restrict__ gaps_w,
+                                                          uint2 *__restrict__ codes8,
+                                                          unsigned long long *__restrict__ err_key, int kbase) {
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
@@ -351,8 +351,7 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
     const int g = blockIdx.y;  // 0 .. G8: the extra row G8 lies past row m-1 => all skipped
     bool skipcol = true;
     if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
-    uint32_t half[8];
-    const uint32_t lane8 = (uint32_t)(c % tcols) << lshift;  // the column's lane in its similarity workgroup
+    uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = g * 8 + r;
@@ -370,10 +369,9 @@ __global__ __launch_bounds__(256) void sim_encode16_kernel(const uint8_t *__rest
                 idx = code >> 3;
             }
         }
-        half[r] = (idx << eshift) + lane8;
+        w[r >> 2] |= ((uint32_t)kbase + idx) << (8 * (r & 3));
     }
-    codes16[(size_t)g * ld + c] = make_uint4(half[0] | (half[1] << 16), half[2] | (half[3] << 16),
-                                             half[4] | (half[5] << 16), half[6] | (half[7] << 16));
+    codes8[(size_t)g * ld + c] = make_uint2(w[0], w[1]);
 }
 
 __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
@@ -877,7 +875,7 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
 
 // ------------------------------------------------------------------------------------------
 // similarity NUMERATORS (the denominators come from sim_den_kernel): producer/consumer like
-// similarity_pc_kernel, with REGISTER-RESIDENT codes (m <= 2016 rows) and half the LDS traffic.
+// similarity_pc_kernel, with REGISTER-RESIDENT codes (m <= 4032 rows) and half the LDS traffic.
 //
 // In similarity_pc_kernel every workgroup re-reads its column tile of codes once per row j: at
 // 2000 x 10000 that is 85 GB through the vector memory pipe per launch, and that kernel's skeleton
@@ -888,27 +886,34 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
 //     function of q: the row loop is unrolled over q.  Row j starts at round q0 = ((j+1)>>3) / 14;
 //     the octs of that round that lie at or before j multiply W = 0 (W is strictly upper
 //     triangular) -- exact no-ops, like the null octs past the last row;
-//   * 16-bit codes (byte offset into the table slice), two per dword: 8 VGPRs per oct, 144 for
-//     NK_RMAX = 18 rounds; a gather costs one SDWA add (slice base + halfword) and one ds_read_b32;
+//   * 8-bit codes (table entry + NK_K), four per dword: 4 VGPRs per round, 144 for NK_RMAX = 36 rounds
+//     (m <= 4032); a gather costs one v_perm_b32 (address from the code byte) and one ds_read_b32;
 //   * the table slices hold D alone ([entry][lane] x 4 B), the ring carries x = W * D (4 B per lane
 //     and step, one float4 = 4 steps), the chain is one v_add_f32 per step; a skipped pair
 //     contributes W * 0 = +0;
 //   * the only global traffic left in the loop is W (see nk_producer).
 // Barrier protocol as in similarity_pc_kernel (2 + rounds barriers, ring buffer = round parity);
 // rounds are padded to a multiple of 3 with pseudo-rows j = m-1, whose W row is all zero.
-// LDS: master D [29][32] f32 | 2 slices [29][64] f32 | ring 2 x [28][64] float4 | W stage.
+// LDS: master D [29][32] f32 | slice 0 | ring 2 x [28][64] float4 | slice 1 (64 KB above slice 0) | W stage.
 // ------------------------------------------------------------------------------------------
-constexpr int NK_RMAX_2OCT = 18;  // rounds per row at most with 2 octs per producer and round: m <= 2016
-constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712
-constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424
-constexpr int NK_ROUND_OCTS = SIM_NP * NK_OCTS;  // 28 octs = 224 steps per round
-constexpr int NK_RMAX = NK_RMAX_2OCT * 2 / NK_OCTS;  // rounds per row at most (the codes fill the same registers)
+constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712, at LDS address 0
+constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424: [entry][lane] x 4 B
+constexpr int NK_ROUND_OCTS = SIM_NP * NK_OCTS;  // 14 octs = 112 steps per round
 constexpr int NK_QUADS = NK_ROUND_OCTS * 2;      // float4 (4 steps) per lane per round
-constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 114688
-constexpr int NK_SLICES_OFF = NK_MASTER_BYTES;
-constexpr int NK_RING_OFF = NK_SLICES_OFF + 2 * NK_SLICE_STRIDE;  // 18560
-constexpr int NK_WSTAGE_OFF = NK_RING_OFF + NK_RING_BYTES;  // per producer 2 x 256 B: the W values of this and the next round
-__host__ __device__ constexpr int nk_lds_bytes() { return NK_WSTAGE_OFF + SIM_NP * 512; }  // 79488
+constexpr int NK_RING_BYTES = 2 * NK_QUADS * 64 * 16;  // 57344
+// A code is ONE BYTE: NK_K + table entry.  The gather address (slice base + entry * 256 + lane * 4) is built by a
+// single v_perm_b32: byte 0 = lane * 4, byte 1 = the code, byte 2 = the row parity (the two slices lie 64 KB apart).
+constexpr int NK_K = 16;                                   // slice 0 starts at LDS byte NK_K * 256
+constexpr int NK_SLICE0_OFF = NK_K * 256;                  // 4096
+constexpr int NK_SLICE1_OFF = NK_SLICE0_OFF + 65536;       // 69632
+constexpr int NK_RING_OFF = NK_SLICE0_OFF + NK_SLICE_STRIDE;  // 11520 .. 68864: between the slices
+constexpr int NK_WSTAGE_OFF = NK_SLICE1_OFF + NK_SLICE_STRIDE;  // 77056; per producer 2 x 256 B: W of this and the next round
+static_assert(NK_MASTER_BYTES <= NK_SLICE0_OFF && NK_RING_OFF + NK_RING_BYTES <= NK_SLICE1_OFF && NK_K + 29 <= 256, "LDS layout");
+// Rounds per row with resident codes (one uint4 = 16 codes per round): two instantiations, 18 rounds (m <= 2016)
+// and 36 (m <= 4032) -- the row loop is unrolled over the rounds, and the 36-round body (70 KB of code) overflows
+// the instruction cache enough to cost 13 % at m = 2000, and the denominator kernel next door as much.
+constexpr int NK_RMAX = 36;
+__host__ __device__ constexpr int nk_lds_bytes() { return NK_WSTAGE_OFF + SIM_NP * 512; }  // 80640
 
 template <int B>
 __device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS / 4]) {  // quads B .. B+6: 28 steps
@@ -926,11 +931,11 @@ __device__ __forceinline__ void nk_chain(float &acc, const float4 (&v)[NK_QUADS 
 #undef NK_Q
 }
 
-template <int Q, class F>
+template <int Q, int RM, class F>
 __device__ __forceinline__ void nk_unroll(F &&f) {
-    if constexpr (Q < NK_RMAX) {
+    if constexpr (Q < RM) {
         f(std::integral_constant<int, Q>{});
-        nk_unroll<Q + 1>(f);
+        nk_unroll<Q + 1, RM>(f);
     }
 }
 
@@ -996,39 +1001,36 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
     if (c < n) num_out[c] = acc;
 }
 
-// RESIDENT = true: the codes stay in registers (m <= 2016).  RESIDENT = false: any m; the codes of the next
-// round are fetched one round ahead into one of two register sets (16-bit codes: half the bytes of the
-// streaming similarity_pc_kernel), everything else is shared.
-template <bool DIAG, bool RESIDENT>
-__device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, const uint4 *__restrict__ codes16, int m,
+// RESIDENT = true: the codes stay in registers (m <= 4032).  RESIDENT = false: any m; the codes are fetched two
+// rounds ahead into three rotating register sets (16 B per lane and round: a quarter of the bytes of the streaming
+// similarity_pc_kernel), everything else is shared.
+template <bool DIAG, int RM>  // RM = resident rounds (18 or 36), 0 = streaming codes
+__device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, const uint2 *__restrict__ codes8, int m,
                                             int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
                                             int c, int R, int pad, int rounds) {
     const float *master = reinterpret_cast<const float *>(smem);
-    unsigned char *slices = smem + NK_SLICES_OFF;
     float4 *ring = reinterpret_cast<float4 *>(smem + NK_RING_OFF);
     const int G8 = (m + 7) >> 3;
-    const uint4 *col = codes16 + c;
+    const uint2 *col = codes8 + c;
+    constexpr bool RESIDENT = RM > 0;
 
-    auto fetch_codes = [&](uint4 (&u)[NK_OCTS], int q) {  // row G8 of the array is all-skipped
-#pragma unroll
-        for (int t = 0; t < NK_OCTS; ++t) {
-            const int g = q * NK_ROUND_OCTS + P * NK_OCTS + t;
-            u[t] = col[(size_t)(g >= G8 ? G8 : g) * ld];
-        }
+    auto fetch_codes = [&](uint4 &u, int q) {  // one uint4 = the 16 codes of this producer's round; row G8 is all-skipped
+        const int g0 = q * NK_ROUND_OCTS + P * NK_OCTS, g1 = g0 + 1;
+        const uint2 lo = col[(size_t)(g0 >= G8 ? G8 : g0) * ld], hi = col[(size_t)(g1 >= G8 ? G8 : g1) * ld];
+        u = make_uint4(lo.x, lo.y, hi.x, hi.y);
     };
-    uint4 cod[RESIDENT ? NK_RMAX : 3][NK_OCTS];  // this producer's codes: all of them, or three rounds' worth
+    uint4 cod[RESIDENT ? RM : 3];  // this producer's codes: all of them, or three rounds' worth
     if (RESIDENT) {
 #pragma unroll
-        for (int q = 0; q < NK_RMAX; ++q) fetch_codes(cod[q], q);
+        for (int q = 0; q < (RESIDENT ? RM : 3); ++q) fetch_codes(cod[q], q);
     }
-    auto load_cj = [&](int jn) -> uint32_t {
-        if (jn >= m - 1) return (uint32_t)npos << 8;
-        const uint16_t *cj = reinterpret_cast<const uint16_t *>(col + (size_t)(jn >> 3) * ld);
-        return cj[jn & 7];
+    auto load_cj = [&](int jn) -> uint32_t {  // table row of this lane's residue in row jn
+        if (jn >= m - 1) return (uint32_t)npos;
+        const uint8_t *cj = reinterpret_cast<const uint8_t *>(col + (size_t)(jn >> 3) * ld);
+        return (uint32_t)cj[jn & 7] - (uint32_t)NK_K;
     };
-    auto refresh = [&](int jn, uint32_t cjcode) {
-        const uint32_t idx = cjcode >> 8;
-        float *sl = reinterpret_cast<float *>(slices + (jn & 1) * NK_SLICE_STRIDE) + lane;
+    auto refresh = [&](int jn, uint32_t idx) {
+        float *sl = reinterpret_cast<float *>(smem + ((jn & 1) ? NK_SLICE1_OFF : NK_SLICE0_OFF)) + lane;
         const float *mrow = master + idx * 32;
         for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
     };
@@ -1063,7 +1065,12 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     }
     // One round: cq = this round's codes; wsrc_next = W source of the next round; last_of_row: the table slice of
     // row j+1 is staged at the end; prefetch(): further loads for the next round, issued after the wait.
-    auto round_work = [&](const uint4 (&cq)[NK_OCTS], int j, const float *wsrc_next, bool last_of_row,
+    // v_perm_b32 selectors {lane.b3, lane.b2, code.b[k], lane.b0}, kept in VGPRs (as SGPR constants they
+    // get spilled to VGPR lanes and cost a v_readlane each per round)
+    uint32_t selv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(selv[k]) : "s"(0x03020400u + ((uint32_t)k << 8)));
+    auto round_work = [&](const uint4 &cq, int j, const float *wsrc_next, bool last_of_row,
                           auto &&prefetch) __attribute__((always_inline)) {
         // This round's W (DMA'd a round ago) has landed.  When streaming, the two code loads of the NEXT round,
         // issued after that DMA, may still be in flight (vmcnt counts in order).
@@ -1073,21 +1080,16 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         // (the instruction's immediate offset would also move the LDS address: the source is a full pointer)
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(wsrc_next) : "m0", "memory");
         prefetch();
-        const uint32_t vbase = (uint32_t)(NK_SLICES_OFF + (j & 1) * NK_SLICE_STRIDE);
+        // address bytes: [lane * 4][code][row parity][0]
+        const uint32_t vlane = (uint32_t)lane * 4u + ((uint32_t)(j & 1) << 16);
+        const uint32_t cw[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
-        for (int t = 0; t < NK_OCTS; ++t) {
-            const uint32_t cw[4] = {cq[t].x, cq[t].y, cq[t].z, cq[t].w};
+        for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                uint32_t a0, a1;
-                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-                    : "=v"(a0) : "v"(vbase), "v"(cw[s4]));
-                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-                    : "=v"(a1) : "v"(vbase), "v"(cw[s4]));
-                asm volatile("ds_read_b32 %0, %1" : "=v"(tv[t][2 * s4]) : "v"(a0));
-                asm volatile("ds_read_b32 %0, %1" : "=v"(tv[t][2 * s4 + 1]) : "v"(a1));
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t addr = __builtin_amdgcn_perm(cw[d], vlane, selv[k]);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(tv[d >> 1][(d & 1) * 4 + k]) : "v"(addr));
             }
-        }
         const uint32_t waddr = wstage_base + (uint32_t)(r & 1) * 256u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1136,7 +1138,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         for (int jj = 0; jj < nrows; ++jj) {
             const int q0 = q0_of(jj);
             const float *wrow = wrow_of(jj);
-            nk_unroll<0>([&](auto qc) __attribute__((always_inline)) {
+            nk_unroll<0, RM>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int Q = decltype(qc)::value;
                 if (Q >= q0 && Q < R) {
                     const bool last = Q == R - 1;
@@ -1149,7 +1151,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     } else {
         // (row, round) sequence: row jj runs rounds q0(jj) .. R-1.  Codes are fetched TWO rounds ahead (an L2
         // miss takes longer than a round) into three rotating register sets.
-        static_assert(NK_OCTS == 2, "the vmcnt(2) above counts the two code loads of a round");
+        static_assert(NK_OCTS == 2, "the vmcnt(2) above counts the two 8-byte code loads of a round");
         struct Pos {
             int j, q;
         };
@@ -1159,7 +1161,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         fetch_codes(cod[0], pos.q);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // order: [codes(0)] [W(0) DMA above] -> then codes(1) is the young pair
         fetch_codes(cod[1], pos1.q);
-        auto step = [&](const uint4 (&cur)[NK_OCTS], uint4 (&far)[NK_OCTS]) __attribute__((always_inline)) {
+        auto step = [&](const uint4 &cur, uint4 &far) __attribute__((always_inline)) {
             const Pos pos2 = next(pos1);
             const float *wsrc_next = wrow_of(pos1.j) + pos1.q * (NK_ROUND_OCTS * 8);
             round_work(cur, pos.j, wsrc_next, pos.q == R - 1, [&] { fetch_codes(far, pos2.q); });
@@ -1178,9 +1180,9 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     sim_barrier();  // the consumer's drain round
 }
 
-template <bool DIAG, bool RESIDENT>
+template <bool DIAG, int RM>
 __global__ __launch_bounds__(512) void similarity_num_kernel(
-    const uint4 *__restrict__ codes16, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
+    const uint2 *__restrict__ codes8, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, int R, int pad, int rounds, float *__restrict__ num_out, int tcols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
@@ -1196,7 +1198,7 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
     if (wave != 0) {
         // the chain wave has slack every round; the producer that shares its SIMD does not
         __builtin_amdgcn_s_setprio(2);
-        if (active) nk_producer<DIAG, RESIDENT>(wave - 1, smem, codes16, m, ld, wmat, ldw, npos, lane, c, R, pad, rounds);
+        if (active) nk_producer<DIAG, RM>(wave - 1, smem, codes8, m, ld, wmat, ldw, npos, lane, c, R, pad, rounds);
     } else if (active) {
         nk_consumer<DIAG>(smem, rounds, lane, c, n, num_out);
     }
@@ -1468,13 +1470,8 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
     }
 }
 
-void launch_sim_encode16(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                         const int32_t *gaps_w, void *codes16, unsigned long long *err_key, int tcols, bool num_only) {
-    dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
-    // table slice entry stride / lane stride: 512 / 8 B for {D, valid} pairs, 256 / 4 B for the D-only slices
-    sim_encode16_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes16),
-                                             err_key, tcols, num_only ? 8 : 9, num_only ? 2 : 3);
-}
+void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
+                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key);
 
 // Columns per similarity workgroup: a full wave.  The kernel's time is (pair steps) x (cycles per step)
 // whatever the column count, and the LDS time per instruction does not depend on the active lanes, so
@@ -1533,7 +1530,14 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
 // the numerator kernel keeps every producer's codes in its registers: that bounds the row count
 bool similarity_rc_fits(int m) { return (m + 7) / 8 <= NK_RMAX * NK_ROUND_OCTS; }
 
-int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int64_t ld, const float *wmat, int ldw,
+void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
+                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key) {
+    dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
+    sim_encode8_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint2 *>(codes8), err_key,
+                                            NK_K);
+}
+
+int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64_t ld, const float *wmat, int ldw,
                           const void *tab, int npos, float *num_out, int tcols) {
     const int G8 = (m + 7) / 8;
     const int R = (G8 + NK_ROUND_OCTS - 1) / NK_ROUND_OCTS;
@@ -1544,13 +1548,16 @@ int launch_similarity_num(hipStream_t s, const void *codes16, int m, int n, int6
     // the request is rounded up to the denominator kernel's: no two chain workgroups -- of this launch, of
     // the denominator kernel or of another context's launches -- ever share a CU (and so a SIMD)
     const int lds = nk_lds_bytes() > DEN_LDS_BYTES ? nk_lds_bytes() : DEN_LDS_BYTES;
-    const bool resident = similarity_rc_fits(m);
-    auto kern = (sim_debug_mode() & 64) ? (resident ? similarity_num_kernel<true, true> : similarity_num_kernel<true, false>)
-                                        : (resident ? similarity_num_kernel<false, true> : similarity_num_kernel<false, false>);
+    const int octs = (m + 7) / 8;
+    const int rm = octs <= 18 * NK_ROUND_OCTS ? 18 : (octs <= NK_RMAX * NK_ROUND_OCTS ? NK_RMAX : 0);
+    const bool diag = (sim_debug_mode() & 64) != 0;
+    auto kern = rm == 18 ? (diag ? similarity_num_kernel<true, 18> : similarity_num_kernel<false, 18>)
+              : rm == 0 ? (diag ? similarity_num_kernel<true, 0> : similarity_num_kernel<false, 0>)
+                        : (diag ? similarity_num_kernel<true, NK_RMAX> : similarity_num_kernel<false, NK_RMAX>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
-        reinterpret_cast<const uint4 *>(codes16), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, R, pad,
+        reinterpret_cast<const uint2 *>(codes8), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, R, pad,
         (int)rounds, num_out, tcols);
     return 0;
 }

@@ -288,7 +288,7 @@ def test_similarity_narrow_column_tiles(ctx, monkeypatch, kernel, tcols):
 
 @pytest.mark.parametrize("kernel", ["", "pc"])
 def test_similarity_above_resident_limit(ctx, monkeypatch, kernel):
-    """m > 2016: the codes no longer fit the producers' registers; the numerator kernel streams them."""
+    """m > 2016: second instantiation of the numerator kernel; also the single-chain kernel at that size."""
     if kernel:
         monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
     else:
@@ -296,9 +296,16 @@ def test_similarity_above_resident_limit(ctx, monkeypatch, kernel):
     _sim_parity(ctx, synth_msa(2100, 72, 77))
 
 
-def test_similarity_streaming_numerator_odd_rows(ctx, monkeypatch):
+def test_similarity_36_round_resident_kernel(ctx, monkeypatch):
+    """2016 < m <= 4032: the 36-round instantiation of the resident numerator kernel."""
     monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     _sim_parity(ctx, synth_msa(2017, 33, 79))
+
+
+def test_similarity_streaming_numerator(ctx, monkeypatch):
+    """m > 4032: the codes no longer fit the producers' registers and are streamed two rounds ahead."""
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(4040, 20, 80))
 
 
 def test_similarity_at_resident_limit(ctx, monkeypatch):
