@@ -217,12 +217,13 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
 // symmetric matrix is read column-wise so that loads coalesce.
 // ------------------------------------------------------------------------------------------
 // The sums are short sequential float32 chains (m adds per row); what costs time is feeding
-// them.  Four waves stage [256 rows j][64 columns i] tiles of the symmetric matrix through LDS
-// (every wave loads, so 4x the memory-level parallelism of the chain wave alone), wave 0 walks
-// each tile in ascending j.
+// them.  Eight waves stage [128 rows j][64 columns i] tiles of the symmetric matrix through LDS,
+// each with its 16 loads of a tile in flight at once (the kernel is bound by memory latency: only
+// m/64 workgroups exist), wave 0 walks each tile in ascending j.
 constexpr int IDS_TJ = 128;
+constexpr int IDS_WAVES = 8;
 
-__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+__global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
                                                             float *__restrict__ row_avg, float *__restrict__ row_max) {
     __shared__ float tile[2][IDS_TJ][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,11 +232,14 @@ __global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restr
     const int ntiles = (m + IDS_TJ - 1) / IDS_TJ;
     auto load_tile = [&](int t, int buf) {
         const int jb = t * IDS_TJ;
-#pragma unroll 8
-        for (int r = wave; r < IDS_TJ; r += 4) {
-            const int j = jb + r;
-            tile[buf][r][lane] = (j < m) ? ident[(size_t)j * ldw + i] : 0.0f;  // ident[j][i] == ident[i][j]
+        float v[IDS_TJ / IDS_WAVES];
+#pragma unroll
+        for (int u = 0; u < IDS_TJ / IDS_WAVES; ++u) {
+            const int j = jb + wave + u * IDS_WAVES;
+            v[u] = (j < m) ? ident[(size_t)j * ldw + i] : 0.0f;  // ident[j][i] == ident[i][j]
         }
+#pragma unroll
+        for (int u = 0; u < IDS_TJ / IDS_WAVES; ++u) tile[buf][wave + u * IDS_WAVES][lane] = v[u];
     };
     float mx = 0.0f, avg = 0.0f;
     load_tile(0, 0);
@@ -1462,7 +1466,7 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2) {
-    identity_rows_kernel<<<(m + 63) / 64, 256, 0, s>>>(ident, m, ldw, row_avg, row_max);
+    identity_rows_kernel<<<(m + 63) / 64, 64 * IDS_WAVES, 0, s>>>(ident, m, ldw, row_avg, row_max);
     if ((size_t)m * 8 <= 64 * 1024) {
         identity_final_kernel<<<1, 256, (size_t)m * 8, s>>>(row_avg, row_max, m, out2);
     } else {
