@@ -191,7 +191,7 @@ int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
     c->indet = indet;
     c->nchunk = (n + 31) / 32;
     // + 20: the denominator kernel reads the validity plane one 20-row group past the last row (zeros)
-    c->m_pad = round_up(std::max(m, 1) + 20, 64 * msak::PAIR_TJ);
+    c->m_pad = round_up(std::max(m, 1) + 20, 128);
     c->ldw = round_up(std::max(m, 1), 64);
     invalidate(c);
     return MSA_OK;

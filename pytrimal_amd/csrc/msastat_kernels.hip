@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------
 // pair_counts: hit/dst of every sequence pair (Cleaner::calculateSeqIdentity ==
 // Similarity::calculateMatrixIdentity integers).  One wave = TI rows "i" (wave-uniform, read
-// through the scalar cache, used as SGPR operands) x 64*TJ rows "j" (TJ per lane); per 32
+// through the scalar cache, used as SGPR operands) x 64*TJ rows "j" (TJ per lane; TJ = 1 in production:
+// the kernel is short of waves, not of reuse); per 32
 // columns and pair: 7 xor/or (v_or3 / v_bitop3 fuse most of them) + and-not + 2 bcnt + or.
 // Integer work, any order is exact.
 // ------------------------------------------------------------------------------------------
@@ -1459,9 +1460,17 @@ void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
                         uint32_t *dst, float *ident, float *wmat) {
-    constexpr int TI = PAIR_TI, TJ = PAIR_TJ;
-    dim3 grid((m + TI - 1) / TI, m_pad / (64 * TJ));
-    pair_counts_kernel<TI, TJ><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+    // Two rows "j" per lane reuse the wave-uniform "i" words twice, but halve the number of waves: worth it only
+    // once the upper triangle still holds several waves per SIMD (m >= ~3000); m_pad is a multiple of 128.
+    constexpr int TI = PAIR_TI;
+    const long waves2 = (long)((m + TI - 1) / TI) * (m_pad / 128) / 2;
+    if (waves2 >= 8192) {
+        dim3 grid((m + TI - 1) / TI, m_pad / 128);
+        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+    } else {
+        dim3 grid((m + TI - 1) / TI, m_pad / 64);
+        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+    }
 }
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
