@@ -151,6 +151,22 @@ def main():
                         "denominator kernels side by side); bound by per-wave issue rate and LDS latency, not HBM "
                         "(DESIGN.md section 5)",
             }
+        # The similarity kernels are two dependent-add chains of m(m-1)/2 steps per column: their own yardstick is
+        # cycles per pair step against the issue floor of a lone wave, not bytes.
+        chain = None
+        if "simnum" in kernels and "simden" in kernels:
+            steps = m * (m - 1) // 2
+            clock_ghz = 2.4  # MI355X peak engine clock
+            chain = {
+                "pair_steps_per_column": steps,
+                "numerator": {"ns_per_step": round(kernels["simnum"]["ms_avg"] * 1e6 / steps, 3),
+                              "cycles_per_step_at_2.4GHz": round(kernels["simnum"]["ms_avg"] * 1e6 / steps * clock_ghz, 2),
+                              "floor_cycles_per_step": 4.3, "floor": "one dependent v_add_f32 per step"},
+                "denominator": {"ns_per_step": round(kernels["simden"]["ms_avg"] * 1e6 / steps, 3),
+                                "cycles_per_step_at_2.4GHz": round(kernels["simden"]["ms_avg"] * 1e6 / steps * clock_ghz, 2),
+                                "floor_cycles_per_step": 10.8,
+                                "floor": "s_and_b32 into EXEC + v_add_f32 per step, measured in isolation"},
+            }
         roofline_all = {}
         for kname, kv in kernels.items():
             if kname in ("overlap", "cluster"):
@@ -180,6 +196,7 @@ def main():
             },
             "roofline": roofline,
             "roofline_all_kernels": roofline_all,
+            "chain_latency": chain,
             "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in kernels.items()},
         }
         if not args.no_cpu_baseline and world == 1:
