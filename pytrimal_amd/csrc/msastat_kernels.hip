@@ -774,8 +774,11 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
     uint32_t vnext = __builtin_amdgcn_readfirstlane(masks[0]);
     for (int j = 0; j + 1 < m; ++j) {
         const uint32_t vj = vnext;
-        vnext = __builtin_amdgcn_readfirstlane(masks[j + 1]);
-        if (vj == 0u) continue;  // no column of this chunk has a residue in row j
+        const uint32_t *mnext = masks + j + 1;
+        if (vj == 0u) {  // no column of this chunk has a residue in row j
+            vnext = __builtin_amdgcn_readfirstlane(*mnext);
+            continue;
+        }
         const int k0 = (j + 1) / G * G;
         const int ng = (mend - k0) / G;  // >= 1 groups
         n_steps += (unsigned long long)ng * G;
@@ -788,7 +791,8 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
         asm volatile(
             "s_mov_b64 s[10:11], exec\n\t"
             "s_mov_b32 exec_hi, 0\n\t"
-            "s_mov_b32 s8, %1\n\ts_sub_u32 s9, %2, 1\n\ts_mov_b64 s[12:13], %3\n\ts_mov_b64 s[14:15], %4\n\ts_mov_b32 s30, 0\n\t"
+            "s_mov_b32 s8, %2\n\ts_sub_u32 s9, %3, 1\n\ts_mov_b64 s[12:13], %4\n\ts_mov_b64 s[14:15], %5\n\ts_mov_b32 s30, 0\n\t"
+            "s_load_dword %1, %6, 0x0\n\t"  // V(j+1): a vector load + readfirstlane here costs a memory round trip per row
             "s_load_dwordx16 s[36:51], s[12:13], s30\n\ts_load_dwordx16 s[52:67], s[14:15], s30\n\t"
             "1:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -833,8 +837,8 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             "2:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 exec, s[10:11]"
-            : "+v"(den)
-            : "s"(vj), "s"(ng), "s"(mp), "s"(wp)
+            : "+v"(den), "=&s"(vnext)
+            : "s"(vj), "s"(ng), "s"(mp), "s"(wp), "s"(mnext)
             : "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s30", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "scc", "memory");
     }
     if (lane == 0) {  // diagnostics (tools/sim_modes.py)

@@ -311,3 +311,31 @@ def test_similarity_streaming_numerator(ctx, monkeypatch):
 def test_similarity_at_resident_limit(ctx, monkeypatch):
     monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     _sim_parity(ctx, synth_msa(2016, 40, 78))
+
+
+def _random_case(seed):
+    """Small random alignments with extreme compositions: very gappy / fully gapped rows and columns,
+    identical rows, indeterminations, lower case."""
+    r = np.random.default_rng(seed)
+    m = int(r.integers(2, 48))
+    n = int(r.integers(1, 140))
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    a = alpha[r.integers(0, 20, (m, n))].copy()
+    gap_rate = float(r.choice([0.0, 0.1, 0.5, 0.9]))
+    a[r.random((m, n)) < gap_rate] = ord("-")
+    a[r.random((m, n)) < 0.03] = ord("X")
+    if r.random() < 0.5:
+        a[int(r.integers(0, m)), :] = ord("-")                 # a sequence of gaps only
+    if r.random() < 0.5:
+        a[:, int(r.integers(0, n))] = ord("-")                 # an all-gap column
+    if r.random() < 0.5 and m > 2:
+        a[int(r.integers(1, m)), :] = a[0, :]                  # duplicated sequence
+    if r.random() < 0.3:
+        low = r.random((m, n)) < 0.2
+        a[low & (a >= 65) & (a <= 90)] += 32                   # lower-case residues
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_small_alignments(ctx, seed):
+    all_stats(ctx, _random_case(9000 + seed))
