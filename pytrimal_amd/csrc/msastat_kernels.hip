@@ -754,7 +754,7 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
 // ~24 cycles of issue).  Rows start at the 16-aligned k below j+1 and end at the 16-aligned k above m:
 // W is strictly upper triangular and zero-padded, so the extra steps add +0.
 // ------------------------------------------------------------------------------------------
-constexpr int DEN_WAVES = 4;             // chunks per workgroup at most, one per SIMD
+constexpr int DEN_WAVES = 8;             // chunks per workgroup at most (default 4: one per SIMD)
 constexpr int DEN_GROUP = 16;            // pair steps per SGPR buffer of the denominator loop
 constexpr int DEN_LDS_BYTES = 96 * 1024;  // never touched: keeps a numerator workgroup off this CU (see below)
 __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t *__restrict__ planes, int nchunk,
@@ -863,7 +863,7 @@ int sim_den_waves(int m) {
     }
     const long mask_bytes = 4L * (m + 64);
     const long w = (36 * 1024) / mask_bytes;
-    return (int)(w < 1 ? 1 : (w > DEN_WAVES ? DEN_WAVES : w));
+    return (int)(w < 1 ? 1 : (w > 4 ? 4 : w));
 }
 int sim_den_workgroups(int nchunk, int m) {
     const int w = sim_den_waves(m);
