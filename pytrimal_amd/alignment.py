@@ -244,16 +244,18 @@ class Alignment:
                 raise TypeError(f"{ty!r} object is not open in binary mode.")
             fmt = format
         if fmt is None:
-            head = data.lstrip()[:7].upper()
-            fmt = "clustal" if head.startswith(b"CLUSTAL") else "fasta"
+            fmt = _sniff_format(data)
         fmt = fmt.lower()
         if fmt == "fasta":
             fast = _load_fasta_native(cls, data, file)
             if fast is not None:
                 return fast
             names, seqs = _parse_fasta(data)
-        elif fmt == "clustal":
-            names, seqs = _parse_clustal(data)
+        elif fmt in _PARSERS:
+            try:
+                names, seqs = _PARSERS[fmt](data)
+            except (ValueError, IndexError) as err:
+                raise RuntimeError(f"Failed to recognize format {format!r} in {file!r}") from err
         else:
             raise ValueError(f"Unknown alignment format: {format!r}")
         if not names:
@@ -445,6 +447,127 @@ def _parse_fasta(data):
     return names, [b"".join(s) for s in seqs]
 
 
+def _sniff_format(data):
+    """Content-based format detection, the role of trimAl's FormatManager::CheckAlignment chain
+    (format_handling.pxd:11-32) for the formats of the reference's own loader tests."""
+    head = data.lstrip()
+    up = head[:8].upper()
+    if up.startswith(b"CLUSTAL"):
+        return "clustal"
+    if up.startswith(b"#NEXUS"):
+        return "nexus"
+    if head[:1] == b">":
+        return "pir" if len(head) > 3 and head[3:4] == b";" and head[1:3].isalnum() else "fasta"
+    first = head.split(b"\n", 1)[0].split()
+    if len(first) == 2 and first[0].isdigit() and first[1].isdigit():
+        try:
+            _parse_phylip(data)
+            return "phylip"
+        except (ValueError, IndexError):
+            return "phylip32"
+    return "fasta"
+
+
+def _phylip_header(lines):
+    for k, line in enumerate(lines):
+        parts = line.split()
+        if parts:
+            if len(parts) < 2 or not (parts[0].isdigit() and parts[1].isdigit()):
+                raise ValueError("not a PHYLIP header")
+            return int(parts[0]), int(parts[1]), k + 1
+    raise ValueError("empty file")
+
+
+def _parse_phylip(data):
+    """PHYLIP 4.0, interleaved: the first block carries the names, later blocks residues only."""
+    lines = data.splitlines()
+    m, n, at = _phylip_header(lines)
+    body = [ln for ln in lines[at:] if ln.strip()]
+    if m == 0 or len(body) % m:
+        raise ValueError("interleaved PHYLIP needs a multiple of the sequence count of lines")
+    names, seqs = [], [[] for _ in range(m)]
+    for k, line in enumerate(body):
+        parts = line.split()
+        if k < m:
+            names.append(parts[0])
+            parts = parts[1:]
+        seqs[k % m].append(b"".join(parts))
+    out = [b"".join(x) for x in seqs]
+    if any(len(x) != n for x in out):
+        raise ValueError("sequence lengths do not match the PHYLIP header")
+    return names, out
+
+
+def _parse_phylip32(data):
+    """PHYLIP 3.2, sequential: each sequence (name first) runs on until it has its residues."""
+    lines = data.splitlines()
+    m, n, at = _phylip_header(lines)
+    tokens = [ln.split() for ln in lines[at:] if ln.strip()]
+    names, out, k = [], [], 0
+    for _ in range(m):
+        names.append(tokens[k][0])
+        got = [b"".join(tokens[k][1:])]
+        k += 1
+        while sum(map(len, got)) < n:
+            got.append(b"".join(tokens[k]))
+            k += 1
+        out.append(b"".join(got))
+    if any(len(x) != n for x in out):
+        raise ValueError("sequence lengths do not match the PHYLIP header")
+    return names, out
+
+
+def _parse_nexus(data):
+    """NEXUS data block: the (possibly interleaved) MATRIX up to the closing ';'."""
+    import re
+
+    text = re.sub(rb"\[[^\]]*\]", b"", data)  # [comments]
+    lines = text.splitlines()
+    start = next(k for k, ln in enumerate(lines) if ln.strip().upper() == b"MATRIX")
+    names, seqs = [], {}
+    for line in lines[start + 1:]:
+        stripped = line.strip()
+        if stripped.startswith(b";"):
+            break
+        parts = stripped.rstrip(b";").split()
+        if len(parts) < 2:
+            if stripped.endswith(b";"):
+                break
+            continue
+        if parts[0] not in seqs:
+            names.append(parts[0])
+            seqs[parts[0]] = []
+        seqs[parts[0]].append(b"".join(parts[1:]))
+        if stripped.endswith(b";"):
+            break
+    if not names:
+        raise ValueError("empty NEXUS matrix")
+    return names, [b"".join(seqs[k]) for k in names]
+
+
+def _parse_pir(data):
+    """NBRF/PIR: '>P1;name', a description line, residues up to '*'."""
+    names, seqs = [], []
+    lines = iter(data.splitlines())
+    for line in lines:
+        line = line.strip()
+        if not line.startswith(b">"):
+            continue
+        names.append(line.split(b";", 1)[1].split()[0] if b";" in line else line[1:].split()[0])
+        next(lines, None)  # description
+        chunks = []
+        for body in lines:
+            body = body.strip()
+            done = body.endswith(b"*")
+            chunks.append(body.rstrip(b"*").replace(b" ", b""))
+            if done:
+                break
+        seqs.append(b"".join(chunks))
+    if not names:
+        raise ValueError("no PIR records")
+    return names, seqs
+
+
 def _parse_clustal(data):
     names, seqs = [], {}
     lines = data.splitlines()
@@ -459,3 +582,7 @@ def _parse_clustal(data):
             seqs[parts[0]] = []
         seqs[parts[0]].append(parts[1])
     return names, [b"".join(seqs[k]) for k in names]
+
+
+_PARSERS = {"clustal": _parse_clustal, "phylip": _parse_phylip, "phylip40": _parse_phylip, "phylip32": _parse_phylip32,
+            "nexus": _parse_nexus, "pir": _parse_pir, "nbrf": _parse_pir}

@@ -275,3 +275,57 @@ def test_native_fasta_ingest_errors(text, message):
     assert str(fast.value) == str(slow.value) == message
     with pytest.raises(RuntimeError):
         Alignment.load(io.BytesIO(b"no records here\n"), "fasta")
+
+
+# --- the other formats of the reference's loader tests (tests/test_alignment.py:186-215): written here by small
+# --- formatters from the docstring example, read back explicitly and by content sniffing
+
+
+def _chunks(seq, k=10):
+    return " ".join(seq[i:i + k] for i in range(0, len(seq), k))
+
+
+def _format_sample(fmt):
+    names = [n.decode() for n in EXAMPLE_001_NAMES]
+    seqs = list(EXAMPLE_001)
+    m, n = len(seqs), len(seqs[0])
+    if fmt == "phylip":  # 4.0, interleaved in two blocks
+        half = 30
+        out = [f" {m} {n}"] + [f"{nm:<12} {s[:half]}" for nm, s in zip(names, seqs)] + [""]
+        out += [s[half:] for s in seqs] + [""]
+    elif fmt == "phylip32":  # 3.2, sequential
+        out = [f" {m} {n}"]
+        for nm, s in zip(names, seqs):
+            out += [f"{nm:<12} {_chunks(s[:30])}", f"             {_chunks(s[30:])}", ""]
+    elif fmt == "nexus":
+        out = ["#NEXUS", "BEGIN DATA;", f" DIMENSIONS NTAX={m} NCHAR={n};", "FORMAT DATATYPE=PROTEIN INTERLEAVE=yes GAP=-;"]
+        out += [f"[Name: {nm:<8} Len: {n}]" for nm in names] + ["", "MATRIX"]
+        out += [f"{nm:<8} {_chunks(s)}" for nm, s in zip(names, seqs)] + ["", ";", "END;", ""]
+    elif fmt == "pir":
+        out = []
+        for nm, s in zip(names, seqs):
+            out += [f">P1;{nm}", f"sample record {nm}", f"  {_chunks(s)}*", ""]
+    elif fmt == "clustal":
+        out = ["CLUSTAL W multiple sequence alignment", "", ""] + [f"{nm:<16}{s}" for nm, s in zip(names, seqs)] + [" " * 16 + "*" * 3, ""]
+    else:
+        out = [x for nm, s in zip(names, seqs) for x in (f">{nm}", s)]
+    return ("\n".join(out) + "\n").encode()
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "clustal", "phylip", "phylip32", "nexus", "pir"])
+def test_load_formats(tmp_path, fmt):
+    text = _format_sample(fmt)
+    ali = Alignment.load(io.BytesIO(text), fmt)
+    assert ali.names == list(EXAMPLE_001_NAMES)
+    assert list(ali.sequences) == list(EXAMPLE_001)
+    path = tmp_path / f"sample.{fmt}"
+    path.write_bytes(text)
+    sniffed = Alignment.load(str(path))  # format detected from the content
+    assert sniffed.names == ali.names and list(sniffed.sequences) == list(ali.sequences)
+
+
+def test_load_unknown_format_and_garbage():
+    with pytest.raises(ValueError):
+        Alignment.load(io.BytesIO(b">a\nAC\n"), "stockholm")
+    with pytest.raises(RuntimeError):
+        Alignment.load(io.BytesIO(b" 2 4\nonly-one-line\n"), "phylip")
