@@ -95,7 +95,7 @@ struct msa_ctx {
     DevBuf<float> ident, wmat;
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
-    DevBuf<float> row_avg, row_max, stats2;
+    DevBuf<float> row_avg, row_max, row_min, stats2;
     DevBuf<uint32_t> codes16;  // [G8 + 1][ld] x 16 B
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
@@ -577,6 +577,81 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     return MSA_OK;
 }
 
+// RepresentativeTrimmer(clusters=K): Cleaner::getCutPointClusters bisects the identity threshold until the greedy
+// clustering yields K clusters.  Start value and bounds come from the row statistics (the start value is the
+// selectMethod mean, same order of operations), every probe is one run of the device clustering: no m*m transfer.
+int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
+    const int m = c->m;
+    if (m < 2 || clusters < 1) return MSA_E_INVALID;
+    // below ~2000 sequences the m*m copy (< 16 MB) is cheaper than a synchronisation per probe: host path
+    if (m < 2000 && !getenv("MSA_DEVICE_CLUSTERS")) return MSA_E_INVALID;
+    int rc = run_pairs(c, true, false, false);
+    if (rc) return rc;
+    const size_t words = msak::cluster_adj_words(m);
+    if ((size_t)4 * words * sizeof(uint32_t) > 60 * 1024) return MSA_E_INVALID;  // host path
+    HIPCHK(c, c->row_avg.reserve(m + 64));
+    HIPCHK(c, c->row_max.reserve(m + 64));
+    HIPCHK(c, c->row_min.reserve(m + 64));
+    HIPCHK(c, c->stats2.reserve(2));
+    {
+        ProfScope ps(c, "idstats");
+        msak::launch_identity_stats(c->stream, c->ident.p, m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p, c->row_min.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->h_f32.reserve((size_t)2 * m + 8));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->stats2.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + 2, c->row_max.p, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + 2 + m, c->row_min.p, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> lengths;
+    rc = row_digest(c, lengths, nullptr);  // synchronises the stream
+    if (rc) return rc;
+    float threshold = c->h_f32.p[0], hi = 0, lo = 1;
+    for (int i = 0; i < m; ++i) {
+        hi = std::max(hi, c->h_f32.p[2 + i]);
+        lo = std::min(lo, c->h_f32.p[2 + m + i]);
+    }
+    if (clusters == m) threshold = 1;
+    if (clusters == 1) threshold = 0;
+    const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
+    HIPCHK(c, c->pairs.reserve((size_t)m + 64));
+    HIPCHK(c, c->col_ok.reserve((size_t)m * words + 64));
+    HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
+    HIPCHK(c, c->equal.reserve(4));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    std::memcpy(c->h_i32.p, seq_at.data(), sizeof(int32_t) * m);
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+    float previous = 0, stalled = 0;
+    for (;;) {
+        HIPCHK(c, hipMemsetAsync(c->equal.p, 0, sizeof(int32_t), c->stream));
+        {
+            ProfScope ps(c, "cluster");
+            if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, threshold, c->col_ok.p,
+                                     c->keep_seq_d.p, c->equal.p) != 0)
+                return MSA_E_INVALID;
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->equal.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int count = c->h_i32.p[0];
+        if (clusters == m || clusters == 1) break;  // the bounds of getCutPointClusters: no search
+        if (count == clusters || stalled > 10) break;
+        if (count > clusters) hi = threshold;
+        else lo = threshold;
+        threshold = (hi + lo) / 2;
+        if (previous != count) {
+            stalled = 0;
+            previous = static_cast<float>(count);
+        } else {
+            ++stalled;
+        }
+    }
+    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
+    HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(keep_seq, c->h_u8.p, m);
+    return MSA_OK;
+}
+
 int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of the identity matrix
     int rc = run_pairs(c, true, false, false);
     if (rc) return rc;
@@ -645,7 +720,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
-    c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release();
+    c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->codes16.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
@@ -854,9 +929,12 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     } else if (p->max_identity != -1 && p->clusters == -1 && device_representatives(c, p->max_identity, keep_seq) == MSA_OK) {
         // RepresentativeTrimmer(identity_threshold): clustered on the device, only the mask comes back
         seq_mode = true;
+    } else if (p->clusters != -1 && device_cluster_count(c, p->clusters, keep_seq) == MSA_OK) {
+        // RepresentativeTrimmer(clusters=K): the threshold search probes the device clustering
+        seq_mode = true;
     } else if (p->clusters != -1 || p->max_identity != -1) {
-        // clusters=K (bisection over thresholds) or very large m: the m*m identities come to the
-        // host for the greedy clustering
+        // very large m (the bit sets of the clustering no longer fit the LDS): the m*m identities come to
+        // the host for the greedy clustering
         std::vector<float> ident;
         rc = fetch_ident(c, ident);
         if (rc) return rc;

@@ -225,7 +225,9 @@ constexpr int IDS_TJ = 128;
 constexpr int IDS_WAVES = 8;
 
 __global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
-                                                            float *__restrict__ row_avg, float *__restrict__ row_max) {
+                                                                       float *__restrict__ row_avg,
+                                                                       float *__restrict__ row_max,
+                                                                       float *__restrict__ row_min) {
     __shared__ float tile[2][IDS_TJ][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.x * 64;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const flo
 #pragma unroll
         for (int u = 0; u < IDS_TJ / IDS_WAVES; ++u) tile[buf][wave + u * IDS_WAVES][lane] = v[u];
     };
-    float mx = 0.0f, avg = 0.0f;
+    float mx = 0.0f, avg = 0.0f, mn = 1.0f;  // (getCutPointClusters starts its minimum at 1)
     load_tile(0, 0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const flo
                 const float v = tile[t & 1][r][lane];
                 if (jb + r != i) {
                     mx = mx < v ? v : mx;
+                    mn = mn > v ? v : mn;
                     avg += v;
                 }
             }
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const flo
     if (wave == 0 && i < m) {
         row_avg[i] = avg / (float)(m - 1);
         row_max[i] = mx;
+        if (row_min) row_min[i] = mn;
     }
 }
 
@@ -1478,8 +1482,8 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
 }
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
-                           float *out2) {
-    identity_rows_kernel<<<(m + 63) / 64, 64 * IDS_WAVES, 0, s>>>(ident, m, ldw, row_avg, row_max);
+                           float *out2, float *row_min) {
+    identity_rows_kernel<<<(m + 63) / 64, 64 * IDS_WAVES, 0, s>>>(ident, m, ldw, row_avg, row_max, row_min);
     if ((size_t)m * 8 <= 64 * 1024) {
         identity_final_kernel<<<1, 256, (size_t)m * 8, s>>>(row_avg, row_max, m, out2);
     } else {

@@ -220,3 +220,18 @@ def test_threads_are_independent(enog_ali):
         out = pool.map(trimmer.trim, alis)
     for ali, t in zip(alis, out):
         assert_matches_oracle(t, oracle.pack(list(ali.sequences)), method="strict")
+
+
+@pytest.mark.parametrize("clusters", [3, 40, 400])
+def test_clusters_device_search(monkeypatch, clusters):
+    """clusters=K with the threshold search probing the device clustering (the default from 2000 sequences on;
+    forced here on a smaller alignment as well) against the oracle's getCutPointClusters + greedy clustering."""
+    from pytrimal_amd.synth import synth_msa
+
+    monkeypatch.setenv("MSA_DEVICE_CLUSTERS", "1")
+    for m, n, seed in ((300, 120, 31), (2050, 90, 32)):
+        a = synth_msa(m, n, seed)
+        a[5] = a[4]  # identical sequences: identity 1
+        ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+        trimmed = RepresentativeTrimmer(clusters=clusters, platform=PLATFORM).trim(ali)
+        assert_matches_oracle(trimmed, a, clusters=clusters)
