@@ -960,52 +960,56 @@ __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int
     sim_barrier();  // slice[0] staged
     sim_barrier();  // round 0 produced
     constexpr int QP = NK_QUADS / 4;
-    float4 s0[QP], s1[QP], s2[QP];
+    // Six quarter-round register sets.  A round's 28 ring reads are issued together right after the barrier;
+    // the chain first adds the two quarters left pending by the previous round (their reads landed long
+    // ago), then this round's first two, and leaves the last two pending across the next barrier: every read
+    // has at least two quarters of adds (~240 cycles) plus a barrier to land before it is needed.
+    float4 sa[QP], sb[QP], sc[QP], sd[QP], se[QP], sf[QP];
 #pragma unroll
-    for (int p = 0; p < QP; ++p) s0[p] = s1[p] = s2[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < QP; ++p) sa[p] = sb[p] = sc[p] = sd[p] = se[p] = sf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto rd = [&](float4 (&v)[QP], const float4 *in, int quarter) {
 #pragma unroll
         for (int p = 0; p < QP; ++p) v[p] = in[(quarter * QP + p) * 64];
-        __builtin_amdgcn_sched_barrier(0);
     };
     static_assert(QP % 7 == 0, "the chain is issued in blocks of 7 quads");
     auto add = [&](const float4 (&v)[QP]) {
         nk_chain<0>(acc, v);
         if constexpr (QP > 7) nk_chain<7>(acc, v);
     };
-    // same rotation as the consumer of similarity_pc_kernel: two quarter-rounds stay pending in registers
-    // across the barrier
     const bool stamp = DIAG && blockIdx.x == 0;
     unsigned long long tw = 0, tb = 0;
-    auto one_round = [&](float4 (&x)[QP], float4 (&y)[QP], float4 (&z)[QP], int r) {
+    // (p0, p1) pending on entry; (q0 .. q3) receive this round; (q2, q3) are pending on exit
+    auto one_round = [&](float4 (&p0)[QP], float4 (&p1)[QP], float4 (&q0)[QP], float4 (&q1)[QP], float4 (&q2)[QP],
+                         float4 (&q3)[QP], int r) {
         unsigned long long t0 = 0, t1 = 0;
         if (stamp) t0 = sim_now();
         const float4 *in = ring + ((r - 1) & 1) * NK_QUADS * 64 + lane;
-        rd(z, in, 0);
-        add(x);
-        rd(x, in, 1);
-        add(y);
-        rd(y, in, 2);
-        add(z);
-        rd(z, in, 3);
-        add(x);
+        rd(q0, in, 0);
+        rd(q1, in, 1);
+        rd(q2, in, 2);
+        rd(q3, in, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        add(p0);
+        add(p1);
+        add(q0);
+        add(q1);
         if (stamp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             t1 = sim_now();
         }
-        sim_barrier();
+        sim_barrier();  // also waits for the q2 / q3 reads: their buffer is rewritten two rounds on
         if (stamp) {
             tw += t1 - t0;
             tb += sim_now() - t1;
         }
     };
-    for (int r = 1; r + 2 <= rounds; r += 3) {
-        one_round(s0, s1, s2, r);
-        one_round(s1, s2, s0, r + 1);
-        one_round(s2, s0, s1, r + 2);
+    for (int r = 1; r + 2 <= rounds; r += 3) {  // the launcher makes `rounds` a multiple of 3
+        one_round(sa, sb, sc, sd, se, sf, r);
+        one_round(se, sf, sa, sb, sc, sd, r + 1);
+        one_round(sc, sd, se, sf, sa, sb, r + 2);
     }
-    add(s0);
-    add(s1);
+    add(sa);  // the two quarters still pending
+    add(sb);
     if (stamp && lane == 0) {
         g_sim_stamps[0] = tw;
         g_sim_stamps[1] = tb;
