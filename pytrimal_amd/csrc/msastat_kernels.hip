@@ -334,9 +334,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int SIM_NP = 7;    // producer waves (+1 consumer = 8 waves = 2 per SIMD)
 constexpr int SIM_OCTS = 2;  // octs per producer per round
 constexpr int SIM_ROUND_OCTS = SIM_NP * SIM_OCTS;       // 14 octs = 112 steps per round
-#ifndef SIM_SKEW_SPLIT
-#define SIM_SKEW_SPLIT 7  // producers below this index gather first and fetch while the LDS answers
-#endif
 constexpr int SIM_PAIRS = SIM_ROUND_OCTS * 4;           // float4 {x0,w0,x1,w1} per lane per round
 constexpr int SIM_MASTER_BYTES = 29 * 32 * 8;           // {D, valid} table, [29][32] x 8 B
 constexpr int SIM_RING_BYTES = 2 * SIM_PAIRS * 64 * 16; // 114688
@@ -522,7 +519,6 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
         const int gw = g0 >= G8 ? G8 - 1 : g0;
         wv = wlane[wrow + 8u * (uint32_t)gw];
     };
-    auto settle = [&](const SimOct (&u)[SIM_OCTS]) { (void)u; };
     // this lane's table row index for row jn (its residue in that row), npos when skipped
     auto load_cj = [&](int jn) -> uint32_t {
         if (jn >= m - 1) return (uint32_t)npos << 9;
@@ -614,7 +610,6 @@ __device__ __forceinline__ void sim_producer(const int P, unsigned char *smem, c
     auto round = [&](SimOct (&cur)[SIM_OCTS], float wcur, SimOct (&far)[SIM_OCTS], float &wfar, int r) {
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (stamp) t0 = sim_now();
-        settle(cur);
         if (stamp) t1 = sim_now();
         const SimPos pos2 = sim_next(pos1, G8);
         if (DIAG && (mode & 1)) {
