@@ -235,3 +235,57 @@ def test_clusters_device_search(monkeypatch, clusters):
         ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
         trimmed = RepresentativeTrimmer(clusters=clusters, platform=PLATFORM).trim(ali)
         assert_matches_oracle(trimmed, a, clusters=clusters)
+
+
+# --- randomized sweep: every trimmer family on small random alignments, masks against the oracle's trim ---------
+
+
+def _random_alignment(seed):
+    r = np.random.default_rng(seed)
+    m = int(r.integers(4, 60))
+    n = int(r.integers(8, 160))
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    root = alpha[r.integers(0, 20, n)]
+    a = np.where(r.random((m, n)) < r.uniform(0.2, 0.9), root, alpha[r.integers(0, 20, (m, n))]).astype(np.uint8)
+    a[r.random((m, n)) < float(r.choice([0.05, 0.3, 0.6]))] = ord("-")
+    a[r.random((m, n)) < 0.01] = ord("X")
+    if r.random() < 0.4:
+        a[:, int(r.integers(0, n))] = ord("-")
+    if r.random() < 0.3:
+        a[int(r.integers(1, m))] = a[0]
+    return np.ascontiguousarray(a)
+
+
+_SWEEP = [
+    (lambda: AutomaticTrimmer("strict", platform=PLATFORM), dict(method="strict")),
+    (lambda: AutomaticTrimmer("strictplus", platform=PLATFORM), dict(method="strictplus")),
+    (lambda: AutomaticTrimmer("gappyout", platform=PLATFORM), dict(method="gappyout")),
+    (lambda: AutomaticTrimmer("automated1", platform=PLATFORM), dict(method="automated1")),
+    (lambda: AutomaticTrimmer("nogaps", platform=PLATFORM), dict(method="nogaps")),
+    (lambda: AutomaticTrimmer("noallgaps", platform=PLATFORM), dict(method="noallgaps")),
+    (lambda: ManualTrimmer(gap_threshold=0.7, platform=PLATFORM), dict(gap_threshold=0.7)),
+    (lambda: ManualTrimmer(similarity_threshold=0.3, conservation_percentage=40, platform=PLATFORM),
+     dict(similarity_threshold=0.3, conservation_percentage=40)),
+    (lambda: ManualTrimmer(gap_threshold=0.6, similarity_threshold=0.2, window=1, platform=PLATFORM),
+     dict(gap_threshold=0.6, similarity_threshold=0.2, window=1)),
+    (lambda: OverlapTrimmer(50.0, 0.6, platform=PLATFORM), dict(sequence_overlap=50.0, residue_overlap=0.6)),
+    (lambda: RepresentativeTrimmer(identity_threshold=0.6, platform=PLATFORM), dict(identity_threshold=0.6)),
+    (lambda: RepresentativeTrimmer(clusters=3, platform=PLATFORM), dict(clusters=3)),
+]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_alignments_all_trimmers(seed):
+    a = _random_alignment(7000 + seed)
+    ali = Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+    for make, kw in _SWEEP:
+        trimmer = make()
+        try:
+            expected = oracle.trim(a, **kw)
+        except oracle.OracleError:
+            with pytest.raises((ValueError, RuntimeError)):
+                trimmer.trim(ali)
+            continue
+        trimmed = trimmer.trim(ali)
+        assert trimmed.residues_mask == [bool(x) for x in expected[0]], (seed, repr(trimmer))
+        assert trimmed.sequences_mask == [bool(x) for x in expected[1]], (seed, repr(trimmer))
