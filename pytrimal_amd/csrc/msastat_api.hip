@@ -113,6 +113,11 @@ struct msa_ctx {
     PinBuf<float> h_f32;
     PinBuf<unsigned long long> h_u64;
     PinBuf<uint8_t> h_u8, h_raw;
+    // results that are fetched asynchronously and validated at the next synchronisation of the stream
+    PinBuf<int> h_planeflag;       // prep_planes' non-ASCII flag
+    bool planes_pending = false;
+    PinBuf<int32_t> h_gapstage;    // gap / indetermination counts on their way to h_gaps / h_indets
+    int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
 
     // host copies valid for the current alignment
     std::vector<int32_t> h_gaps, h_indets;
@@ -133,6 +138,26 @@ int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
     do {                                                     \
         hipError_t _e = (expr);                              \
         if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
+    } while (0)
+
+// Every wait on the context's stream goes through here: it also settles the asynchronous fetches above.
+static int sync_stream(msa_ctx *c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
+    if (c->gaps_staged == 1) c->gaps_staged = 2;
+    if (c->planes_pending) {
+        c->planes_pending = false;
+        if (c->h_planeflag.p[0]) {
+            c->have_planes = false;
+            return MSA_E_NON_ASCII;
+        }
+    }
+    return MSA_OK;
+}
+#define SYNC(c)                          \
+    do {                                 \
+        const int rc_sync_ = sync_stream(c); \
+        if (rc_sync_) return rc_sync_;   \
     } while (0)
 
 struct ProfScope {  // records an event pair around a launch sequence when profiling is on
@@ -181,6 +206,8 @@ void prof_collect(msa_ctx *c) {
 void invalidate(msa_ctx *c) {
     c->have_planes = c->have_gaps = c->have_ident = c->have_w = false;
     c->h_gaps.clear();
+    c->gaps_staged = 0;
+    c->planes_pending = false;
     c->h_indets.clear();
 }
 
@@ -208,10 +235,11 @@ int ensure_planes(msa_ctx *c) {
                                  c->errflag.p);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, c->h_i32.reserve(4));
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->h_i32.p[0]) return MSA_E_NON_ASCII;
+    // the non-ASCII verdict comes back with the next synchronisation of the stream (sync_stream): every caller
+    // synchronises before it hands anything derived from the planes to the host
+    HIPCHK(c, c->h_planeflag.reserve(1));
+    HIPCHK(c, hipMemcpyAsync(c->h_planeflag.p, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->planes_pending = true;
     c->have_planes = true;
     return MSA_OK;
 }
@@ -230,14 +258,30 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
         c->have_gaps = true;
     }
     if (to_host && c->h_gaps.empty() && c->n > 0) {
-        HIPCHK(c, c->h_i32.reserve((size_t)2 * c->n));
-        HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_i32.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost,
-                                 c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->h_gaps.assign(c->h_i32.p, c->h_i32.p + c->n);
-        c->h_indets.assign(c->h_i32.p + c->n, c->h_i32.p + 2 * c->n);
+        if (c->gaps_staged == 0) {
+            HIPCHK(c, c->h_gapstage.reserve((size_t)2 * c->n));
+            HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost,
+                                     c->stream));
+            c->gaps_staged = 1;
+        }
+        if (c->gaps_staged == 1) SYNC(c);  // (2: a synchronisation has already covered the copies)
+        c->h_gaps.assign(c->h_gapstage.p, c->h_gapstage.p + c->n);
+        c->h_indets.assign(c->h_gapstage.p + c->n, c->h_gapstage.p + 2 * c->n);
+        c->gaps_staged = 0;
     }
+    return MSA_OK;
+}
+
+// enqueue the gap counts and their copy to the host without waiting: the next synchronisation completes them
+int stage_gaps(msa_ctx *c) {
+    int rc = ensure_gaps(c, false);
+    if (rc) return rc;
+    if (!c->h_gaps.empty() || c->gaps_staged || c->n <= 0) return MSA_OK;
+    HIPCHK(c, c->h_gapstage.reserve((size_t)2 * c->n));
+    HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    c->gaps_staged = 1;
     return MSA_OK;
 }
 
@@ -287,7 +331,7 @@ int identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_f32.reserve(2));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->stats2.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     *avg_seq = c->h_f32.p[0];
     *max_seq = c->h_f32.p[1];
     return MSA_OK;
@@ -409,7 +453,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     const unsigned long long key = c->h_u64.p[0];
     if (key != ~0ull) {
         if (detail) {
@@ -440,7 +484,7 @@ int overlap(msa_ctx *c, float residue_overlap, float *out) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->good.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     for (int i = 0; i < m; ++i) out[i] = static_cast<float>(c->h_i32.p[i]) / n;
     return MSA_OK;
 }
@@ -460,7 +504,7 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
     msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     bool all_rows = true;
     for (int i = 0; i < m; ++i) {
         if (keep_seq[i] && c->h_i32.p[i] == 0) keep_seq[i] = 0;
@@ -478,7 +522,7 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
     msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     for (int j = 0; j < n; ++j)
         if (keep_res[j] && c->h_i32.p[j] == 0) keep_res[j] = 0;
     return MSA_OK;
@@ -495,7 +539,7 @@ int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned l
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->lengths.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->hashes.p, sizeof(unsigned long long) * 2 * m, hipMemcpyDeviceToHost,
                              c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     lengths.assign(c->h_i32.p, c->h_i32.p + m);
     if (hashes) hashes->assign(c->h_u64.p, c->h_u64.p + 2 * m);
     return MSA_OK;
@@ -536,7 +580,7 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
     HIPCHK(c, hipGetLastError());
     std::vector<int32_t> equal(npairs);
     HIPCHK(c, hipMemcpyAsync(equal.data(), c->equal.p, npairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     for (int p = 0; p < npairs; ++p)
         if (equal[p]) keep_seq[std::min(pairs[2 * p], pairs[2 * p + 1])] = 0;  // a later identical row exists
     return MSA_OK;
@@ -572,7 +616,7 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
     HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     std::memcpy(keep_seq, c->h_u8.p, m);
     return MSA_OK;
 }
@@ -631,7 +675,7 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->equal.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        SYNC(c);
         const int count = c->h_i32.p[0];
         if (clusters == m || clusters == 1) break;  // the bounds of getCutPointClusters: no search
         if (count == clusters || stalled > 10) break;
@@ -647,7 +691,7 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     }
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
     HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     std::memcpy(keep_seq, c->h_u8.p, m);
     return MSA_OK;
 }
@@ -658,7 +702,7 @@ int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of th
     host.resize((size_t)c->m * c->m);
     HIPCHK(c, hipMemcpy2DAsync(host.data(), (size_t)c->m * sizeof(float), c->ident.p, (size_t)c->ldw * sizeof(float),
                                (size_t)c->m * sizeof(float), c->m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     return MSA_OK;
 }
 
@@ -726,6 +770,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
+    c->h_planeflag.release(); c->h_gapstage.release();
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);
@@ -740,7 +785,7 @@ void *msa_ctx_stream(msa_ctx *c) { return c ? static_cast<void *>(c->stream) : n
 
 int msa_ctx_sync(msa_ctx *c) {
     if (!c) return MSA_E_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     return MSA_OK;
 }
 
@@ -769,7 +814,7 @@ int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n,
             HIPCHK(c, hipMemcpyAsync(c->raw_own.p, c->h_raw.p, bytes, hipMemcpyHostToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `rowmajor` on return
+    SYNC(c);  // the caller may free `rowmajor` on return
     return MSA_OK;
 }
 
@@ -818,7 +863,7 @@ int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
     const size_t bytes = (size_t)c->m * c->m * sizeof(uint32_t);
     if (hit) HIPCHK(c, hipMemcpyAsync(hit, c->hit.p, bytes, hipMemcpyDeviceToHost, c->stream));
     if (dst) HIPCHK(c, hipMemcpyAsync(dst, c->dst.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     return MSA_OK;
 }
 
@@ -834,7 +879,7 @@ int msa_identities(msa_ctx *c, float *ident, float *w) {
     if (w)
         HIPCHK(c, hipMemcpy2DAsync(w, row, c->wmat.p, (size_t)c->ldw * sizeof(float), row, c->m, hipMemcpyDeviceToHost,
                                    c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SYNC(c);
     if (w) {  // the device keeps W strictly upper triangular; the ABI returns the symmetric matrix
         const size_t m = c->m;
         for (size_t i = 0; i < m; ++i)
@@ -959,6 +1004,8 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         if (method == MSA_METHOD_AUTOMATED1) {
             // one pair pass produces both float matrices when strict is likely to follow
             rc = run_pairs(c, true, true, false);
+            if (rc) return rc;
+            rc = stage_gaps(c);  // both methods need the gap counts: they ride on the identity statistics' wait
             if (rc) return rc;
             trace.mark("pairs enqueued");
             rc = identity_stats(c, &info->avg_seq, &info->max_seq);
