@@ -96,7 +96,7 @@ struct msa_ctx {
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, row_min, stats2;
-    DevBuf<uint32_t> codes16;  // [G8 + 1][ld] x 16 B
+    DevBuf<uint32_t> simcodes;  // similarity codes: [G8 + 1][ld] x 8 B (codes8) or [G8 + 1][2][ld] x 16 B (codes32)
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
     DevBuf<int32_t> gaps_w;
@@ -396,7 +396,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
-    HIPCHK(c, c->codes16.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // [G8 + 1][2][ld] x 16 B (32-bit codes)
+    HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // sized for the larger format (codes32)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     HIPCHK(c, c->q.reserve((size_t)n + 64));
@@ -426,11 +426,11 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipEventRecord(c->ev_join, sden));
         {
             ProfScope pe(c, "encode");
-            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p);
+            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p);
         }
         {
             ProfScope pn(c, "simnum");
-            const int e = msak::launch_similarity_num(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p,
+            const int e = msak::launch_similarity_num(c->stream, c->simcodes.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p,
                                                       npos, c->simnum.p, tcols);
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_num");
         }
@@ -439,12 +439,12 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     } else {
         {
             ProfScope ps(c, "encode");
-            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->codes16.p, c->errkey.p,
+            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p,
                                       tcols);
         }
         HIPCHK(c, hipGetLastError());
         ProfScope ps(c, "sim");
-        const int e = msak::launch_similarity_pc(c->stream, c->codes16.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
+        const int e = msak::launch_similarity_pc(c->stream, c->simcodes.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
                                                  gw_dev, c->q.p, c->mdk.p, tcols);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
@@ -765,7 +765,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
-    c->stats2.release(); c->codes16.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
+    c->stats2.release(); c->simcodes.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();

@@ -9,7 +9,8 @@
 //   gaps / indet [n]             i32  per-column '-' / indetermination counts
 //   ident [m][ldw]               f32  pairwise identity, symmetric (ldw % 64 == 0, pad = 0)
 //   w     [m][ldw]               f32  1 - identity, STRICTLY UPPER triangular (0 elsewhere)
-//   codes16 [ceil(m/8)+1][ld]    8xu16 per column, 8 consecutive rows' byte offsets into a table slice
+//   codes8  [ceil(m/8)+1][ld]    8xu8 per column: table entries of 8 consecutive rows (numerator kernel);
+//                                the single-chain kernel uses codes32, one byte offset per dword
 //   tab     [29][32]             f32x2 {distance, both-valid} indexed by (row index, column index)
 //
 // No MFMA anywhere: this is integer / lookup / ordered-fp32 work.
@@ -304,7 +305,9 @@ __global__ void identity_final_big_kernel(const float *__restrict__ row_avg, con
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
-// similarity_mdk, producer/consumer form (the one msa_similarity launches).
+// similarity_mdk, single-chain producer/consumer form: both sums in one packed chain.  msa_similarity
+// launches the numerator + denominator kernels further down; this one remains as the alternative
+// selected by MSA_SIM_KERNEL=pc and is parity-tested at every size.
 //
 // The float32 sums of one column are a strictly sequential chain, so the only way to go faster
 // than one-wave-does-everything is to strip the chain-carrying wave down to the chain itself.
@@ -319,7 +322,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //              (a skipped pair contributes {+0, +0}, which leaves both sums unchanged).
 // Each producer keeps a private, lane-interleaved copy of the table row of its current j
 // ([entry][lane] x 8 B: every lane owns its bank pair, so the per-step gather is conflict-free).
-// codes16 [ceil(m/8) + 1][ld] x 8 u16: entry * 512 + (column & 63) * 8, i.e. the byte offset
+// codes32 [ceil(m/8) + 1][2][ld] x 4 u32: entry * 512 + (column % tile) * 8, i.e. the byte offset
 // into such a slice; entry `npos` is the all-zero entry of skipped residues; the extra last
 // row is all-skipped and is what producers read once they run past the end of the sequence.
 // W is strictly upper triangular, so the rows k <= j of a row's first oct need no masking.
