@@ -786,6 +786,18 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
         n_steps += (unsigned long long)ng * G;
         const uint32_t *mp = masks + k0;
         const float *wp = wmat + ((size_t)j * (size_t)ldw + (size_t)k0);
+        // W is streamed once per XCD (16 MB at m = 2000: it does not stay in the 4 MB L2) and the loop below
+        // covers only one group of latency: a W line that has to come from HBM stalls every wave that needs it
+        // (alone on the GPU this kernel runs 2.4x slower than beside the numerator kernel, whose W traffic
+        // happens to warm the L2).  So the workgroup touches the row after next with vector loads that nobody
+        // waits for: LDS-DMA into a scratch line, no register in flight.
+        if (j + 2 < m) {
+            const float *pre = wmat + (size_t)(j + 2) * (size_t)ldw;
+            for (int off = (j + 2) / 8 * 8 + (threadIdx.x * 8); off < ldw; off += (int)blockDim.x * 8) {
+                const uint32_t voff = (uint32_t)off * 4u;
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(1024u), "v"(voff), "s"(pre) : "m0", "memory");
+            }
+        }
         // Two SGPR buffers of 16 steps: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99].
         // The loop is ISSUE-bound (a lone wave issues one instruction per ~4.3 cycles whatever its type: 2
         // instructions per step + the loop's own), so the bookkeeping is pared down: one byte offset (s30)
