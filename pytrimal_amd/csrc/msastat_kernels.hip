@@ -919,7 +919,9 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
 // rounds are padded to a multiple of 3 with pseudo-rows j = m-1, whose W row is all zero.
 // LDS: master D [29][32] f32 | slice 0 | ring 2 x [28][64] float4 | slice 1 (64 KB above slice 0) | W stage.
 // ------------------------------------------------------------------------------------------
-constexpr int NK_MASTER_BYTES = 29 * 32 * 4;   // 3712, at LDS address 0
+constexpr int NK_MASTER_LD = 33;                // row pitch of the master table: lanes read different ROWS at the same
+                                               // column when a slice is staged -- with a pitch of 32 that is one bank
+constexpr int NK_MASTER_BYTES = 29 * NK_MASTER_LD * 4;   // 3828, at LDS address 0
 constexpr int NK_SLICE_STRIDE = 29 * 256;      // 7424: [entry][lane] x 4 B
 constexpr int NK_ROUND_OCTS = SIM_NP * NK_OCTS;  // 14 octs = 112 steps per round
 constexpr int NK_QUADS = NK_ROUND_OCTS * 2;      // float4 (4 steps) per lane per round
@@ -1058,7 +1060,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     };
     auto refresh = [&](int jn, uint32_t idx) {
         float *sl = reinterpret_cast<float *>(smem + ((jn & 1) ? NK_SLICE1_OFF : NK_SLICE0_OFF)) + lane;
-        const float *mrow = master + idx * 32;
+        const float *mrow = master + idx * NK_MASTER_LD;
         for (int e = P; e <= npos; e += SIM_NP) sl[e * 64] = mrow[e];
     };
     auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / NK_ROUND_OCTS : R - 1; };
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
     const bool active = lane < tcols && c < ld;
     {
         float *master = reinterpret_cast<float *>(smem);
-        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[t] = tab_g[t].x;
+        for (int t = threadIdx.x; t < 29 * 32; t += 512) master[(t >> 5) * NK_MASTER_LD + (t & 31)] = tab_g[t].x;
     }
     __syncthreads();
     if (wave != 0) {
