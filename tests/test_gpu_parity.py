@@ -339,3 +339,15 @@ def _random_case(seed):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_small_alignments(ctx, seed):
     all_stats(ctx, _random_case(9000 + seed))
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_nucleotide_statistics(ctx, degenerate):
+    """DNA alignments: indetermination 'N', the built-in nucleotide matrices."""
+    r = np.random.default_rng(17 + degenerate)
+    alpha = np.frombuffer(b"ACGTRYKM" if degenerate else b"ACGT", dtype=np.uint8)
+    a = alpha[r.integers(0, len(alpha), (70, 210))].copy()
+    a[r.random(a.shape) < 0.25] = ord("-")
+    a[r.random(a.shape) < 0.03] = ord("N")
+    err = all_stats(ctx, np.ascontiguousarray(a), indet=ord("N"), matrix=oracle.nt_matrix(degenerate))
+    assert err is None

@@ -289,3 +289,33 @@ def test_random_alignments_all_trimmers(seed):
         trimmed = trimmer.trim(ali)
         assert trimmed.residues_mask == [bool(x) for x in expected[0]], (seed, repr(trimmer))
         assert trimmed.sequences_mask == [bool(x) for x in expected[1]], (seed, repr(trimmer))
+
+
+# --- nucleotide alignments: type detection picks 'N' as the indetermination symbol and the NT / degenerate-NT matrix
+
+
+def _nt_alignment(seed, alphabet, m=40, n=150):
+    r = np.random.default_rng(seed)
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    root = alpha[r.integers(0, len(alpha), n)]
+    a = np.where(r.random((m, n)) < 0.7, root, alpha[r.integers(0, len(alpha), (m, n))]).astype(np.uint8)
+    a[r.random((m, n)) < 0.2] = ord("-")
+    a[r.random((m, n)) < 0.02] = ord("N")
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ACGU", b"ACGTRYKMSW"])
+def test_nucleotide_alignments(alphabet):
+    a = _nt_alignment(len(alphabet), alphabet)
+    ali = Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+    for make, kw in _SWEEP:
+        trimmer = make()
+        try:
+            expected = oracle.trim(a, **kw)
+        except oracle.OracleError:
+            with pytest.raises((ValueError, RuntimeError)):
+                trimmer.trim(ali)
+            continue
+        trimmed = trimmer.trim(ali)
+        assert trimmed.residues_mask == [bool(x) for x in expected[0]], (alphabet, repr(trimmer))
+        assert trimmed.sequences_mask == [bool(x) for x in expected[1]], (alphabet, repr(trimmer))
