@@ -351,3 +351,9 @@ def test_nucleotide_statistics(ctx, degenerate):
     a[r.random(a.shape) < 0.03] = ord("N")
     err = all_stats(ctx, np.ascontiguousarray(a), indet=ord("N"), matrix=oracle.nt_matrix(degenerate))
     assert err is None
+
+
+def test_wide_alignment_many_workgroups(ctx, monkeypatch):
+    """Many more column tiles than CUs (the chain workgroups take a CU each): several waves of workgroups."""
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(60, 40000, 4321))
