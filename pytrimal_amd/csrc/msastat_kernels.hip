@@ -805,9 +805,13 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
         asm volatile(
             "s_mov_b64 s[10:11], exec\n\t"
             "s_mov_b32 exec_hi, 0\n\t"
-            "s_mov_b32 s8, %2\n\ts_sub_u32 s9, %3, 1\n\ts_mov_b64 s[12:13], %4\n\ts_mov_b64 s[14:15], %5\n\ts_mov_b32 s30, 0\n\t"
+            "s_mov_b32 s8, %2\n\ts_mov_b64 s[12:13], %4\n\ts_mov_b64 s[14:15], %5\n\ts_mov_b32 s30, 0\n\t"
             "s_load_dword %1, %6, 0x0\n\t"  // V(j+1): a vector load + readfirstlane here costs a memory round trip per row
             "s_load_dwordx16 s[36:51], s[12:13], s30\n\ts_load_dwordx16 s[52:67], s[14:15], s30\n\t"
+            // %3 = ng: the loop runs ng / 2 pairs of groups with ONE exit test per pair, an odd group follows
+            "s_lshr_b32 s9, %3, 1\n\t"
+            "s_sub_u32 s9, s9, 1\n\t"
+            "s_cbranch_scc1 2f\n\t"  // no pair at all
             "1:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_load_dwordx16 s[68:83], s[12:13], s30 offset:0x40\n\ts_load_dwordx16 s[84:99], s[14:15], s30 offset:0x40\n\t"
@@ -827,7 +831,6 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             "s_and_b32 exec_lo, s8, s49\n\tv_add_f32 %0, s65, %0\n\t"
             "s_and_b32 exec_lo, s8, s50\n\tv_add_f32 %0, s66, %0\n\t"
             "s_and_b32 exec_lo, s8, s51\n\tv_add_f32 %0, s67, %0\n\t"
-            "s_sub_u32 s9, s9, 1\n\ts_cbranch_scc1 2f\n\t"
             "s_add_u32 s30, s30, 0x80\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_load_dwordx16 s[36:51], s[12:13], s30\n\ts_load_dwordx16 s[52:67], s[14:15], s30\n\t"
@@ -850,6 +853,25 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             "s_sub_u32 s9, s9, 1\n\ts_cbranch_scc0 1b\n\t"
             "2:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
+            "s_bitcmp0_b32 %3, 0\n\t"
+            "s_cbranch_scc1 3f\n\t"  // even group count: done (buffer A holds a group past the row end)
+            "s_and_b32 exec_lo, s8, s36\n\tv_add_f32 %0, s52, %0\n\t"
+            "s_and_b32 exec_lo, s8, s37\n\tv_add_f32 %0, s53, %0\n\t"
+            "s_and_b32 exec_lo, s8, s38\n\tv_add_f32 %0, s54, %0\n\t"
+            "s_and_b32 exec_lo, s8, s39\n\tv_add_f32 %0, s55, %0\n\t"
+            "s_and_b32 exec_lo, s8, s40\n\tv_add_f32 %0, s56, %0\n\t"
+            "s_and_b32 exec_lo, s8, s41\n\tv_add_f32 %0, s57, %0\n\t"
+            "s_and_b32 exec_lo, s8, s42\n\tv_add_f32 %0, s58, %0\n\t"
+            "s_and_b32 exec_lo, s8, s43\n\tv_add_f32 %0, s59, %0\n\t"
+            "s_and_b32 exec_lo, s8, s44\n\tv_add_f32 %0, s60, %0\n\t"
+            "s_and_b32 exec_lo, s8, s45\n\tv_add_f32 %0, s61, %0\n\t"
+            "s_and_b32 exec_lo, s8, s46\n\tv_add_f32 %0, s62, %0\n\t"
+            "s_and_b32 exec_lo, s8, s47\n\tv_add_f32 %0, s63, %0\n\t"
+            "s_and_b32 exec_lo, s8, s48\n\tv_add_f32 %0, s64, %0\n\t"
+            "s_and_b32 exec_lo, s8, s49\n\tv_add_f32 %0, s65, %0\n\t"
+            "s_and_b32 exec_lo, s8, s50\n\tv_add_f32 %0, s66, %0\n\t"
+            "s_and_b32 exec_lo, s8, s51\n\tv_add_f32 %0, s67, %0\n\t"
+            "3:\n\t"
             "s_mov_b64 exec, s[10:11]"
             : "+v"(den), "=&s"(vnext)
             : "s"(vj), "s"(ng), "s"(mp), "s"(wp), "s"(mnext)
