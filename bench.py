@@ -217,6 +217,22 @@ def main():
                 "pair_columns_per_s": round(2 * (m * (m - 1) // 2) * ncols / cpu_s, 1),
             }
             out["speedup_vs_cpu_port"] = round(value / (ncols / cpu_s), 1)
+            # the same port on every host core: one column slice per thread (the C calls release the GIL)
+            cores = os.cpu_count() or 1
+            if cores > 1:
+                from multiprocessing.pool import ThreadPool
+
+                per = max(256, min(ncols, n // cores))
+                slices = [np.ascontiguousarray(a[:, i * per:(i + 1) * per]) for i in range(cores) if (i + 1) * per <= n]
+                t0 = time.perf_counter()
+                with ThreadPool(len(slices)) as pool:
+                    pool.map(lambda x: oracle.trim(x, method=method), slices)
+                all_s = time.perf_counter() - t0
+                out["cpu_baseline"]["all_cores"] = {
+                    "value": round(len(slices) * per / all_s, 2), "unit": "columns/s", "cores": len(slices),
+                    "sample": f"{len(slices)} threads x {per} columns each, {all_s:.1f} s",
+                }
+                out["speedup_vs_cpu_port_all_cores"] = round(value / (len(slices) * per / all_s), 1)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
