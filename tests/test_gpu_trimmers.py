@@ -319,3 +319,26 @@ def test_nucleotide_alignments(alphabet):
         trimmed = trimmer.trim(ali)
         assert trimmed.residues_mask == [bool(x) for x in expected[0]], (alphabet, repr(trimmer))
         assert trimmed.sequences_mask == [bool(x) for x in expected[1]], (alphabet, repr(trimmer))
+
+
+def test_concurrent_contexts_keep_parity():
+    """Several threads trimming different alignments at once (one device context and two HIP streams each):
+    every result still equals the oracle's."""
+    from multiprocessing.pool import ThreadPool
+
+    cases = []
+    for seed in range(18):
+        a = synth_msa(120 + 37 * (seed % 5), 300 + 64 * (seed % 4), 8800 + seed)
+        res, seq, _ = oracle.trim(a, method="strict")
+        cases.append((a, [bool(x) for x in res], [bool(x) for x in seq]))
+    trimmer = AutomaticTrimmer("strict", platform=PLATFORM)
+
+    def run(case):
+        a, res, seq = case
+        ali = Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+        out = trimmer.trim(ali)
+        return out.residues_mask == res and out.sequences_mask == seq
+
+    with ThreadPool(4) as pool:
+        for _ in range(3):
+            assert all(pool.map(run, cases))
