@@ -274,25 +274,21 @@ class Alignment:
             file.write(text)
 
     def dumps(self, format="fasta", encoding="utf-8"):
+        """Dump the alignment to a string in one of the formats of the reference's writer
+        (``/root/reference/src/pytrimal/_trimal.pyx:604-731``): clustal, fasta, html, mega, nexus,
+        phylip / phylip40, phylip32, phylippaml, nbrf / pir, and the ``_m10`` variants (names cut to
+        10 characters) of fasta, nexus, phylippaml, phylip32 and phylip40."""
         fmt = format.lower()
-        names = [n.decode(encoding) for n in self.names]
-        seqs = list(self.sequences)
-        out = io.StringIO()
-        if fmt == "fasta":
-            for name, seq in zip(names, seqs):
-                out.write(f">{name}\n")
-                for k in range(0, len(seq), 60):
-                    out.write(seq[k:k + 60] + "\n")
-        elif fmt == "clustal":
-            out.write("CLUSTAL multiple sequence alignment\n\n")
-            width = max((len(x) for x in names), default=0) + 6
-            n = len(seqs[0]) if seqs else 0
-            for k in range(0, n, 60):
-                for name, seq in zip(names, seqs):
-                    out.write(name.ljust(width) + seq[k:k + 60] + "\n")
-                out.write("\n\n")
-        else:
+        short = fmt.endswith("_m10")
+        base = fmt[:-4] if short else fmt
+        writer = _WRITERS.get(base)
+        if writer is None or (short and base not in _M10_FORMATS):
             raise ValueError(f"Could not recognize alignment format: {format!r}")
+        names = [n.decode(encoding) for n in self.names]
+        if short:
+            names = [x[:10] for x in names]
+        out = io.StringIO()
+        writer(out, names, list(self.sequences), self._alignment_type() if names else 0)
         return out.getvalue()
 
     # --- magic ------------------------------------------------------------------
@@ -456,6 +452,8 @@ def _sniff_format(data):
         return "clustal"
     if up.startswith(b"#NEXUS"):
         return "nexus"
+    if up.startswith(b"#MEGA"):
+        return "mega"
     if head[:1] == b">":
         return "pir" if len(head) > 3 and head[3:4] == b";" and head[1:3].isalnum() else "fasta"
     first = head.split(b"\n", 1)[0].split()
@@ -584,5 +582,164 @@ def _parse_clustal(data):
     return names, [b"".join(seqs[k]) for k in names]
 
 
+def _parse_mega(data):
+    """MEGA: '#MEGA', '!' command statements (each runs to its ';'), then '#name residues' lines,
+    interleaved or not."""
+    lines = data.splitlines()
+    if not lines or not lines[0].strip().upper().startswith(b"#MEGA"):
+        raise ValueError("not a MEGA file")
+    names, seqs, in_command, current = [], {}, False, None
+    for line in lines[1:]:
+        stripped = line.strip()
+        if in_command or stripped.startswith(b"!"):
+            in_command = not stripped.endswith(b";")
+            continue
+        if not stripped:
+            continue
+        if stripped.startswith(b"#"):
+            parts = stripped[1:].split()
+            if not parts:
+                raise ValueError("MEGA record without a name")
+            current = parts[0]
+            if current not in seqs:
+                names.append(current)
+                seqs[current] = []
+            seqs[current].append(b"".join(parts[1:]))
+        elif current is not None:
+            seqs[current].append(stripped.replace(b" ", b""))
+    if not names:
+        raise ValueError("no MEGA records")
+    return names, [b"".join(seqs[k]) for k in names]
+
+
 _PARSERS = {"clustal": _parse_clustal, "phylip": _parse_phylip, "phylip40": _parse_phylip, "phylip32": _parse_phylip32,
-            "nexus": _parse_nexus, "pir": _parse_pir, "nbrf": _parse_pir}
+            "phylippaml": _parse_phylip32, "nexus": _parse_nexus, "pir": _parse_pir, "nbrf": _parse_pir, "mega": _parse_mega}
+for _name in ("nexus", "phylippaml", "phylip32", "phylip40", "phylip"):
+    _PARSERS[_name + "_m10"] = _PARSERS[_name]
+
+
+# --- writers (the formats of trimAl's FormatManager, format_handling.pxd:11-32; layouts follow the public format
+# definitions -- blocks of 60 residues in groups of 10 where the format is free -- and every one is read back by
+# the loader above) ---------------------------------------------------------------------------------------------
+
+def _groups(seq, width=10):
+    return " ".join(seq[k:k + width] for k in range(0, len(seq), width))
+
+
+def _is_nucleotide(datatype):
+    return bool(datatype & 3) and not datatype & 4  # SequenceTypes bits DNA | RNA without AA
+
+
+def _write_fasta(out, names, seqs, datatype):
+    for name, seq in zip(names, seqs):
+        out.write(f">{name}\n")
+        for k in range(0, len(seq), 60):
+            out.write(seq[k:k + 60] + "\n")
+
+
+def _write_clustal(out, names, seqs, datatype):
+    out.write("CLUSTAL multiple sequence alignment\n\n")
+    width = max((len(x) for x in names), default=0) + 6
+    n = len(seqs[0]) if seqs else 0
+    for k in range(0, n, 60):
+        for name, seq in zip(names, seqs):
+            out.write(name.ljust(width) + seq[k:k + 60] + "\n")
+        out.write("\n\n")
+
+
+def _write_phylip40(out, names, seqs, datatype):
+    n = len(seqs[0]) if seqs else 0
+    width = max(max((len(x) for x in names), default=0), 10) + 3
+    out.write(f" {len(names)} {n}\n")
+    for k in range(0, max(n, 1), 60):
+        for name, seq in zip(names, seqs):
+            out.write((name if k == 0 else "").ljust(width) + _groups(seq[k:k + 60]) + "\n")
+        out.write("\n")
+
+
+def _write_phylip32(out, names, seqs, datatype):
+    n = len(seqs[0]) if seqs else 0
+    width = max(max((len(x) for x in names), default=0), 10) + 3
+    out.write(f" {len(names)} {n}\n")
+    for name, seq in zip(names, seqs):
+        for k in range(0, max(n, 1), 60):
+            out.write((name if k == 0 else "").ljust(width) + _groups(seq[k:k + 60]) + "\n")
+        out.write("\n")
+
+
+def _write_phylippaml(out, names, seqs, datatype):
+    n = len(seqs[0]) if seqs else 0
+    width = max(max((len(x) for x in names), default=0), 10) + 3
+    out.write(f" {len(names)} {n}\n")
+    for name, seq in zip(names, seqs):
+        out.write(name.ljust(width) + seq + "\n")
+
+
+def _write_nexus(out, names, seqs, datatype):
+    n = len(seqs[0]) if seqs else 0
+    width = max((len(x) for x in names), default=0) + 4
+    kind = "DNA" if _is_nucleotide(datatype) else "PROTEIN"
+    out.write("#NEXUS\nBEGIN DATA;\n")
+    out.write(f" DIMENSIONS NTAX={len(names)} NCHAR={n};\n")
+    out.write(f"FORMAT DATATYPE={kind} INTERLEAVE=yes GAP=-;\n")
+    for name in names:
+        out.write(f"[Name: {name.ljust(width)}Len: {n}]\n")
+    out.write("\nMATRIX\n")
+    for k in range(0, max(n, 1), 50):
+        for name, seq in zip(names, seqs):
+            out.write(name.ljust(width) + _groups(seq[k:k + 50]) + "\n")
+        out.write("\n")
+    out.write(";\nEND;\n")
+
+
+def _write_mega(out, names, seqs, datatype):
+    n = len(seqs[0]) if seqs else 0
+    width = max((len(x) for x in names), default=0) + 4
+    kind = "DNA" if _is_nucleotide(datatype) else "protein"
+    out.write("#MEGA\n!Title alignment;\n")
+    out.write(f"!Format DataType={kind} NSeqs={len(names)} Nsites={n} indel=- CodeTable=Standard;\n\n")
+    for k in range(0, max(n, 1), 50):
+        for name, seq in zip(names, seqs):
+            out.write(("#" + name).ljust(width + 1) + _groups(seq[k:k + 50]) + "\n")
+        out.write("\n")
+
+
+def _write_pir(out, names, seqs, datatype):
+    code = "DL" if _is_nucleotide(datatype) else "P1"
+    for name, seq in zip(names, seqs):
+        out.write(f">{code};{name}\n{name} {len(seq)} bases\n")
+        body = seq + "*"
+        for k in range(0, len(body), 50):
+            out.write("  " + _groups(body[k:k + 50]) + "\n")
+        out.write("\n")
+
+
+_HTML_CLASSES = {  # Clustal-style residue classes
+    "AVFPMILW": "hyd", "DE": "neg", "RK": "pos", "STYHCNGQ": "pol",
+}
+
+
+def _write_html(out, names, seqs, datatype):
+    import html
+
+    n = len(seqs[0]) if seqs else 0
+    width = max((len(x) for x in names), default=0) + 4
+    cls = {c: k for letters, k in _HTML_CLASSES.items() for c in letters}
+    out.write("<!DOCTYPE html>\n<html><head><meta charset=\"utf-8\"><title>alignment</title>\n<style>\n"
+              "pre{font-family:monospace} .hyd{background:#f9a19a} .neg{background:#d6a5f7} .pos{background:#9ab8f9}"
+              " .pol{background:#a5f7b0}\n</style></head><body><pre>\n")
+    for k in range(0, max(n, 1), 120):
+        for name, seq in zip(names, seqs):
+            out.write(html.escape(name).ljust(width))
+            for c in seq[k:k + 120]:
+                tag = cls.get(c.upper())
+                out.write(f'<span class="{tag}">{c}</span>' if tag else html.escape(c))
+            out.write("\n")
+        out.write("\n")
+    out.write("</pre></body></html>\n")
+
+
+_WRITERS = {"fasta": _write_fasta, "clustal": _write_clustal, "phylip": _write_phylip40, "phylip40": _write_phylip40,
+            "phylip32": _write_phylip32, "phylippaml": _write_phylippaml, "nexus": _write_nexus, "mega": _write_mega,
+            "pir": _write_pir, "nbrf": _write_pir, "html": _write_html}
+_M10_FORMATS = {"fasta", "nexus", "phylippaml", "phylip32", "phylip40", "phylip"}

@@ -329,3 +329,67 @@ def test_load_unknown_format_and_garbage():
         Alignment.load(io.BytesIO(b">a\nAC\n"), "stockholm")
     with pytest.raises(RuntimeError):
         Alignment.load(io.BytesIO(b" 2 4\nonly-one-line\n"), "phylip")
+
+
+# --- writers: every format of the reference's `Alignment.dump` (_trimal.pyx:604-731) is read back by the loader,
+# --- explicitly and by content sniffing, for a protein, a nucleotide and a long-named alignment
+
+_LONG_NAMES = [b"sequence_with_a_long_name_%d" % i for i in range(3)]
+_WRITER_CASES = {
+    "protein": (list(EXAMPLE_001_NAMES), list(EXAMPLE_001)),
+    "dna": ([b"s1", b"s2", b"s3"], ["ACGT-ACGTTGCA" * 11, "ACGTTACG--GCA" * 11, "AC-TTACGATGCA" * 11]),
+    "long": (_LONG_NAMES, ["MKV-LA" * 21 + "W", "MKVALA" * 21 + "-", "MRV-LG" * 21 + "Y"]),
+}
+_TEXT_FORMATS = ["fasta", "clustal", "phylip", "phylip40", "phylip32", "phylippaml", "nexus", "mega", "pir", "nbrf"]
+
+
+@pytest.mark.parametrize("case", sorted(_WRITER_CASES))
+@pytest.mark.parametrize("fmt", _TEXT_FORMATS)
+def test_dump_round_trips_through_load(tmp_path, fmt, case):
+    names, seqs = _WRITER_CASES[case]
+    ali = Alignment(names, seqs)
+    text = ali.dumps(fmt)
+    back = Alignment.load(io.BytesIO(text.encode()), fmt)
+    assert back.names == names and list(back.sequences) == seqs
+    path = tmp_path / f"out.{fmt}"
+    ali.dump(str(path), fmt)
+    assert path.read_text() == text
+    sniffed = Alignment.load(str(path))
+    assert sniffed.names == names and list(sniffed.sequences) == seqs
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "nexus", "phylippaml", "phylip32", "phylip40"])
+def test_dump_m10_variants_cut_names(fmt):
+    names, seqs = _WRITER_CASES["long"]
+    ali = Alignment([b"%d" % i + b"a" * 14 for i in range(3)], seqs)
+    back = Alignment.load(io.BytesIO(ali.dumps(fmt + "_m10").encode()), fmt)
+    assert back.names == [b"%d" % i + b"a" * 9 for i in range(3)] and list(back.sequences) == seqs
+    full = Alignment.load(io.BytesIO(ali.dumps(fmt).encode()), fmt)
+    assert full.names == ali.names
+
+
+def test_dump_headers_and_datatypes():
+    names, seqs = _WRITER_CASES["dna"]
+    dna, prot = Alignment(names, seqs), Alignment(*_WRITER_CASES["protein"])
+    assert "DATATYPE=DNA" in dna.dumps("nexus") and "DATATYPE=PROTEIN" in prot.dumps("nexus")
+    assert "NTAX=3 NCHAR=143" in dna.dumps("nexus")
+    assert dna.dumps("pir").startswith(">DL;s1\n") and prot.dumps("pir").startswith(">P1;Sp8\n")
+    assert dna.dumps("mega").startswith("#MEGA\n") and "NSeqs=3 Nsites=143" in dna.dumps("mega")
+    assert prot.dumps("phylip").splitlines()[0].split() == ["6", "46"]
+    page = prot.dumps("html")
+    assert page.startswith("<!DOCTYPE html>") and all(n.decode() in page for n in EXAMPLE_001_NAMES)
+    for bad in ("stockholm", "clustal_m10", "mega_m10", "html_m10"):
+        with pytest.raises(ValueError):
+            prot.dumps(bad)
+
+
+def test_trimmed_alignment_dumps_only_kept_cells():
+    names, seqs = _WRITER_CASES["protein"]
+    keep_seq = [True, False, True, True, False, True]
+    keep_res = [c % 3 != 0 for c in range(len(seqs[0]))]
+    t = TrimmedAlignment(names, seqs, keep_seq, keep_res)
+    expect = ["".join(c for c, k in zip(s, keep_res) if k) for s, k in zip(seqs, keep_seq) if k]
+    for fmt in _TEXT_FORMATS:
+        back = Alignment.load(io.BytesIO(t.dumps(fmt).encode()), fmt)
+        assert list(back.sequences) == expect, fmt
+        assert back.names == [n for n, k in zip(names, keep_seq) if k]
