@@ -43,15 +43,15 @@ def _pack_masks(results):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
 
-def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=2):
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=4):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
 
     Within a rank the shard is trimmed by `threads` threads (`trim` is re-entrant, one device context
-    per thread): the similarity kernels of one alignment leave most CUs idle, so two alignments in
-    flight double the throughput of a GPU (1000 x 4000 alignments: 1.0 -> 2.0 M columns/s; more threads
-    add nothing).
+    per thread): the similarity kernels of one alignment occupy 95 of the 256 CUs (each chain workgroup
+    claims a CU), so alignments in flight side by side raise the throughput of a GPU until the CUs are
+    taken (1000 x 4000 alignments: 1.1 / 2.0 / 2.5 / 2.8 M columns/s with 1 / 2 / 3-4 / 6 threads).
 
     `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
     which have no device).
