@@ -986,10 +986,10 @@ __device__ __forceinline__ void nk_unroll(F &&f) {
     }
 }
 
-template <bool DIAG>
+template <bool DIAG, int RING_OFF>
 __device__ __forceinline__ void nk_consumer(unsigned char *smem, int rounds, int lane, int c, int n,
                                             float *__restrict__ num_out) {
-    const float4 *ring = reinterpret_cast<const float4 *>(smem + NK_RING_OFF);
+    const float4 *ring = reinterpret_cast<const float4 *>(smem + RING_OFF);
     float acc = 0.0f;
     sim_barrier();  // slice[0] staged
     sim_barrier();  // round 0 produced
@@ -1231,7 +1231,190 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     sim_barrier();  // the consumer's drain round
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Transposed producers (tiles of 64 columns, resident codes).  The numerator kernel is bound by LDS cycles, and
+// in the layout above a producer lane is a column: 4 steps of a column leave as one ds_write_b128 (13 LDS
+// cycles: a store moves its 5 dwords per lane to the LDS at 2-3 cycles each) and W arrives as four broadcast
+// ds_read_b128.  Here lane p of a producer works, in register (w, b), on column 16 w + p / 4 at step
+// 4 b + p % 4 of the producer's 16 steps: a quad of the ring ([column][4 steps] x 4 B = 1 KB) is then four
+// 256-byte pieces whose dword index is the lane number -- ds_write_addtid_b32 (address = M0 + offset + 4 lane, no
+// address VGPR, 2 LDS cycles) stores each -- and the 4 W values a lane needs are one ds_read_b128 of a line the
+// DMA fills already permuted.  Per 112-step round: 112 gathers x 2 + 7 W reads x 4 + 112 stores x 2 + 28 ring
+// reads x 4 = 588 LDS cycles instead of 812.  The price: the table slices hold every entry four times
+// ([entry][column][step % 4], 1 KB per entry, so that the four lanes of a column hit four banks), and the
+// ring must lie below 64 KB (M0 carries 16 address bits).  The consumer is unchanged.
+// LDS: master | ring 2 x 28 KB | slice 0 (29 KB) | W stage | ... | slice 1 (64 KB above slice 0).
+// A code byte is 4 x the table entry: byte 1 of the gather address = entry x 1 KB.
+// ------------------------------------------------------------------------------------------
+constexpr int TP_RING_OFF = 4096;
+constexpr int TP_SLICE_OFF = TP_RING_OFF + NK_RING_BYTES;  // 61440
+constexpr int TP_SLICE_BYTES = 29 * 1024;
+constexpr int TP_WSTAGE_OFF = TP_SLICE_OFF + TP_SLICE_BYTES;  // 91136; per producer 2 x 256 B
+constexpr int TP_SLICE1_OFF = TP_SLICE_OFF + 65536;           // 126976
+__host__ __device__ constexpr int tp_lds_bytes() { return TP_SLICE1_OFF + TP_SLICE_BYTES; }  // 156672
+static_assert(NK_MASTER_BYTES <= TP_RING_OFF && TP_RING_OFF + NK_RING_BYTES <= 65536 - 4096 &&
+                  TP_WSTAGE_OFF + SIM_NP * 512 <= TP_SLICE1_OFF && TP_SLICE_OFF + 768 < 65536 && tp_lds_bytes() <= 160 * 1024,
+              "LDS layout of the transposed producers");
+
 template <bool DIAG, int RM>
+__device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem, const uint2 *__restrict__ codes8, int m,
+                                               int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
+                                               int c0, int R, int pad) {
+    const float *master = reinterpret_cast<const float *>(smem);
+    const int G8 = (m + 7) >> 3;
+    const int last_col = (int)ld - 1;
+    auto colptr = [&](int cc) { return reinterpret_cast<const uint8_t *>(codes8 + (cc < last_col ? cc : last_col)); };
+    // resident codes: word w, byte b of round q = 4 x entry of (column c0 + 16 w + lane / 4, row 8 (14 q + 2 P) + 4 b + lane % 4)
+    // Gathered byte by byte from the [oct][column] layout in a rolled loop, parked in this producer's part of the
+    // (still unused) LDS and read back into registers: unrolled, the 288 byte loads and their addresses spill.
+    uint4 cod[RM];
+    {
+        const int i = lane & 3;
+        const uint8_t *cp[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cp[w] = colptr(c0 + 16 * w + (lane >> 2));
+        uint4 *stash = reinterpret_cast<uint4 *>(smem + TP_RING_OFF + P * (RM * 1024)) + lane;
+        static_assert(TP_RING_OFF + SIM_NP * RM * 1024 <= tp_lds_bytes(), "code stash");
+#pragma unroll 1
+        for (int q = 0; q < RM; ++q) {
+            uint32_t word[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int g = q * NK_ROUND_OCTS + P * NK_OCTS + (b >> 1);
+                const size_t off = (size_t)(g >= G8 ? G8 : g) * (size_t)ld * 8u + (size_t)(4 * (b & 1) + i);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) word[w] |= (((uint32_t)cp[w][off] - (uint32_t)NK_K) * 4u) << (8 * b);
+            }
+            stash[q * 64] = make_uint4(word[0], word[1], word[2], word[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < RM; ++q) cod[q] = stash[q * 64];
+    }
+    sim_barrier();  // every producer holds its codes before slice 0 and the ring take the stash over
+    const uint8_t *mycol = colptr(c0 + lane);  // for the slice refresh a lane is a column
+    auto load_cj = [&](int jn) -> uint32_t {
+        if (jn >= m - 1) return (uint32_t)npos;
+        return (uint32_t)mycol[(size_t)(jn >> 3) * (size_t)ld * 8u + (size_t)(jn & 7)] - (uint32_t)NK_K;
+    };
+    auto refresh = [&](int jn, uint32_t idx) {
+        float4 *sl = reinterpret_cast<float4 *>(smem + ((jn & 1) ? TP_SLICE1_OFF : TP_SLICE_OFF)) + lane;
+        const float *mrow = master + idx * NK_MASTER_LD;
+        for (int e = P; e <= npos; e += SIM_NP) {
+            const float v = mrow[e];
+            sl[e * 64] = make_float4(v, v, v, v);
+        }
+    };
+    auto q0_of = [&](int j) { return j < m - 1 ? ((j + 1) >> 3) / NK_ROUND_OCTS : R - 1; };
+    int r = 0;
+    refresh(0, load_cj(0));
+    uint32_t cj_next = load_cj(1);
+    sim_barrier();  // slice[0] complete
+
+    const bool stamp = DIAG && blockIdx.x == 0;
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, tg = 0;
+    if (stamp) tg = sim_now();
+    // W[j][k0 .. k0 + 15] of this producer's round, DMA'd one round ahead: DMA lane 4 i + b carries element
+    // 4 b + i, so that the line reads back as [i][b] and lane p takes its four values W[4 b + p % 4] in one read
+    const uint32_t wstage_base = (uint32_t)(TP_WSTAGE_OFF + P * 512);
+    const uint32_t dma_off = (uint32_t)(((lane & 3) * 4 + ((lane >> 2) & 3)) * 4);
+    const uint32_t wread_off = (uint32_t)(lane & 3) * 16u;
+    const uint32_t ring_m0 = (uint32_t)(TP_RING_OFF + P * NK_OCTS * 2 * 1024);
+    auto wrow_of = [&](int jj) {
+        const int jr = jj < m - 1 ? jj : m - 1;
+        return wmat + ((size_t)jr * (size_t)ldw + (size_t)(P * NK_OCTS * 8));
+    };
+    {
+        const float *src = wrow_of(0) + q0_of(0) * (NK_ROUND_OCTS * 8);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(dma_off), "s"(src) : "m0", "memory");
+    }
+    uint32_t selv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(selv[k]) : "s"(0x03020400u + ((uint32_t)k << 8)));
+    auto round_work = [&](const uint4 &cq, int j, const float *wsrc_next, bool last_of_row) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this round's W has landed
+        const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(dma_off), "s"(wsrc_next) : "m0", "memory");
+        const uint32_t vlane = (uint32_t)lane * 4u + ((uint32_t)(j & 1) << 16);  // [lane * 4][code][row parity][0]
+        const uint32_t cw[4] = {cq.x, cq.y, cq.z, cq.w};
+        float tv[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t addr = __builtin_amdgcn_perm(cw[w], vlane, selv[b]);
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tv[w][b]) : "v"(addr), "i"(TP_SLICE_OFF + 256 * w));
+            }
+        f32x4 wq;
+        const uint32_t waddr = wstage_base + (uint32_t)(r & 1) * 256u + wread_off;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wq) : "v"(waddr));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(wq), "+v"(tv[0][0]), "+v"(tv[0][1]), "+v"(tv[0][2]), "+v"(tv[0][3]), "+v"(tv[1][0]),
+                       "+v"(tv[1][1]), "+v"(tv[1][2]), "+v"(tv[1][3]), "+v"(tv[2][0]), "+v"(tv[2][1]), "+v"(tv[2][2]),
+                       "+v"(tv[2][3]), "+v"(tv[3][0]), "+v"(tv[3][1]), "+v"(tv[3][2]), "+v"(tv[3][3])
+                     :
+                     : "memory");
+        unsigned long long td = 0;
+        if (stamp) td = sim_now();
+        f32x2 xa[4], xb[4];  // two packed multiplies per register set (separate rounding of every product)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            xa[w] = f32x2{tv[w][0], tv[w][1]} * f32x2{wq.x, wq.y};
+            xb[w] = f32x2{tv[w][2], tv[w][3]} * f32x2{wq.z, wq.w};
+        }
+        const uint32_t m0v = ring_m0 + (uint32_t)(r & 1) * (uint32_t)(NK_QUADS * 1024);
+#define TP_ST(w, b, reg) "ds_write_addtid_b32 " reg " offset:" #b "*1024+" #w "*256\n\t"
+        // (an SALU write of M0 needs one wait state before an add-TID LDS instruction reads it)
+        asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
+                     TP_ST(0, 0, "%0") TP_ST(0, 1, "%1") TP_ST(0, 2, "%2") TP_ST(0, 3, "%3")
+                     TP_ST(1, 0, "%4") TP_ST(1, 1, "%5") TP_ST(1, 2, "%6") TP_ST(1, 3, "%7")
+                     TP_ST(2, 0, "%8") TP_ST(2, 1, "%9") TP_ST(2, 2, "%10") TP_ST(2, 3, "%11")
+                     TP_ST(3, 0, "%12") TP_ST(3, 1, "%13") TP_ST(3, 2, "%14") TP_ST(3, 3, "%15")
+                     :
+                     : "v"(xa[0].x), "v"(xa[0].y), "v"(xb[0].x), "v"(xb[0].y), "v"(xa[1].x), "v"(xa[1].y), "v"(xb[1].x),
+                       "v"(xb[1].y), "v"(xa[2].x), "v"(xa[2].y), "v"(xb[2].x), "v"(xb[2].y), "v"(xa[3].x), "v"(xa[3].y),
+                       "v"(xb[3].x), "v"(xb[3].y), "s"(m0v)
+                     : "m0", "memory");
+#undef TP_ST
+        if (last_of_row) {  // stage the table slice of row j+1
+            refresh(j + 1, cj_next);
+            cj_next = load_cj(j + 2);
+        }
+        if (stamp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tf = sim_now();
+            sim_barrier();
+            const unsigned long long tn = sim_now();
+            acc_t[0] += td - tg;
+            acc_t[1] += tf - td;
+            acc_t[2] += tn - tf;
+            tg = tn;
+        } else {
+            sim_barrier();
+        }
+        ++r;
+    };
+    const int nrows = m - 1 + pad;
+    for (int jj = 0; jj < nrows; ++jj) {
+        const int q0 = q0_of(jj);
+        const float *wrow = wrow_of(jj);
+        nk_unroll<0, RM>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int Q = decltype(qc)::value;
+            if (Q >= q0 && Q < R) {
+                const bool last = Q == R - 1;
+                const float *wsrc_next = last ? wrow_of(jj + 1) + q0_of(jj + 1) * (NK_ROUND_OCTS * 8)
+                                              : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
+                round_work(cod[Q], jj, wsrc_next, last);
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the W prefetch past the end
+    if (stamp && lane == 0)
+        for (int k = 0; k < 5; ++k) g_sim_stamps[(P + 1) * 8 + k] = acc_t[k];
+    sim_barrier();  // the consumer's drain round
+}
+
+template <bool DIAG, int RM, bool TP = false>
 __global__ __launch_bounds__(512) void similarity_num_kernel(
     const uint2 *__restrict__ codes8, int m, int n, int64_t ld, const float *__restrict__ wmat, int ldw,
     const f32x2 *__restrict__ tab_g, int npos, int R, int pad, int rounds, float *__restrict__ num_out, int tcols) {
@@ -1246,12 +1429,20 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
         for (int t = threadIdx.x; t < 29 * 32; t += 512) master[(t >> 5) * NK_MASTER_LD + (t & 31)] = tab_g[t].x;
     }
     __syncthreads();
-    if (wave != 0) {
+    if constexpr (TP) {  // 64-column tiles: every lane works (a producer lane is not a column)
+        if (wave != 0) {
+            __builtin_amdgcn_s_setprio(2);
+            nk_producer_tp<DIAG, RM>(wave - 1, smem, codes8, m, ld, wmat, ldw, npos, lane, blockIdx.x * 64, R, pad);
+        } else {
+            sim_barrier();  // the producers' code stash (see nk_producer_tp)
+            nk_consumer<DIAG, TP_RING_OFF>(smem, rounds, lane, c, n, num_out);
+        }
+    } else if (wave != 0) {
         // the chain wave has slack every round; the producer that shares its SIMD does not
         __builtin_amdgcn_s_setprio(2);
         if (active) nk_producer<DIAG, RM>(wave - 1, smem, codes8, m, ld, wmat, ldw, npos, lane, c, R, pad, rounds);
     } else if (active) {
-        nk_consumer<DIAG>(smem, rounds, lane, c, n, num_out);
+        nk_consumer<DIAG, NK_RING_OFF>(smem, rounds, lane, c, n, num_out);
     }
 }
 
@@ -1610,6 +1801,17 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
     const int octs = (m + 7) / 8;
     const int rm = octs <= 18 * NK_ROUND_OCTS ? 18 : (octs <= NK_RMAX * NK_ROUND_OCTS ? NK_RMAX : 0);
     const bool diag = (sim_debug_mode() & 64) != 0;
+    static const bool tp_on = [] { const char *e = getenv("MSA_SIM_TP"); return e ? atoi(e) != 0 : true; }();
+    if (tp_on && rm == 18 && tcols == 64) {
+        auto tk = diag ? similarity_num_kernel<true, 18, true> : similarity_num_kernel<false, 18, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           tp_lds_bytes());
+        if (e != hipSuccess) return (int)e;
+        tk<<<(n + 63) / 64, 512, tp_lds_bytes(), s>>>(reinterpret_cast<const uint2 *>(codes8), m, n, ld, wmat, ldw,
+                                                      reinterpret_cast<const f32x2 *>(tab), npos, R, pad, (int)rounds,
+                                                      num_out, 64);
+        return 0;
+    }
     auto kern = rm == 18 ? (diag ? similarity_num_kernel<true, 18> : similarity_num_kernel<false, 18>)
               : rm == 0 ? (diag ? similarity_num_kernel<true, 0> : similarity_num_kernel<false, 0>)
                         : (diag ? similarity_num_kernel<true, NK_RMAX> : similarity_num_kernel<false, NK_RMAX>);
