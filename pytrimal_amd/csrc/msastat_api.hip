@@ -96,6 +96,7 @@ struct msa_ctx {
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, row_min, stats2;
+    DevBuf<unsigned long long> pairmasks;  // denominator kernel: bit-interleaved validity words of row pairs
     DevBuf<uint32_t> simcodes;  // similarity codes: [G8 + 1][ld] x 8 B (codes8) or [G8 + 1][2][ld] x 16 B (codes32)
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
@@ -407,6 +408,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         if (rc) return rc;
         HIPCHK(c, c->simnum.reserve((size_t)n + 64));
         HIPCHK(c, c->simden.reserve((size_t)c->nchunk * 32 + 64));
+        HIPCHK(c, c->pairmasks.reserve((size_t)c->nchunk * msak::den2_pm_ld(m) + 64));
         if (!c->stream2) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -420,7 +422,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         {
             ProfScope pd(c, "simden", sden);
             const int e = msak::launch_sim_den(sden, c->planes.p, c->nchunk, c->m_pad, m, n, c->wmat.p, c->ldw,
-                                               c->simden.p);
+                                               c->simden.p, c->pairmasks.p);
             if (e) return fail_hip(c, (hipError_t)e, "launch_sim_den");
         }
         HIPCHK(c, hipEventRecord(c->ev_join, sden));
@@ -765,7 +767,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
-    c->stats2.release(); c->simcodes.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
+    c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();

@@ -23,8 +23,9 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
 void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,
                        float *q_out, float *mdk_out);
 int sim_den_workgroups(int nchunk, int m);
+int den2_pm_ld(int m);
 int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
-                   int ldw, float *den_out);
+                   int ldw, float *den_out, unsigned long long *pairmasks);
 bool similarity_rc_fits(int m);
 int sim_tile_cols(int n, int cus, int min_cols);
 int sim_num_min_cols();

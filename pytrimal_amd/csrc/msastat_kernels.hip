@@ -889,6 +889,243 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
     if (lane < 32 && c < n) den_out[c] = den;
 }
 
+// ------------------------------------------------------------------------------------------
+// Denominators, two lanes per column.  The EXEC-masked loop above spends a scalar AND and an add on every pair
+// step and a lone wave issues one instruction per ~4 cycles.  Here lane 2 c + i of a wave works on column c
+// (32 columns per wave, as above) at the steps of parity i: one v_cndmask_b32 selects W or +0 for TWO steps
+// (the 64-bit SGPR mask holds valid(c, k + i) at bit 2 c + i: the validity words of rows k and k + 1,
+// bit-interleaved by den_pairmask_kernel), and the chain add of step k + i reads the term from lane i of the
+// pair through DPP (quad_perm [0,0,2,2] / [1,1,3,3]), so both lanes of a pair carry the same sum.  Per 16 steps:
+// 8 selects, 16 adds, one scalar load (8 masks) and two ds_read_b128 (this lane's 8 W values) -- 1.8
+// instructions per step instead of 2.26, 9.8 cycles instead of 12.3 (a dependent DPP add costs 5.75 cycles;
+// tools/ubench9.hip).  EXEC holds the pairs whose column has a residue in row j.
+// W rows reach the LDS by DMA one ROW ahead (wave-private double buffer; the DMA de-interleaves: dword
+// [g][i][t] of the line = W[16 g + 2 t + i]), which also hides the HBM latency that the loop above needs its L2
+// warm-up loads for.  Rows run from the 16-aligned k below j + 1 over whole blocks of 64 steps: W is strictly
+// upper triangular, and past row m the masks are zero, so the extra steps add +0.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long den_spread_bits(uint32_t x) {
+    unsigned long long v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__global__ __launch_bounds__(256) void den_pairmask_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                           int m, unsigned long long *__restrict__ pm, int pm_ld) {
+    const int kk = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+    if (kk >= pm_ld) return;
+    const uint32_t *masks = planes + ((size_t)7 * nchunk + chunk) * (size_t)m_pad;
+    const int r0 = 2 * kk;
+    const uint32_t a = r0 < m ? masks[r0] : 0u, b = r0 + 1 < m ? masks[r0 + 1] : 0u;
+    pm[(size_t)chunk * pm_ld + kk] = den_spread_bits(a) | (den_spread_bits(b) << 1);
+}
+int den2_pm_ld(int m) { return (((m + 16 + 63) / 64) * 64 + 128) / 2; }
+__host__ __device__ inline int den2_row_bytes(int m) { return ((m + 16 + 63) / 64 + 2) * 256; }
+
+__global__ __launch_bounds__(64 * DEN_WAVES) void sim_den2_kernel(const unsigned long long *__restrict__ pm, int pm_ld,
+                                                                  int nchunk, int m, int n,
+                                                                  const float *__restrict__ wmat, int ldw,
+                                                                  float *__restrict__ den_out, int row_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (chunk >= nchunk) return;
+    const unsigned long long *pmc = pm + (size_t)chunk * (size_t)pm_ld;
+    const int lane = threadIdx.x & 63;
+    const int mend = (m + 15) / 16 * 16;
+    const uint32_t buf0 = (uint32_t)(wave * 2 * row_bytes);
+    // DMA lane L fills dword L of a 256-byte line = [group L / 16][parity (L / 8) % 2][t = L % 8] <- element 16 g + 2 t + i
+    const uint32_t dma_pat = (uint32_t)(((lane >> 4) * 16 + 2 * (lane & 7) + ((lane >> 3) & 1)) * 4);
+    auto issue_row_dma = [&](int jr) {
+        if (jr + 1 >= m) return;
+        const int k0 = (jr + 1) / 16 * 16;
+        const int ng4 = ((mend - k0) / 16 + 3) / 4;
+        const float *src = wmat + ((size_t)jr * (size_t)ldw + (size_t)k0);
+        const uint32_t dst = buf0 + (uint32_t)(jr & 1) * (uint32_t)row_bytes;
+        int q = 0;
+        for (; q + 8 <= ng4; q += 8)  // the immediate offset moves the LDS and the global address alike
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "global_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\t"
+                         "global_load_lds_dword %1, %2 offset:512\n\tglobal_load_lds_dword %1, %2 offset:768\n\t"
+                         "global_load_lds_dword %1, %2 offset:1024\n\tglobal_load_lds_dword %1, %2 offset:1280\n\t"
+                         "global_load_lds_dword %1, %2 offset:1536\n\tglobal_load_lds_dword %1, %2 offset:1792"
+                         ::"s"(dst + (uint32_t)q * 256u), "v"(dma_pat), "s"(src + q * 64) : "m0", "memory");
+        for (; q < ng4; ++q)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                         ::"s"(dst + (uint32_t)q * 256u), "v"(dma_pat), "s"(src + q * 64) : "m0", "memory");
+    };
+    float den = 0.0f;
+    const unsigned long long t_start = sim_now();
+    unsigned long long n_steps = 0;
+    issue_row_dma(0);
+    unsigned long long pw = pmc[0];  // the pair word of rows (j, j ^ 1); the row loop fetches the next one by scalar load
+    for (int j = 0; j + 1 < m; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // row j's W has landed
+        issue_row_dma(j + 1);
+        const unsigned long long *pnext = pmc + ((j + 1) >> 1);
+        const unsigned long long half = (j & 1) ? ((pw >> 1) & 0x5555555555555555ull) : (pw & 0x5555555555555555ull);
+        const unsigned long long vj = half | (half << 1);  // both lanes of every column with a residue in row j
+        if (vj == 0ull) {  // no column of this chunk has a residue in row j
+            pw = *pnext;
+            continue;
+        }
+        const int k0 = (j + 1) / 16 * 16;
+        const int ng4 = ((mend - k0) / 16 + 3) / 4;
+        n_steps += (unsigned long long)ng4 * 64;
+        unsigned long long pw_next;
+        const unsigned long long *pmrow = pmc + (k0 >> 1);
+        const uint32_t waddr = buf0 + (uint32_t)(j & 1) * (uint32_t)row_bytes + (uint32_t)(lane & 1) * 32u;
+        // One loop pass = 64 steps: v1 = LDS address, v[2:33] = this lane's 32 W values, v[34:65] = the 32 terms,
+        // s[36:99] = 32 pair masks.  Scalar loads return out of order, so lgkmcnt(0) is the only usable wait and the
+        // latency a pass can hide is one pass: the next pass's masks and W are requested behind the selects and
+        // land under the 64 adds (~370 cycles; with 16-step passes every group stalled on its mask load).
+        asm volatile(
+            "s_mov_b64 s[10:11], exec\n\t"
+            "s_mov_b64 exec, %2\n\t"
+            "s_mov_b64 s[12:13], %4\n\t"
+            "s_sub_u32 s9, %3, 1\n\t"
+            "v_mov_b32 v1, %5\n\t"
+            "s_load_dwordx2 %1, %6, 0x0\n\t"  // the next row's pair word (a vector load would cost a round trip per row)
+            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\t"
+            "s_load_dwordx16 s[52:67], s[12:13], 0x40\n\t"
+            "s_load_dwordx16 s[68:83], s[12:13], 0x80\n\t"
+            "s_load_dwordx16 s[84:99], s[12:13], 0xc0\n\t"
+            "ds_read_b128 v[2:5], v1 offset:0\n\tds_read_b128 v[6:9], v1 offset:16\n\t"
+            "ds_read_b128 v[10:13], v1 offset:64\n\tds_read_b128 v[14:17], v1 offset:80\n\t"
+            "ds_read_b128 v[18:21], v1 offset:128\n\tds_read_b128 v[22:25], v1 offset:144\n\t"
+            "ds_read_b128 v[26:29], v1 offset:192\n\tds_read_b128 v[30:33], v1 offset:208\n\t"
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cndmask_b32_e64 v34, 0, v2, s[36:37]\n\t"
+            "v_cndmask_b32_e64 v35, 0, v3, s[38:39]\n\t"
+            "v_cndmask_b32_e64 v36, 0, v4, s[40:41]\n\t"
+            "v_cndmask_b32_e64 v37, 0, v5, s[42:43]\n\t"
+            "v_cndmask_b32_e64 v38, 0, v6, s[44:45]\n\t"
+            "v_cndmask_b32_e64 v39, 0, v7, s[46:47]\n\t"
+            "v_cndmask_b32_e64 v40, 0, v8, s[48:49]\n\t"
+            "v_cndmask_b32_e64 v41, 0, v9, s[50:51]\n\t"
+            "v_cndmask_b32_e64 v42, 0, v10, s[52:53]\n\t"
+            "v_cndmask_b32_e64 v43, 0, v11, s[54:55]\n\t"
+            "v_cndmask_b32_e64 v44, 0, v12, s[56:57]\n\t"
+            "v_cndmask_b32_e64 v45, 0, v13, s[58:59]\n\t"
+            "v_cndmask_b32_e64 v46, 0, v14, s[60:61]\n\t"
+            "v_cndmask_b32_e64 v47, 0, v15, s[62:63]\n\t"
+            "v_cndmask_b32_e64 v48, 0, v16, s[64:65]\n\t"
+            "v_cndmask_b32_e64 v49, 0, v17, s[66:67]\n\t"
+            "v_cndmask_b32_e64 v50, 0, v18, s[68:69]\n\t"
+            "v_cndmask_b32_e64 v51, 0, v19, s[70:71]\n\t"
+            "v_cndmask_b32_e64 v52, 0, v20, s[72:73]\n\t"
+            "v_cndmask_b32_e64 v53, 0, v21, s[74:75]\n\t"
+            "v_cndmask_b32_e64 v54, 0, v22, s[76:77]\n\t"
+            "v_cndmask_b32_e64 v55, 0, v23, s[78:79]\n\t"
+            "v_cndmask_b32_e64 v56, 0, v24, s[80:81]\n\t"
+            "v_cndmask_b32_e64 v57, 0, v25, s[82:83]\n\t"
+            "v_cndmask_b32_e64 v58, 0, v26, s[84:85]\n\t"
+            "v_cndmask_b32_e64 v59, 0, v27, s[86:87]\n\t"
+            "v_cndmask_b32_e64 v60, 0, v28, s[88:89]\n\t"
+            "v_cndmask_b32_e64 v61, 0, v29, s[90:91]\n\t"
+            "v_cndmask_b32_e64 v62, 0, v30, s[92:93]\n\t"
+            "v_cndmask_b32_e64 v63, 0, v31, s[94:95]\n\t"
+            "v_cndmask_b32_e64 v64, 0, v32, s[96:97]\n\t"
+            "v_cndmask_b32_e64 v65, 0, v33, s[98:99]\n\t"
+            "s_add_u32 s12, s12, 0x100\n\ts_addc_u32 s13, s13, 0\n\tv_add_u32_e32 v1, 0x100, v1\n\t"
+            "s_load_dwordx16 s[36:51], s[12:13], 0x0\n\t"
+            "s_load_dwordx16 s[52:67], s[12:13], 0x40\n\t"
+            "s_load_dwordx16 s[68:83], s[12:13], 0x80\n\t"
+            "s_load_dwordx16 s[84:99], s[12:13], 0xc0\n\t"
+            "ds_read_b128 v[2:5], v1 offset:0\n\tds_read_b128 v[6:9], v1 offset:16\n\t"
+            "ds_read_b128 v[10:13], v1 offset:64\n\tds_read_b128 v[14:17], v1 offset:80\n\t"
+            "ds_read_b128 v[18:21], v1 offset:128\n\tds_read_b128 v[22:25], v1 offset:144\n\t"
+            "ds_read_b128 v[26:29], v1 offset:192\n\tds_read_b128 v[30:33], v1 offset:208\n\t"
+            "v_add_f32_dpp %0, v34, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v34, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v35, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v35, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v36, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v36, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v37, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v37, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v38, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v38, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v39, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v39, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v40, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v40, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v41, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v41, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v42, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v42, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v43, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v43, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v44, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v44, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v45, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v45, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v46, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v46, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v47, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v47, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v48, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v48, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v49, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v49, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v50, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v50, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v51, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v51, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v52, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v52, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v53, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v53, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v54, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v54, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v55, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v55, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v56, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v56, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v57, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v57, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v58, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v58, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v59, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v59, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v60, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v60, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v61, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v61, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v62, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v62, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v63, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v63, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v64, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v64, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v65, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, v65, %0 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "s_sub_u32 s9, s9, 1\n\ts_cbranch_scc0 1b\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, s[10:11]"
+            : "+v"(den), "=&s"(pw_next)
+            : "s"(vj), "s"(ng4), "s"(pmrow), "v"(waddr), "s"(pnext)
+            : "s9", "s10", "s11", "s12", "s13", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "scc", "memory");
+        pw = pw_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {  // diagnostics (tools/sim_modes.py)
+        const unsigned long long dt = sim_now() - t_start;
+        if (chunk < 1024) g_den_ticks[chunk] = dt;
+        if (chunk == 0) {
+            g_sim_stamps[56] = dt;
+            g_sim_stamps[57] = n_steps;
+        }
+    }
+    const int c = chunk * 32 + (lane >> 1);
+    if ((lane & 1) == 0 && c < n) den_out[c] = den;
+}
+
 // Waves (= 32-column chunks) per denominator workgroup.  Each wave cycles through its m validity words once per
 // row; they are served by the scalar cache while the waves of a CU fit it together (4 x 8 KB at m = 2000 run at
 // 12.4 cycles per step; 4 x 14 KB at m = 3583 ran at 32: every group load exposed the L2 latency).
@@ -906,15 +1143,31 @@ int sim_den_workgroups(int nchunk, int m) {
     return (nchunk + w - 1) / w;
 }
 
+// pairmasks: [nchunk][den2_pm_ld(m)] u64 of scratch for the two-lanes-per-column kernel (nullptr: EXEC-masked kernel)
 int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int n, const float *wmat,
-                   int ldw, float *den_out) {
+                   int ldw, float *den_out, unsigned long long *pairmasks) {
     // The dynamic LDS request is a placement device: with it a CU cannot hold this workgroup and a numerator
-    // workgroup (81 KB) at once -- sharing a SIMD with the chain waves of the other kernel slows both by ~1.7x.
+    // workgroup at once -- sharing a SIMD with the chain waves of the other kernel slows both by ~1.7x.
+    static const bool pair_kernel = [] { const char *e = getenv("MSA_DEN_KERNEL"); return !(e && e[0] == 'e'); }();
+    const int waves = sim_den_waves(m);
+    const int row_bytes = den2_row_bytes(m);
+    const int lds2 = waves * 2 * row_bytes;
+    if (pair_kernel && pairmasks && lds2 <= 150 * 1024) {
+        const int pm_ld = den2_pm_ld(m);
+        den_pairmask_kernel<<<dim3((pm_ld + 255) / 256, nchunk), 256, 0, s>>>(planes, nchunk, m_pad, m, pairmasks, pm_ld);
+        const int lds = lds2 > DEN_LDS_BYTES ? lds2 : DEN_LDS_BYTES;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        sim_den2_kernel<<<sim_den_workgroups(nchunk, m), 64 * waves, lds, s>>>(pairmasks, pm_ld, nchunk, m, n, wmat, ldw,
+                                                                              den_out, row_bytes);
+        return 0;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEN_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    sim_den_kernel<<<sim_den_workgroups(nchunk, m), 64 * sim_den_waves(m), DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n,
-                                                                                             wmat, ldw, den_out);
+    sim_den_kernel<<<sim_den_workgroups(nchunk, m), 64 * waves, DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n, wmat, ldw,
+                                                                                  den_out);
     return 0;
 }
 
