@@ -1527,22 +1527,26 @@ __device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem,
         const uint8_t *cp[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) cp[w] = colptr(c0 + 16 * w + (lane >> 2));
-        uint4 *stash = reinterpret_cast<uint4 *>(smem + TP_RING_OFF + P * (RM * 1024)) + lane;
-        static_assert(TP_RING_OFF + SIM_NP * RM * 1024 <= tp_lds_bytes(), "code stash");
+        constexpr int HALF = RM > 18 ? 18 : RM;  // rounds per pass through the stash (7 x 18 KB fit the LDS)
+        uint4 *stash = reinterpret_cast<uint4 *>(smem + TP_RING_OFF + P * (HALF * 1024)) + lane;
+        static_assert(TP_RING_OFF + SIM_NP * HALF * 1024 <= tp_lds_bytes() && RM % HALF == 0, "code stash");
+#pragma unroll
+        for (int q0s = 0; q0s < RM; q0s += HALF) {
 #pragma unroll 1
-        for (int q = 0; q < RM; ++q) {
-            uint32_t word[4] = {0u, 0u, 0u, 0u};
+            for (int q = q0s; q < q0s + HALF; ++q) {
+                uint32_t word[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int g = q * NK_ROUND_OCTS + P * NK_OCTS + (b >> 1);
-                const size_t off = (size_t)(g >= G8 ? G8 : g) * (size_t)ld * 8u + (size_t)(4 * (b & 1) + i);
+                for (int b = 0; b < 4; ++b) {
+                    const int g = q * NK_ROUND_OCTS + P * NK_OCTS + (b >> 1);
+                    const size_t off = (size_t)(g >= G8 ? G8 : g) * (size_t)ld * 8u + (size_t)(4 * (b & 1) + i);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) word[w] |= (((uint32_t)cp[w][off] - (uint32_t)NK_K) * 4u) << (8 * b);
+                    for (int w = 0; w < 4; ++w) word[w] |= (((uint32_t)cp[w][off] - (uint32_t)NK_K) * 4u) << (8 * b);
+                }
+                stash[(q - q0s) * 64] = make_uint4(word[0], word[1], word[2], word[3]);
             }
-            stash[q * 64] = make_uint4(word[0], word[1], word[2], word[3]);
-        }
 #pragma unroll
-        for (int q = 0; q < RM; ++q) cod[q] = stash[q * 64];
+            for (int q = 0; q < HALF; ++q) cod[q0s + q] = stash[q * 64];
+        }
     }
     sim_barrier();  // every producer holds its codes before slice 0 and the ring take the stash over
     const uint8_t *mycol = colptr(c0 + lane);  // for the slice refresh a lane is a column
@@ -2055,8 +2059,9 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
     const int rm = octs <= 18 * NK_ROUND_OCTS ? 18 : (octs <= NK_RMAX * NK_ROUND_OCTS ? NK_RMAX : 0);
     const bool diag = (sim_debug_mode() & 64) != 0;
     static const bool tp_on = [] { const char *e = getenv("MSA_SIM_TP"); return e ? atoi(e) != 0 : true; }();
-    if (tp_on && rm == 18 && tcols == 64) {
-        auto tk = diag ? similarity_num_kernel<true, 18, true> : similarity_num_kernel<false, 18, true>;
+    if (tp_on && rm != 0 && tcols == 64) {
+        auto tk = rm == 18 ? (diag ? similarity_num_kernel<true, 18, true> : similarity_num_kernel<false, 18, true>)
+                           : (diag ? similarity_num_kernel<true, NK_RMAX, true> : similarity_num_kernel<false, NK_RMAX, true>);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            tp_lds_bytes());
         if (e != hipSuccess) return (int)e;
