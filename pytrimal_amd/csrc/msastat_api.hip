@@ -397,7 +397,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
-    HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 1) * c->ld + 64));  // sized for the larger format (codes32)
+    HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     HIPCHK(c, c->q.reserve((size_t)n + 64));
@@ -428,7 +428,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipEventRecord(c->ev_join, sden));
         {
             ProfScope pe(c, "encode");
-            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p);
+            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p, tcols);
         }
         {
             ProfScope pn(c, "simnum");

@@ -16,8 +16,9 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
                         uint32_t *dst, float *ident, float *wmat);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr);
+bool sim_num_transposed(int tcols);
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key);
+                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols);
 int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64_t ld, const float *wmat, int ldw,
                           const void *tab, int npos, float *num_out, int tcols);
 void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,

@@ -383,6 +383,51 @@ __global__ __launch_bounds__(256) void sim_encode8_kernel(const uint8_t *__restr
     codes8[(size_t)g * ld + c] = make_uint2(w[0], w[1]);
 }
 
+// numerator-kernel codes in the producers' transposed order (tiles of 64 columns):
+// [group of 16 rows g][tile][lane p] x 16 B; word w, byte b of lane p = 4 x table row of
+// (row 16 g + 4 b + p % 4, column 64 tile + 16 w + p / 4); row `npos` = skipped.  Group (m + 15) / 16 lies past
+// the last row: all skipped.
+__global__ __launch_bounds__(256) void sim_encodeT_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                          const uint8_t *__restrict__ lut_g, int npos,
+                                                          const int32_t *__restrict__ gaps_w,
+                                                          uint4 *__restrict__ codesT, int ntiles,
+                                                          unsigned long long *__restrict__ err_key) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), p = threadIdx.x & 63, g = blockIdx.y;
+    if (tile >= ntiles) return;
+    uint32_t word[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int c = tile * 64 + 16 * w + (p >> 2);
+        bool skipcol = true;
+        if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+        uint32_t x = 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row = g * 16 + 4 * b + (p & 3);
+            uint32_t idx = (uint32_t)npos;
+            if (row < m && c < n) {
+                const uint32_t byte = raw[(size_t)row * ld + c];
+                const uint32_t code = lut[byte];  // idx * 8, 224 = skipped, 0xFE / 0xFF = bad symbol
+                if (code >= 0xFEu) {
+                    if (!skipcol) {
+                        const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
+                                                       ((unsigned long long)(code & 1u) << 8) | byte;
+                        atomicMin(err_key, key);
+                    }
+                } else if (code != 224u) {
+                    idx = code >> 3;
+                }
+            }
+            x |= (idx * 4u) << (8 * b);
+        }
+        word[w] = x;
+    }
+    codesT[((size_t)g * ntiles + tile) * 64 + p] = make_uint4(word[0], word[1], word[2], word[3]);
+}
+
 __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
                                                            const uint8_t *__restrict__ lut_g, int npos,
                                                            const int32_t *__restrict__ gaps_w,
@@ -1510,49 +1555,32 @@ static_assert(NK_MASTER_BYTES <= TP_RING_OFF && TP_RING_OFF + NK_RING_BYTES <= 6
                   TP_WSTAGE_OFF + SIM_NP * 512 <= TP_SLICE1_OFF && TP_SLICE_OFF + 768 < 65536 && tp_lds_bytes() <= 160 * 1024,
               "LDS layout of the transposed producers");
 
-template <bool DIAG, int RM>
-__device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem, const uint2 *__restrict__ codes8, int m,
-                                               int64_t ld, const float *__restrict__ wmat, int ldw, int npos, int lane,
-                                               int c0, int R, int pad) {
+template <bool DIAG, int RM>  // RM = resident rounds (18 or 36), 0 = codes streamed two rounds ahead
+__device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem, const uint4 *__restrict__ codesT, int ntiles,
+                                               int m, const float *__restrict__ wmat, int ldw, int npos, int lane, int R,
+                                               int pad, int rounds) {
     const float *master = reinterpret_cast<const float *>(smem);
-    const int G8 = (m + 7) >> 3;
-    const int last_col = (int)ld - 1;
-    auto colptr = [&](int cc) { return reinterpret_cast<const uint8_t *>(codes8 + (cc < last_col ? cc : last_col)); };
-    // resident codes: word w, byte b of round q = 4 x entry of (column c0 + 16 w + lane / 4, row 8 (14 q + 2 P) + 4 b + lane % 4)
-    // Gathered byte by byte from the [oct][column] layout in a rolled loop, parked in this producer's part of the
-    // (still unused) LDS and read back into registers: unrolled, the 288 byte loads and their addresses spill.
-    uint4 cod[RM];
-    {
-        const int i = lane & 3;
-        const uint8_t *cp[4];
+    const int GG = (m + 15) >> 4;
+    constexpr bool RESIDENT = RM > 0;
+    const uint4 *mine = codesT + (size_t)blockIdx.x * 64 + lane;  // + group * ntiles * 64
+    auto fetch_codes = [&](uint4 &u, int q) {  // round q of this producer = row group 7 q + P
+        const int g = q * SIM_NP + P;
+        u = mine[(size_t)(g >= GG ? GG : g) * (size_t)ntiles * 64u];
+    };
+    uint4 cod[RESIDENT ? RM : 3];  // this producer's codes: all of them, or three rounds' worth
+    if (RESIDENT) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) cp[w] = colptr(c0 + 16 * w + (lane >> 2));
-        constexpr int HALF = RM > 18 ? 18 : RM;  // rounds per pass through the stash (7 x 18 KB fit the LDS)
-        uint4 *stash = reinterpret_cast<uint4 *>(smem + TP_RING_OFF + P * (HALF * 1024)) + lane;
-        static_assert(TP_RING_OFF + SIM_NP * HALF * 1024 <= tp_lds_bytes() && RM % HALF == 0, "code stash");
-#pragma unroll
-        for (int q0s = 0; q0s < RM; q0s += HALF) {
-#pragma unroll 1
-            for (int q = q0s; q < q0s + HALF; ++q) {
-                uint32_t word[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int g = q * NK_ROUND_OCTS + P * NK_OCTS + (b >> 1);
-                    const size_t off = (size_t)(g >= G8 ? G8 : g) * (size_t)ld * 8u + (size_t)(4 * (b & 1) + i);
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) word[w] |= (((uint32_t)cp[w][off] - (uint32_t)NK_K) * 4u) << (8 * b);
-                }
-                stash[(q - q0s) * 64] = make_uint4(word[0], word[1], word[2], word[3]);
-            }
-#pragma unroll
-            for (int q = 0; q < HALF; ++q) cod[q0s + q] = stash[q * 64];
-        }
+        for (int q = 0; q < (RESIDENT ? RM : 3); ++q) fetch_codes(cod[q], q);
     }
-    sim_barrier();  // every producer holds its codes before slice 0 and the ring take the stash over
-    const uint8_t *mycol = colptr(c0 + lane);  // for the slice refresh a lane is a column
+    // for the slice refresh a lane is a column: its code of row jn sits in lane 4 (lane % 16) + jn % 4 of the tile's
+    // group jn / 16, word lane / 16, byte (jn % 16) / 4
+    const uint8_t *tile_bytes = reinterpret_cast<const uint8_t *>(codesT + (size_t)blockIdx.x * 64);
     auto load_cj = [&](int jn) -> uint32_t {
         if (jn >= m - 1) return (uint32_t)npos;
-        return (uint32_t)mycol[(size_t)(jn >> 3) * (size_t)ld * 8u + (size_t)(jn & 7)] - (uint32_t)NK_K;
+        const int r16 = jn & 15;
+        const size_t off = ((size_t)(jn >> 4) * (size_t)ntiles * 64u + (size_t)(4 * (lane & 15) + (r16 & 3))) * 16u +
+                           (size_t)((lane >> 4) * 4 + (r16 >> 2));
+        return (uint32_t)tile_bytes[off] >> 2;
     };
     auto refresh = [&](int jn, uint32_t idx) {
         float4 *sl = reinterpret_cast<float4 *>(smem + ((jn & 1) ? TP_SLICE1_OFF : TP_SLICE_OFF)) + lane;
@@ -1588,10 +1616,15 @@ __device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem,
     uint32_t selv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(selv[k]) : "s"(0x03020400u + ((uint32_t)k << 8)));
-    auto round_work = [&](const uint4 &cq, int j, const float *wsrc_next, bool last_of_row) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this round's W has landed
+    auto round_work = [&](const uint4 &cq, int j, const float *wsrc_next, bool last_of_row,
+                          auto &&prefetch) __attribute__((always_inline)) {
+        // This round's W (DMA'd a round ago) has landed.  When streaming, the code load of the round after next,
+        // issued behind that DMA, may still be in flight (vmcnt counts in order).
+        if (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(dma_off), "s"(wsrc_next) : "m0", "memory");
+        prefetch();
         const uint32_t vlane = (uint32_t)lane * 4u + ((uint32_t)(j & 1) << 16);  // [lane * 4][code][row parity][0]
         const uint32_t cw[4] = {cq.x, cq.y, cq.z, cq.w};
         float tv[4][4];
@@ -1652,18 +1685,45 @@ __device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem,
         ++r;
     };
     const int nrows = m - 1 + pad;
-    for (int jj = 0; jj < nrows; ++jj) {
-        const int q0 = q0_of(jj);
-        const float *wrow = wrow_of(jj);
-        nk_unroll<0, RM>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int Q = decltype(qc)::value;
-            if (Q >= q0 && Q < R) {
-                const bool last = Q == R - 1;
-                const float *wsrc_next = last ? wrow_of(jj + 1) + q0_of(jj + 1) * (NK_ROUND_OCTS * 8)
-                                              : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
-                round_work(cod[Q], jj, wsrc_next, last);
-            }
-        });
+    if constexpr (RESIDENT) {
+        (void)rounds;
+        for (int jj = 0; jj < nrows; ++jj) {
+            const int q0 = q0_of(jj);
+            const float *wrow = wrow_of(jj);
+            nk_unroll<0, RM>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int Q = decltype(qc)::value;
+                if (Q >= q0 && Q < R) {
+                    const bool last = Q == R - 1;
+                    const float *wsrc_next = last ? wrow_of(jj + 1) + q0_of(jj + 1) * (NK_ROUND_OCTS * 8)
+                                                  : wrow + (Q + 1) * (NK_ROUND_OCTS * 8);
+                    round_work(cod[Q], jj, wsrc_next, last, [] {});
+                }
+            });
+        }
+    } else {
+        // (row, round) sequence: row jj runs rounds q0(jj) .. R-1.  Codes are fetched TWO rounds ahead (an L2 miss
+        // takes longer than a round) into three rotating register sets.
+        struct Pos {
+            int j, q;
+        };
+        auto next = [&](Pos p) { return p.q == R - 1 ? Pos{p.j + 1, q0_of(p.j + 1)} : Pos{p.j, p.q + 1}; };
+        Pos pos = {0, q0_of(0)};
+        Pos pos1 = next(pos);
+        fetch_codes(cod[0], pos.q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // order: [codes(0)] [W(0) DMA above] -> codes(1) is the young one
+        fetch_codes(cod[1], pos1.q);
+        auto step = [&](const uint4 &cur, uint4 &far) __attribute__((always_inline)) {
+            const Pos pos2 = next(pos1);
+            const float *wsrc_next = wrow_of(pos1.j) + pos1.q * (NK_ROUND_OCTS * 8);
+            round_work(cur, pos.j, wsrc_next, pos.q == R - 1, [&] { fetch_codes(far, pos2.q); });
+            pos = pos1;
+            pos1 = pos2;
+        };
+        for (int rr = 0; rr < rounds; rr += 3) {
+            step(cod[0], cod[2]);
+            if (rr + 1 < rounds) step(cod[1], cod[0]);
+            if (rr + 2 < rounds) step(cod[2], cod[1]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the W prefetch past the end
     if (stamp && lane == 0)
@@ -1686,12 +1746,12 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
         for (int t = threadIdx.x; t < 29 * 32; t += 512) master[(t >> 5) * NK_MASTER_LD + (t & 31)] = tab_g[t].x;
     }
     __syncthreads();
-    if constexpr (TP) {  // 64-column tiles: every lane works (a producer lane is not a column)
+    if constexpr (TP) {  // 64-column tiles, codes in the transposed layout: every lane works (a producer lane is not a column)
         if (wave != 0) {
             __builtin_amdgcn_s_setprio(2);
-            nk_producer_tp<DIAG, RM>(wave - 1, smem, codes8, m, ld, wmat, ldw, npos, lane, blockIdx.x * 64, R, pad);
+            nk_producer_tp<DIAG, RM>(wave - 1, smem, reinterpret_cast<const uint4 *>(codes8), (int)gridDim.x, m, wmat, ldw,
+                                     npos, lane, R, pad, rounds);
         } else {
-            sim_barrier();  // the producers' code stash (see nk_producer_tp)
             nk_consumer<DIAG, TP_RING_OFF>(smem, rounds, lane, c, n, num_out);
         }
     } else if (wave != 0) {
@@ -1978,7 +2038,8 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
 }
 
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key);
+                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols);
+bool sim_num_transposed(int tcols);
 
 // Columns per similarity workgroup: a full wave.  The kernel's time is (pair steps) x (cycles per step)
 // whatever the column count, and the LDS time per instruction does not depend on the active lanes, so
@@ -2037,8 +2098,22 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
 // the numerator kernel keeps every producer's codes in its registers: that bounds the row count
 bool similarity_rc_fits(int m) { return (m + 7) / 8 <= NK_RMAX * NK_ROUND_OCTS; }
 
+// The numerator kernel's producers read the transposed layout on 64-column tiles (MSA_SIM_TP=0: the [oct][column]
+// layout, which narrower tiles -- a diagnostic -- always use).
+bool sim_num_transposed(int tcols) {
+    static const bool tp_on = [] { const char *e = getenv("MSA_SIM_TP"); return e ? atoi(e) != 0 : true; }();
+    return tp_on && tcols == 64;
+}
+
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
-                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key) {
+                        const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols) {
+    if (sim_num_transposed(tcols)) {
+        const int ntiles = (n + 63) / 64;
+        dim3 grid((unsigned)((ntiles + 3) / 4), (m + 15) / 16 + 1);
+        sim_encodeT_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint4 *>(codes8), ntiles,
+                                                err_key);
+        return;
+    }
     dim3 grid((unsigned)((ld + 255) / 256), (m + 7) / 8 + 1);
     sim_encode8_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, npos, gaps_w, reinterpret_cast<uint2 *>(codes8), err_key,
                                             NK_K);
@@ -2058,10 +2133,10 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
     const int octs = (m + 7) / 8;
     const int rm = octs <= 18 * NK_ROUND_OCTS ? 18 : (octs <= NK_RMAX * NK_ROUND_OCTS ? NK_RMAX : 0);
     const bool diag = (sim_debug_mode() & 64) != 0;
-    static const bool tp_on = [] { const char *e = getenv("MSA_SIM_TP"); return e ? atoi(e) != 0 : true; }();
-    if (tp_on && rm != 0 && tcols == 64) {
+    if (sim_num_transposed(tcols)) {
         auto tk = rm == 18 ? (diag ? similarity_num_kernel<true, 18, true> : similarity_num_kernel<false, 18, true>)
-                           : (diag ? similarity_num_kernel<true, NK_RMAX, true> : similarity_num_kernel<false, NK_RMAX, true>);
+                : rm == 0 ? (diag ? similarity_num_kernel<true, 0, true> : similarity_num_kernel<false, 0, true>)
+                          : (diag ? similarity_num_kernel<true, NK_RMAX, true> : similarity_num_kernel<false, NK_RMAX, true>);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            tp_lds_bytes());
         if (e != hipSuccess) return (int)e;
