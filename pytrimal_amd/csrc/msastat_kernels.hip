@@ -1193,7 +1193,8 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
                    int ldw, float *den_out, unsigned long long *pairmasks) {
     // The dynamic LDS request is a placement device: with it a CU cannot hold this workgroup and a numerator
     // workgroup at once -- sharing a SIMD with the chain waves of the other kernel slows both by ~1.7x.
-    static const bool pair_kernel = [] { const char *e = getenv("MSA_DEN_KERNEL"); return !(e && e[0] == 'e'); }();
+    const char *which = getenv("MSA_DEN_KERNEL");  // "exec": the EXEC-masked kernel (diagnostics, parity tests)
+    const bool pair_kernel = !(which && which[0] == 'e');
     const int waves = sim_den_waves(m);
     const int row_bytes = den2_row_bytes(m);
     const int lds2 = waves * 2 * row_bytes;
@@ -2101,8 +2102,8 @@ bool similarity_rc_fits(int m) { return (m + 7) / 8 <= NK_RMAX * NK_ROUND_OCTS; 
 // The numerator kernel's producers read the transposed layout on 64-column tiles (MSA_SIM_TP=0: the [oct][column]
 // layout, which narrower tiles -- a diagnostic -- always use).
 bool sim_num_transposed(int tcols) {
-    static const bool tp_on = [] { const char *e = getenv("MSA_SIM_TP"); return e ? atoi(e) != 0 : true; }();
-    return tp_on && tcols == 64;
+    const char *e = getenv("MSA_SIM_TP");
+    return (e ? atoi(e) != 0 : true) && tcols == 64;
 }
 
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,

@@ -308,6 +308,19 @@ def test_similarity_streaming_numerator(ctx, monkeypatch):
     _sim_parity(ctx, synth_msa(4040, 20, 80))
 
 
+@pytest.mark.parametrize("switch", ["MSA_SIM_TP=0", "MSA_DEN_KERNEL=exec"])
+@pytest.mark.parametrize("shape", [(9, 33), (225, 96), (640, 257), (2017, 33), (4040, 20)])
+def test_similarity_fallback_kernels(ctx, monkeypatch, switch, shape):
+    """The kernels the defaults replaced stay selectable and exact: numerator producers on the [oct][column] codes
+    (a producer lane = a column, 16-byte ring stores), and the EXEC-masked denominator kernel (one lane per
+    column), which also serves alignments whose W rows do not fit the LDS."""
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    name, value = switch.split("=")
+    monkeypatch.setenv(name, value)
+    m, n = shape
+    _sim_parity(ctx, synth_msa(m, n, 515 + m))
+
+
 def test_similarity_at_resident_limit(ctx, monkeypatch):
     monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     _sim_parity(ctx, synth_msa(2016, 40, 78))
