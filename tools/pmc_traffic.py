@@ -42,7 +42,8 @@ def traffic(kernel):
     return int((2 * sum(f) + sum(w)) * 1024)
 
 
-t = {"C3:simnum": traffic("similarity_num_kernel"), "C3:simden": traffic("sim_den_kernel"),
+t = {"C3:simnum": traffic("similarity_num_kernel"),
+     "C3:simden": traffic("sim_den_kernel") + traffic("sim_den2_kernel") + traffic("den_pairmask_kernel"),
      "C3:pairs": traffic("pair_counts_kernel"), "C3:gaps": traffic("gap_counts_kernel")}
 t["C3:sim"] = t["C3:simnum"] + t["C3:simden"]
 t["_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch; 'sim' = numerator + denominator kernel; "
