@@ -51,7 +51,7 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     Within a rank the shard is trimmed by `threads` threads (`trim` is re-entrant, one device context
     per thread): the similarity kernels of one alignment occupy 95 of the 256 CUs (each chain workgroup
     claims a CU), so alignments in flight side by side raise the throughput of a GPU until the CUs are
-    taken (1000 x 4000 alignments: 1.1 / 2.0 / 2.5 / 2.8 M columns/s with 1 / 2 / 3-4 / 6 threads).
+    taken (1000 x 4000 alignments: 1.2 / 2.2 / 2.8 / 3.2 M columns/s with 1 / 2 / 3 / 4 threads).
 
     `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
     which have no device).
