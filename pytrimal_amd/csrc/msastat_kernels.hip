@@ -253,12 +253,29 @@ __global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const flo
         if (wave == 0) {
             const int jb = t * IDS_TJ;
             const int cnt = min(IDS_TJ, m - jb);
-            for (int r = 0; r < cnt; ++r) {
-                const float v = tile[t & 1][r][lane];
-                if (jb + r != i) {
-                    mx = mx < v ? v : mx;
-                    mn = mn > v ? v : mn;
-                    avg += v;
+            if (cnt == IDS_TJ && (jb + IDS_TJ <= i0 || jb >= i0 + 64)) {
+                // a full tile away from this block's diagonal: 16 LDS reads in flight per batch (one read per
+                // iteration exposes the LDS latency 2000 times: 150 us at m = 2000)
+#pragma unroll 1
+                for (int r0 = 0; r0 < IDS_TJ; r0 += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = tile[t & 1][r0 + u][lane];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        mx = mx < v[u] ? v[u] : mx;
+                        mn = mn > v[u] ? v[u] : mn;
+                        avg += v[u];
+                    }
+                }
+            } else {
+                for (int r = 0; r < cnt; ++r) {
+                    const float v = tile[t & 1][r][lane];
+                    if (jb + r != i) {
+                        mx = mx < v ? v : mx;
+                        mn = mn > v ? v : mn;
+                        avg += v;
+                    }
                 }
             }
         }
@@ -282,7 +299,21 @@ __global__ __launch_bounds__(256) void identity_final_kernel(const float *__rest
     __syncthreads();
     if (threadIdx.x) return;
     float a = 0.0f, x = 0.0f;
-    for (int i = 0; i < m; ++i) {
+    int i = 0;
+    for (; i + 16 <= m; i += 16) {  // 32 LDS reads in flight, then the two sequential sums
+        float va[16], vx[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            va[u] = stage[i + u];
+            vx[u] = stage[m + i + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            a += va[u];
+            x += vx[u];
+        }
+    }
+    for (; i < m; ++i) {
         a += stage[i];
         x += stage[m + i];
     }
