@@ -1879,9 +1879,22 @@ __global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restri
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= m) return;
-    const uint8_t *p = raw + (size_t)row * ld;
+    // 16 bytes per lane and load (rows are 64-byte aligned, ld % 64 == 0; keep_res has 64 bytes of slack); bytes at
+    // or past n are masked off
+    const uint4 *p = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld);
+    const uint4 *k = reinterpret_cast<const uint4 *>(keep_res);
     int cnt = 0;
-    for (int c = lane; c < n; c += 64) cnt += (keep_res[c] && p[c] != '-') ? 1 : 0;
+    for (int q = lane; q * 16 < n; q += 64) {
+        const uint4 x = p[q], kk = k[q];
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ks[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int left = n - (q * 16 + w * 4);  // bytes of this word inside the row
+            const uint32_t inside = left >= 4 ? 0x80808080u : (left <= 0 ? 0u : (0x80808080u >> (8 * (4 - left))));
+            const uint32_t kept = ~zero_bytes(ks[w]) & 0x80808080u, gap = zero_bytes(xs[w] ^ 0x2d2d2d2du);
+            cnt += __popc(kept & ~gap & inside);
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
     if (lane == 0) row_nongap[row] = cnt;
