@@ -321,6 +321,13 @@ def test_similarity_fallback_kernels(ctx, monkeypatch, switch, shape):
     _sim_parity(ctx, synth_msa(m, n, 515 + m))
 
 
+def test_similarity_many_rows_few_columns(ctx, monkeypatch):
+    """m = 9000: one denominator wave per workgroup (its W row buffers take 72 KB of LDS), streamed numerator
+    codes over 81 rounds per row, a single partial column tile."""
+    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+    _sim_parity(ctx, synth_msa(9000, 8, 81))
+
+
 def test_similarity_at_resident_limit(ctx, monkeypatch):
     monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     _sim_parity(ctx, synth_msa(2016, 40, 78))
