@@ -1643,7 +1643,7 @@ __device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem,
     };
     {
         const float *src = wrow_of(0) + q0_of(0) * (NK_ROUND_OCTS * 8);
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(dma_off), "s"(src) : "m0", "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(dma_off), "s"(src) : "m0", "memory");
     }
     uint32_t selv[4];
 #pragma unroll
@@ -1655,7 +1655,7 @@ __device__ __forceinline__ void nk_producer_tp(const int P, unsigned char *smem,
         if (RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(dma_off), "s"(wsrc_next) : "m0", "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(dma_off), "s"(wsrc_next) : "m0", "memory");
         prefetch();
         const uint32_t vlane = (uint32_t)lane * 4u + ((uint32_t)(j & 1) << 16);  // [lane * 4][code][row parity][0]
         const uint32_t cw[4] = {cq.x, cq.y, cq.z, cq.w};
