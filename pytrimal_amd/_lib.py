@@ -310,6 +310,15 @@ class Context:
 _tls = threading.local()
 
 
+def reset_thread_context():
+    """Drop this thread's context (the next `trim` creates a new one, which re-reads the MSA_* diagnostic
+    switches: the library reads them once per context)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is not None:
+        ctx.close()
+    _tls.ctx = None
+
+
 def thread_context():
     """A per-thread context, so that `trim` is re-entrant across threads like the reference
     (``_trimal.pyx:1305-1316``)."""

@@ -21,6 +21,8 @@
 
 namespace {
 
+constexpr int MSA_E_FALLBACK = -100;  // internal: a device path does not apply, take the host path (never returned by the ABI)
+
 template <typename T>
 struct DevBuf {  // grow-only device allocation, reused across uploads
     T *p = nullptr;
@@ -93,6 +95,11 @@ struct msa_ctx {
     DevBuf<int32_t> gaps, indets;
     bool have_gaps = false;
     DevBuf<float> ident, wmat;
+    DevBuf<float> wlow;        // strictly lower triangular mirror of wmat (binade-exact similarity kernel)
+    DevBuf<uint8_t> codeT;     // column-major similarity codes of that kernel
+    DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
+    PinBuf<int32_t> h_simcols;
+    msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, row_min, stats2;
@@ -130,6 +137,11 @@ struct msa_ctx {
 };
 
 namespace {
+
+struct TuneScope {  // the context's diagnostic switches, visible to the launch wrappers for the duration of a call
+    explicit TuneScope(msa_ctx *c) { msak::set_tuning(&c->tuning); }
+    ~TuneScope() { msak::set_tuning(nullptr); }
+};
 
 int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
     std::snprintf(c->hip_err, sizeof(c->hip_err), "%s: %s", what, hipGetErrorString(e));
@@ -297,9 +309,12 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         HIPCHK(c, c->ident.reserve(fsz));
         HIPCHK(c, hipMemsetAsync(c->ident.p, 0, fsz * sizeof(float), c->stream));
     }
+    const size_t lsz = (msak::bx_wlow_rows(c->m) + 2) * (size_t)c->ldw;  // rows past m: zeros the kernel's prefetch may touch
     if (need_w) {
         HIPCHK(c, c->wmat.reserve(fsz));
         HIPCHK(c, hipMemsetAsync(c->wmat.p, 0, fsz * sizeof(float), c->stream));
+        HIPCHK(c, c->wlow.reserve(lsz));
+        HIPCHK(c, hipMemsetAsync(c->wlow.p, 0, lsz * sizeof(float), c->stream));
     }
     if (want_counts) {
         HIPCHK(c, c->hit.reserve((size_t)c->m * c->m + 1));
@@ -311,7 +326,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         ProfScope ps(c, "pairs");
         msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
                                  want_counts ? c->hit.p : nullptr, want_counts ? c->dst.p : nullptr,
-                                 need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr);
+                                 need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr);
     }
     HIPCHK(c, hipGetLastError());
     if (need_ident) c->have_ident = true;
@@ -359,12 +374,34 @@ void build_tables(const int32_t *vhash, const float *dist, int npos, uint8_t ind
         }
 }
 
+// MDK / Q and the first-bad-residue key back to the host (one synchronisation)
+int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
+    HIPCHK(c, c->h_u64.reserve(1));
+    HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32, (size_t)2 * n + 64)));
+    HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    SYNC(c);
+    const unsigned long long key = c->h_u64.p[0];
+    if (key != ~0ull) {
+        if (detail) {
+            detail->col = static_cast<int32_t>(key >> 40);
+            detail->row = static_cast<int32_t>((key >> 16) & 0xFFFFFFull);
+            detail->byte = static_cast<int32_t>(key & 0xFF);
+        }
+        return ((key >> 8) & 1ull) ? MSA_E_UNDEFINED_SYMBOL : MSA_E_INCORRECT_SYMBOL;
+    }
+    std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
+    if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
+    return MSA_OK;
+}
+
 int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed,
                float *mdk_out, float *q_out, msa_err_detail *detail) {
     if (npos < 1 || npos > 28) return MSA_E_INVALID;
     int rc = run_pairs(c, false, true, false);
     if (rc) return rc;
-    rc = ensure_gaps(c, false);
+    rc = ensure_gaps(c, c->tuning.sim_kernel == 0);  // (the binade-exact kernel's column list is built on the host)
     if (rc) return rc;
     const int m = c->m, n = c->n;
     // tables
@@ -389,12 +426,47 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         gw_dev = c->gaps_w.p;
     }
     const int G8 = (m + 7) / 8;
-    // kernel choice: numerator + denominator kernels (the numerator kernel keeps its codes in registers when
-    // the rows fit, m <= 2016, and streams them otherwise); MSA_SIM_KERNEL=pc forces the single-chain
-    // producer/consumer kernel (parity-tested at every size).
-    const char *which = getenv("MSA_SIM_KERNEL");
-    const bool split = !(which && which[0] == 'p');
-    // the denominator workgroups occupy CUs of their own: spread the numerator columns over the others
+    // Kernel choice (MSA_SIM_KERNEL, read when the context was created): the binade-exact kernel by default;
+    // "chain" = the numerator + denominator chain kernels of round 1, "pc" = the single-chain producer/consumer
+    // kernel.  All three are bit-exact and parity-tested against each other and the oracle.
+    if (c->tuning.sim_kernel == 0) {
+        HIPCHK(c, c->codeT.reserve((size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64));
+        HIPCHK(c, c->errkey.reserve(1));
+        HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
+        HIPCHK(c, c->q.reserve((size_t)n + 64));
+        HIPCHK(c, c->mdk.reserve((size_t)n + 64));
+        HIPCHK(c, c->simnum.reserve((size_t)n + 64));
+        HIPCHK(c, c->simden.reserve((size_t)n + 64));
+        {
+            ProfScope pe(c, "encode");
+            msak::launch_sim_encode_cm(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
+        }
+        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; sorted by gap count so that the columns of a
+        // wave cross their binades in the same rounds (their denominators grow alike)
+        const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
+        const int cw = msak::bx_cols_per_wave();
+        HIPCHK(c, c->h_simcols.reserve((size_t)n + 8));
+        int nact = 0;
+        for (int j = 0; j < n; ++j)
+            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) c->h_simcols.p[nact++] = j;
+        std::stable_sort(c->h_simcols.p, c->h_simcols.p + nact, [&](int32_t x, int32_t y) { return gw_host[x] < gw_host[y]; });
+        int npad = nact;
+        while (npad % cw) c->h_simcols.p[npad++] = n;  // the all-skipped column behind the last one
+        HIPCHK(c, c->simcols.reserve((size_t)n + 8));
+        if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
+        {
+            ProfScope ps(c, "sim");
+            const int e = msak::launch_similarity_bx(c->stream, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
+                                                     c->ldw, c->tab.p, c->simnum.p, c->simden.p);
+            if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
+        }
+        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
+        HIPCHK(c, hipGetLastError());
+        return fetch_similarity(c, n, mdk_out, q_out, detail);
+    }
+    const bool split = c->tuning.sim_kernel == 1;
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
@@ -415,7 +487,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
         ProfScope ps(c, "sim");
-        const bool serial = getenv("MSA_SIM_SERIAL") != nullptr;  // diagnostics: both kernels on one stream
+        const bool serial = c->tuning.sim_serial != 0;  // diagnostics: both kernels on one stream
         hipStream_t sden = serial ? c->stream : c->stream2;
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(sden, c->ev_fork, 0));
@@ -451,23 +523,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, c->h_u64.reserve(1));
-    HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    SYNC(c);
-    const unsigned long long key = c->h_u64.p[0];
-    if (key != ~0ull) {
-        if (detail) {
-            detail->col = static_cast<int32_t>(key >> 40);
-            detail->row = static_cast<int32_t>((key >> 16) & 0xFFFFFFull);
-            detail->byte = static_cast<int32_t>(key & 0xFF);
-        }
-        return ((key >> 8) & 1ull) ? MSA_E_UNDEFINED_SYMBOL : MSA_E_INCORRECT_SYMBOL;
-    }
-    std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
-    if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
-    return MSA_OK;
+    return fetch_similarity(c, n, mdk_out, q_out, detail);
 }
 
 int overlap(msa_ctx *c, float residue_overlap, float *out) {
@@ -593,7 +649,7 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
 // round-based independent-set kernel on the device, mask to the host (m bytes).
 int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     const int m = c->m;
-    if (m < 2) return MSA_E_INVALID;
+    if (m < 2) return MSA_E_FALLBACK;
     int rc = run_pairs(c, true, false, false);
     if (rc) return rc;
     std::vector<int32_t> lengths;
@@ -613,7 +669,7 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
         ProfScope ps(c, "cluster");
         if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, max_identity, c->col_ok.p,
                                  c->keep_seq_d.p, c->equal.p) != 0)
-            return MSA_E_INVALID;  // too many sequences for the LDS bit sets: host path
+            return MSA_E_FALLBACK;  // too many sequences for the LDS bit sets: host path
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
@@ -628,13 +684,13 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
 // selectMethod mean, same order of operations), every probe is one run of the device clustering: no m*m transfer.
 int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     const int m = c->m;
-    if (m < 2 || clusters < 1) return MSA_E_INVALID;
+    if (m < 2 || clusters < 1) return MSA_E_FALLBACK;
     // below ~2000 sequences the m*m copy (< 16 MB) is cheaper than a synchronisation per probe: host path
-    if (m < 2000 && !getenv("MSA_DEVICE_CLUSTERS")) return MSA_E_INVALID;
+    if (c->tuning.device_clusters == 0 || (m < 2000 && c->tuning.device_clusters < 0)) return MSA_E_FALLBACK;
     int rc = run_pairs(c, true, false, false);
     if (rc) return rc;
     const size_t words = msak::cluster_adj_words(m);
-    if ((size_t)4 * words * sizeof(uint32_t) > 60 * 1024) return MSA_E_INVALID;  // host path
+    if ((size_t)4 * words * sizeof(uint32_t) > 60 * 1024) return MSA_E_FALLBACK;  // host path
     HIPCHK(c, c->row_avg.reserve(m + 64));
     HIPCHK(c, c->row_max.reserve(m + 64));
     HIPCHK(c, c->row_min.reserve(m + 64));
@@ -673,7 +729,7 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
             ProfScope ps(c, "cluster");
             if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, threshold, c->col_ok.p,
                                      c->keep_seq_d.p, c->equal.p) != 0)
-                return MSA_E_INVALID;
+                return MSA_E_FALLBACK;
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->equal.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -747,6 +803,7 @@ int msa_ctx_create(int device, msa_ctx **out) {
     msa_ctx *c = new (std::nothrow) msa_ctx();
     if (!c) return MSA_E_NOMEM;
     c->device = device;
+    c->tuning = msak::tuning_from_env();
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cus = cus;
@@ -766,7 +823,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
-    c->wmat.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
@@ -900,6 +957,7 @@ int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t 
                    float *mdk_out, float *q_out, msa_err_detail *detail) {
     if (!c || !c->raw || !vhash || !dist || !mdk_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     return similarity(c, vhash, dist, npos, gaps_windowed, mdk_out, q_out, detail);
 }
 
@@ -912,7 +970,8 @@ int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
 namespace {
 // MSA_TRACE=1: host-side wall-clock marks of msa_trim on stderr (diagnostics)
 struct TrimTrace {
-    bool on = getenv("MSA_TRACE") != nullptr;
+    bool on = false;
+    explicit TrimTrace(bool enabled) : on(enabled) {}
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
     void mark(const char *what) {
         if (!on) return;
@@ -928,7 +987,8 @@ struct TrimTrace {
 int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    TrimTrace trace;
+    TrimTrace trace(c->tuning.trace != 0);
+    TuneScope tune(c);
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
@@ -973,15 +1033,18 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         rc = remove_duplicates(c, keep_seq);
         if (rc) return rc;
         seq_mode = true;
-    } else if (p->max_identity != -1 && p->clusters == -1 && device_representatives(c, p->max_identity, keep_seq) == MSA_OK) {
-        // RepresentativeTrimmer(identity_threshold): clustered on the device, only the mask comes back
-        seq_mode = true;
-    } else if (p->clusters != -1 && device_cluster_count(c, p->clusters, keep_seq) == MSA_OK) {
-        // RepresentativeTrimmer(clusters=K): the threshold search probes the device clustering
-        seq_mode = true;
     } else if (p->clusters != -1 || p->max_identity != -1) {
-        // very large m (the bit sets of the clustering no longer fit the LDS): the m*m identities come to
-        // the host for the greedy clustering
+        // RepresentativeTrimmer: clustered on the device, only the mask comes back (identity_threshold: one run of
+        // the clustering kernels; clusters=K: the threshold search probes them).  MSA_E_FALLBACK = "not applicable
+        // here" (bit sets larger than the LDS, or a small m where the m*m copy is cheaper than a synchronisation
+        // per probe); every other code is a real failure and propagates.
+        rc = p->clusters == -1 ? device_representatives(c, p->max_identity, keep_seq)
+                               : device_cluster_count(c, p->clusters, keep_seq);
+        if (rc != MSA_OK && rc != MSA_E_FALLBACK) return rc;
+        seq_mode = true;
+    }
+    if (seq_mode && rc == MSA_E_FALLBACK) {
+        // the m*m identities come to the host for the greedy clustering
         std::vector<float> ident;
         rc = fetch_ident(c, ident);
         if (rc) return rc;
@@ -991,8 +1054,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         float thr = p->max_identity;
         if (p->clusters != -1) thr = msah::cutpoint_clusters(ident.data(), m, lengths.data(), m, p->clusters);
         msah::representatives(ident.data(), m, lengths.data(), m, thr, keep_seq);
-        seq_mode = true;
-    } else if (p->residue_overlap != -1 && p->sequence_overlap != -1) {
+    } else if (!seq_mode && p->residue_overlap != -1 && p->sequence_overlap != -1) {
         std::vector<float> ov(m);
         rc = overlap(c, p->residue_overlap, ov.data());
         if (rc) return rc;

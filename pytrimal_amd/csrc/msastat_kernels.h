@@ -5,6 +5,28 @@
 
 namespace msak {
 
+// Diagnostic switches (environment variables MSA_*), read ONCE when a context is created and handed to the
+// launch wrappers through a thread-local pointer for the duration of an API call (contexts are per thread).
+struct Tuning {
+    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact (default), 1 "chain" numerator + denominator kernels, 2 "pc"
+    int sim_tcols = 0;         // MSA_SIM_TCOLS: column-tile width of the chain kernels (0 = 64)
+    int sim_mode = 0;          // MSA_SIM_MODE: in-kernel stamps / ablations of the chain kernels
+    int sim_tp = 1;            // MSA_SIM_TP=0: column-per-lane producers
+    int den_waves = 0;         // MSA_DEN_WAVES
+    int den_exec = 0;          // MSA_DEN_KERNEL=exec
+    int sim_serial = 0;        // MSA_SIM_SERIAL: numerator and denominator kernel on one stream
+    int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
+    int trace = 0;             // MSA_TRACE
+    int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)
+    int bx_r0 = -1;            // MSA_BX_R0: rows evaluated in order before the first round (-1 = default)
+    int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
+};
+Tuning tuning_from_env();
+void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults
+const Tuning &tuning();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
+int set_max_lds_once(const void *kernel, int bytes);
+
 constexpr int PAIR_TI = 8;   // rows "i" per wave in pair_counts (wave-uniform, SGPR operands)
 constexpr int PAIR_TJ = 2;   // rows "j" per lane at most (1 below ~3000 rows: twice the waves, 0.77 -> 0.52 ms at 2000 x 10000); m_pad % 128 == 0
 
@@ -13,7 +35,16 @@ void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t
 void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
                        int32_t *indets);
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat);
+                        uint32_t *dst, float *ident, float *wmat, float *wlow);
+// binade-exact similarity kernel (msastat_simx.hip)
+int64_t bx_ldk(int m);
+int bx_cols_pad(int n);
+size_t bx_wlow_rows(int m);
+void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
+                          const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key);
+int bx_cols_per_wave();
+int launch_similarity_bx(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
+                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr);
 bool sim_num_transposed(int tcols);

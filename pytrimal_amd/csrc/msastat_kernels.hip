@@ -18,7 +18,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "msastat_kernels.h"
 
@@ -137,7 +140,7 @@ template <int TI, int TJ>
 __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
                                                          int m, int ldw, uint32_t *__restrict__ hit_out,
                                                          uint32_t *__restrict__ dst_out, float *__restrict__ ident,
-                                                         float *__restrict__ wmat) {
+                                                         float *__restrict__ wmat, float *__restrict__ wlow) {
     const int lane = threadIdx.x;
     const int i0 = blockIdx.x * TI;  // uniform
     const int j0 = blockIdx.y * (64 * TJ);
@@ -207,6 +210,8 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
                     const float v = 1.0f - r;
                     if (i < j) wmat[(size_t)i * ldw + j] = v;
                     else wmat[(size_t)j * ldw + i] = v;
+                    // the mirror image (strictly lower triangular) for the kernel whose lanes are the rows j
+                    if (wlow) wlow[(size_t)(i < j ? j : i) * ldw + (i < j ? i : j)] = v;
                 }
             }
         }
@@ -1206,10 +1211,7 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den2_kernel(const unsigned
 // row; they are served by the scalar cache while the waves of a CU fit it together (4 x 8 KB at m = 2000 run at
 // 12.4 cycles per step; 4 x 14 KB at m = 3583 ran at 32: every group load exposed the L2 latency).
 int sim_den_waves(int m) {
-    if (const char *e = getenv("MSA_DEN_WAVES")) {
-        const int w = atoi(e);
-        if (w >= 1 && w <= DEN_WAVES) return w;
-    }
+    if (tuning().den_waves >= 1 && tuning().den_waves <= DEN_WAVES) return tuning().den_waves;
     const long mask_bytes = 4L * (m + 64);
     const long w = (36 * 1024) / mask_bytes;
     return (int)(w < 1 ? 1 : (w > 4 ? 4 : w));
@@ -1224,8 +1226,7 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
                    int ldw, float *den_out, unsigned long long *pairmasks) {
     // The dynamic LDS request is a placement device: with it a CU cannot hold this workgroup and a numerator
     // workgroup at once -- sharing a SIMD with the chain waves of the other kernel slows both by ~1.7x.
-    const char *which = getenv("MSA_DEN_KERNEL");  // "exec": the EXEC-masked kernel (diagnostics, parity tests)
-    const bool pair_kernel = !(which && which[0] == 'e');
+    const bool pair_kernel = !tuning().den_exec;  // MSA_DEN_KERNEL=exec: the EXEC-masked kernel (diagnostics, parity tests)
     const int waves = sim_den_waves(m);
     const int row_bytes = den2_row_bytes(m);
     const int lds2 = waves * 2 * row_bytes;
@@ -1233,16 +1234,12 @@ int launch_sim_den(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad,
         const int pm_ld = den2_pm_ld(m);
         den_pairmask_kernel<<<dim3((pm_ld + 255) / 256, nchunk), 256, 0, s>>>(planes, nchunk, m_pad, m, pairmasks, pm_ld);
         const int lds = lds2 > DEN_LDS_BYTES ? lds2 : DEN_LDS_BYTES;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
+        if (int e = set_max_lds_once(reinterpret_cast<const void *>(sim_den2_kernel), lds)) return e;
         sim_den2_kernel<<<sim_den_workgroups(nchunk, m), 64 * waves, lds, s>>>(pairmasks, pm_ld, nchunk, m, n, wmat, ldw,
                                                                               den_out, row_bytes);
         return 0;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sim_den_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, DEN_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    if (int e = set_max_lds_once(reinterpret_cast<const void *>(sim_den_kernel), DEN_LDS_BYTES)) return e;
     sim_den_kernel<<<sim_den_workgroups(nchunk, m), 64 * waves, DEN_LDS_BYTES, s>>>(planes, nchunk, m_pad, m, n, wmat, ldw,
                                                                                   den_out);
     return 0;
@@ -2045,6 +2042,47 @@ __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__res
 // ------------------------------------------------------------------------------------------
 static inline uint32_t rep4(uint8_t b) { return 0x01010101u * b; }
 
+// ---- diagnostic switches ---------------------------------------------------------------------
+static thread_local const Tuning *tl_tuning = nullptr;
+void set_tuning(const Tuning *t) { tl_tuning = t; }
+const Tuning &tuning() {
+    static const Tuning defaults;
+    return tl_tuning ? *tl_tuning : defaults;
+}
+Tuning tuning_from_env() {
+    Tuning t;
+    auto num = [](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : dflt;
+    };
+    if (const char *k = getenv("MSA_SIM_KERNEL")) t.sim_kernel = k[0] == 'c' ? 1 : (k[0] == 'p' ? 2 : 0);
+    t.sim_tcols = num("MSA_SIM_TCOLS", 0);
+    t.sim_mode = num("MSA_SIM_MODE", 0);
+    t.sim_tp = num("MSA_SIM_TP", 1);
+    t.den_waves = num("MSA_DEN_WAVES", 0);
+    if (const char *k = getenv("MSA_DEN_KERNEL")) t.den_exec = k[0] == 'e';
+    t.sim_serial = getenv("MSA_SIM_SERIAL") != nullptr;
+    t.device_clusters = num("MSA_DEVICE_CLUSTERS", -1);
+    t.trace = getenv("MSA_TRACE") != nullptr;
+    t.bx_cols = num("MSA_BX_COLS", 0);
+    t.bx_r0 = num("MSA_BX_R0", -1);
+    t.bx_waves = num("MSA_BX_WAVES", 0);
+    return t;
+}
+int set_max_lds_once(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> done;  // (kernel, device) -> bytes granted
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({kernel, dev});
+    if (it != done.end() && it->second >= bytes) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[{kernel, dev}] = bytes;
+    return 0;
+}
+
 void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
                         int nchunk, int m_pad, int *err_flag) {
     dim3 grid((m_pad + 255) / 256, (nchunk + 1) / 2);
@@ -2058,17 +2096,17 @@ void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 }
 
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat) {
+                        uint32_t *dst, float *ident, float *wmat, float *wlow) {
     // Two rows "j" per lane reuse the wave-uniform "i" words twice, but halve the number of waves: worth it only
     // once the upper triangle still holds several waves per SIMD (m >= ~3000); m_pad is a multiple of 128.
     constexpr int TI = PAIR_TI;
     const long waves2 = (long)((m + TI - 1) / TI) * (m_pad / 128) / 2;
     if (waves2 >= 8192) {
         dim3 grid((m + TI - 1) / TI, m_pad / 128);
-        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow);
     } else {
         dim3 grid((m + TI - 1) / TI, m_pad / 64);
-        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat);
+        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow);
     }
 }
 
@@ -2093,10 +2131,7 @@ bool sim_num_transposed(int tcols);
 int sim_tile_cols(int n, int cus, int min_cols) {
     (void)n;
     (void)cus;
-    if (const char *e = getenv("MSA_SIM_TCOLS")) {
-        const int t = atoi(e);
-        if (t >= min_cols && t <= 64) return t;
-    }
+    if (tuning().sim_tcols >= min_cols && tuning().sim_tcols <= 64) return tuning().sim_tcols;
     return 64;
 }
 int sim_num_min_cols() { return 16; }
@@ -2111,8 +2146,7 @@ void launch_sim_encode32(hipStream_t s, const uint8_t *raw, int m, int n, int64_
 // MSA_SIM_MODE (diagnostics only, never set in production): bit0 producers skip gather/emit,
 // bit1 consumer skips the chain
 static int sim_debug_mode() {
-    const char *e = getenv("MSA_SIM_MODE");
-    return e ? atoi(e) : 0;
+    return tuning().sim_mode;
 }
 
 extern "C" int msa_debug_den_ticks(unsigned long long *out1024) {
@@ -2132,8 +2166,7 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
     const int lds = sim_lds_bytes(npos);
     const int mode = sim_debug_mode();
     auto kern = mode ? similarity_pc_kernel<true> : similarity_pc_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (int e = set_max_lds_once(reinterpret_cast<const void *>(kern), lds)) return e;
     kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(reinterpret_cast<const uint4 *>(codes32), m, n, ld, wmat, ldw,
                                                    reinterpret_cast<const f32x2 *>(tab), npos, gaps_w, (int)rounds, mode,
                                                    q_out, mdk_out, tcols);
@@ -2146,8 +2179,7 @@ bool similarity_rc_fits(int m) { return (m + 7) / 8 <= NK_RMAX * NK_ROUND_OCTS; 
 // The numerator kernel's producers read the transposed layout on 64-column tiles (MSA_SIM_TP=0: the [oct][column]
 // layout, which narrower tiles -- a diagnostic -- always use).
 bool sim_num_transposed(int tcols) {
-    const char *e = getenv("MSA_SIM_TP");
-    return (e ? atoi(e) != 0 : true) && tcols == 64;
+    return tuning().sim_tp != 0 && tcols == 64;
 }
 
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
@@ -2182,9 +2214,7 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
         auto tk = rm == 18 ? (diag ? similarity_num_kernel<true, 18, true> : similarity_num_kernel<false, 18, true>)
                 : rm == 0 ? (diag ? similarity_num_kernel<true, 0, true> : similarity_num_kernel<false, 0, true>)
                           : (diag ? similarity_num_kernel<true, NK_RMAX, true> : similarity_num_kernel<false, NK_RMAX, true>);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           tp_lds_bytes());
-        if (e != hipSuccess) return (int)e;
+        if (int e = set_max_lds_once(reinterpret_cast<const void *>(tk), tp_lds_bytes())) return e;
         tk<<<(n + 63) / 64, 512, tp_lds_bytes(), s>>>(reinterpret_cast<const uint2 *>(codes8), m, n, ld, wmat, ldw,
                                                       reinterpret_cast<const f32x2 *>(tab), npos, R, pad, (int)rounds,
                                                       num_out, 64);
@@ -2193,8 +2223,7 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
     auto kern = rm == 18 ? (diag ? similarity_num_kernel<true, 18> : similarity_num_kernel<false, 18>)
               : rm == 0 ? (diag ? similarity_num_kernel<true, 0> : similarity_num_kernel<false, 0>)
                         : (diag ? similarity_num_kernel<true, NK_RMAX> : similarity_num_kernel<false, NK_RMAX>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (int e = set_max_lds_once(reinterpret_cast<const void *>(kern), lds)) return e;
     kern<<<(n + tcols - 1) / tcols, 512, lds, s>>>(
         reinterpret_cast<const uint2 *>(codes8), m, n, ld, wmat, ldw, reinterpret_cast<const f32x2 *>(tab), npos, R, pad,
         (int)rounds, num_out, tcols);

@@ -24,6 +24,27 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def ctx_with(monkeypatch):
+    """Factory of contexts created under given MSA_* diagnostic switches (the library reads them once, when a
+    context is created)."""
+    made = []
+
+    def make(**env):
+        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COLS", "MSA_BX_R0"):
+            monkeypatch.delenv(name, raising=False)
+        for name, value in env.items():
+            if value:
+                monkeypatch.setenv(name, value)
+        c = _lib.Context(0)
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()
+
+
 def bits(x):
     return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
 
@@ -260,77 +281,96 @@ def _sim_parity(ctx, a, indet=ord("X")):
     assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
 
 
-@pytest.mark.parametrize("kernel", ["", "pc"])
-@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (113, 200), (225, 96), (337, 130), (640, 257)])
-def test_similarity_kernel_variants(ctx, monkeypatch, kernel, shape):
-    """Both similarity paths (default numerator + denominator kernels; the streaming producer/consumer kernel
-    that serves m > 2016) against the oracle, at row counts on both sides of the round boundaries (112 rows
-    per round) and with ragged column tiles."""
-    if kernel:
-        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
+KERNELS = ["", "chain", "pc"]  # binade-exact (default), numerator + denominator chain kernels, single chain
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (113, 200), (225, 96), (337, 130), (640, 257)])
+def test_similarity_kernel_variants(ctx_with, kernel, shape):
+    """Every similarity path against the oracle, at row counts on both sides of the round boundaries (64 rows per
+    round of the binade-exact kernel, 112 per round of the chain kernels) and with ragged column tiles."""
     m, n = shape
-    _sim_parity(ctx, synth_msa(m, n, 4242 + m))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(m, n, 4242 + m))
 
 
-@pytest.mark.parametrize("kernel", ["", "pc"])
+@pytest.mark.parametrize("cols", ["1", "2", "4"])
+@pytest.mark.parametrize("r0", ["0", "3", "8", "40"])
+def test_binade_kernel_shapes(ctx_with, cols, r0):
+    """Columns per wave and the number of rows evaluated in order before the first round must not matter."""
+    _sim_parity(ctx_with(MSA_BX_COLS=cols, MSA_BX_R0=r0), synth_msa(300, 150, 31))
+
+
+@pytest.mark.parametrize("kernel", ["chain", "pc"])
 @pytest.mark.parametrize("tcols", ["16", "24", "40"])
-def test_similarity_narrow_column_tiles(ctx, monkeypatch, kernel, tcols):
+def test_similarity_narrow_column_tiles(ctx_with, kernel, tcols):
     """MSA_SIM_TCOLS: fewer than 64 active lanes per wave (the tile width is baked into the codes)."""
-    if kernel:
-        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    monkeypatch.setenv("MSA_SIM_TCOLS", tcols)
-    _sim_parity(ctx, synth_msa(150, 211, 99))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_SIM_TCOLS=tcols), synth_msa(150, 211, 99))
 
 
-@pytest.mark.parametrize("kernel", ["", "pc"])
-def test_similarity_above_resident_limit(ctx, monkeypatch, kernel):
-    """m > 2016: second instantiation of the numerator kernel; also the single-chain kernel at that size."""
-    if kernel:
-        monkeypatch.setenv("MSA_SIM_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(2100, 72, 77))
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_similarity_above_resident_limit(ctx_with, kernel):
+    """m > 2016: second instantiation of the chain numerator kernel; the other kernels at that size."""
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2100, 72, 77))
 
 
-def test_similarity_36_round_resident_kernel(ctx, monkeypatch):
+@pytest.mark.parametrize("kernel", ["", "chain"])
+def test_similarity_36_round_resident_kernel(ctx_with, kernel):
     """2016 < m <= 4032: the 36-round instantiation of the resident numerator kernel."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(2017, 33, 79))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2017, 33, 79))
 
 
-def test_similarity_streaming_numerator(ctx, monkeypatch):
-    """m > 4032: the codes no longer fit the producers' registers and are streamed two rounds ahead."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(4040, 20, 80))
+@pytest.mark.parametrize("kernel", ["", "chain"])
+def test_similarity_streaming_numerator(ctx_with, kernel):
+    """m > 4032: the chain numerator kernel streams its codes two rounds ahead."""
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(4040, 20, 80))
 
 
 @pytest.mark.parametrize("switch", ["MSA_SIM_TP=0", "MSA_DEN_KERNEL=exec"])
 @pytest.mark.parametrize("shape", [(9, 33), (225, 96), (640, 257), (2017, 33), (4040, 20)])
-def test_similarity_fallback_kernels(ctx, monkeypatch, switch, shape):
-    """The kernels the defaults replaced stay selectable and exact: numerator producers on the [oct][column] codes
+def test_similarity_fallback_kernels(ctx_with, switch, shape):
+    """The chain kernels' predecessors stay selectable and exact: numerator producers on the [oct][column] codes
     (a producer lane = a column, 16-byte ring stores), and the EXEC-masked denominator kernel (one lane per
     column), which also serves alignments whose W rows do not fit the LDS."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
     name, value = switch.split("=")
-    monkeypatch.setenv(name, value)
     m, n = shape
-    _sim_parity(ctx, synth_msa(m, n, 515 + m))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="chain", **{name: value}), synth_msa(m, n, 515 + m))
 
 
-def test_similarity_many_rows_few_columns(ctx, monkeypatch):
-    """m = 9000: one denominator wave per workgroup (its W row buffers take 72 KB of LDS), streamed numerator
-    codes over 81 rounds per row, a single partial column tile."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(9000, 8, 81))
+@pytest.mark.parametrize("kernel", ["", "chain"])
+def test_similarity_many_rows_few_columns(ctx_with, kernel):
+    """m = 9000, a single partial column tile."""
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(9000, 8, 81))
 
 
-def test_similarity_at_resident_limit(ctx, monkeypatch):
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(2016, 40, 78))
+@pytest.mark.parametrize("kernel", ["", "chain"])
+def test_similarity_at_resident_limit(ctx_with, kernel):
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2016, 40, 78))
+
+
+def _conserved_case(m, n, seed):
+    """Columns that are fully conserved (numerator stays zero), nearly conserved, all gaps but two rows, and
+    identical sequences (weights zero): the sums that never leave zero or leave it late."""
+    a = synth_msa(m, n, seed)
+    r = np.random.default_rng(seed)
+    a[:, 0] = ord("A")
+    a[:, 1] = ord("A")
+    a[m // 2, 1] = ord("W")
+    a[:, 2] = ord("-")
+    a[m - 2:, 2] = ord("K")
+    a[:, 3] = ord("-")
+    a[0, 3] = ord("K")
+    a[m - 1, 3] = ord("R")
+    a[1, :] = a[0, :]
+    a[m - 1, 5:] = a[m - 2, 5:]
+    a[:, 4] = np.where(r.random(m) < 0.97, ord("-"), ord("C"))
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape", [(70, 40), (200, 70), (513, 66)])
+def test_similarity_zero_and_late_sums(ctx_with, kernel, shape):
+    m, n = shape
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), _conserved_case(m, n, 700 + m))
 
 
 def _random_case(seed):
@@ -373,7 +413,7 @@ def test_nucleotide_statistics(ctx, degenerate):
     assert err is None
 
 
-def test_wide_alignment_many_workgroups(ctx, monkeypatch):
+@pytest.mark.parametrize("kernel", ["", "chain"])
+def test_wide_alignment_many_workgroups(ctx_with, kernel):
     """Many more column tiles than CUs (the chain workgroups take a CU each): several waves of workgroups."""
-    monkeypatch.delenv("MSA_SIM_KERNEL", raising=False)
-    _sim_parity(ctx, synth_msa(60, 40000, 4321))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(60, 40000, 4321))

@@ -228,13 +228,20 @@ def test_clusters_device_search(monkeypatch, clusters):
     forced here on a smaller alignment as well) against the oracle's getCutPointClusters + greedy clustering."""
     from pytrimal_amd.synth import synth_msa
 
+    from pytrimal_amd import _lib
+
     monkeypatch.setenv("MSA_DEVICE_CLUSTERS", "1")
-    for m, n, seed in ((300, 120, 31), (2050, 90, 32)):
-        a = synth_msa(m, n, seed)
-        a[5] = a[4]  # identical sequences: identity 1
-        ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
-        trimmed = RepresentativeTrimmer(clusters=clusters, platform=PLATFORM).trim(ali)
-        assert_matches_oracle(trimmed, a, clusters=clusters)
+    _lib.reset_thread_context()  # the switches are read once per context
+    try:
+        for m, n, seed in ((300, 120, 31), (2050, 90, 32)):
+            a = synth_msa(m, n, seed)
+            a[5] = a[4]  # identical sequences: identity 1
+            ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+            trimmed = RepresentativeTrimmer(clusters=clusters, platform=PLATFORM).trim(ali)
+            assert_matches_oracle(trimmed, a, clusters=clusters)
+    finally:
+        monkeypatch.delenv("MSA_DEVICE_CLUSTERS")
+        _lib.reset_thread_context()
 
 
 # --- randomized sweep: every trimmer family on small random alignments, masks against the oracle's trim ---------
