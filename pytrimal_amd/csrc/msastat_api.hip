@@ -97,6 +97,10 @@ struct msa_ctx {
     DevBuf<float> ident, wmat;
     DevBuf<float> wlow;        // strictly lower triangular mirror of wmat (binade-exact similarity kernel)
     DevBuf<uint8_t> codeT;     // column-major similarity codes of that kernel
+    DevBuf<uint32_t> bx_off;   // ... and the compacted lists of every column's valid rows: W row offset,
+    DevBuf<uint16_t> bx_row;   //     row index,
+    DevBuf<uint8_t> bx_code;   //     code
+    DevBuf<int32_t> bx_nvalid;
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
     PinBuf<int32_t> h_simcols;
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
@@ -429,8 +433,15 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // Kernel choice (MSA_SIM_KERNEL, read when the context was created): the binade-exact kernel by default;
     // "chain" = the numerator + denominator chain kernels of round 1, "pc" = the single-chain producer/consumer
     // kernel.  All three are bit-exact and parity-tested against each other and the oracle.
-    if (c->tuning.sim_kernel == 0) {
-        HIPCHK(c, c->codeT.reserve((size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64));
+    // (its compacted lists hold 16-bit row indices and 32-bit W offsets: larger alignments take the chain kernels)
+    const bool bx_fits = m < 32000;
+    if (c->tuning.sim_kernel == 0 && bx_fits) {
+        const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
+        HIPCHK(c, c->codeT.reserve(lsz));
+        HIPCHK(c, c->bx_off.reserve(lsz));
+        HIPCHK(c, c->bx_row.reserve(lsz));
+        HIPCHK(c, c->bx_code.reserve(lsz));
+        HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
         HIPCHK(c, c->errkey.reserve(1));
         HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
         HIPCHK(c, c->q.reserve((size_t)n + 64));
@@ -440,33 +451,35 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         {
             ProfScope pe(c, "encode");
             msak::launch_sim_encode_cm(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
+            msak::launch_bx_compact(c->stream, c->codeT.p, m, n, c->ldw, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p);
         }
-        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; sorted by gap count so that the columns of a
-        // wave cross their binades in the same rounds (their denominators grow alike)
+        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first
+        // (their waves run longest)
         const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
-        const int cw = msak::bx_cols_per_wave();
         HIPCHK(c, c->h_simcols.reserve((size_t)n + 8));
         int nact = 0;
         for (int j = 0; j < n; ++j)
             if (!(((float)gw_host[j] / (float)m) >= 0.8f)) c->h_simcols.p[nact++] = j;
-        std::stable_sort(c->h_simcols.p, c->h_simcols.p + nact, [&](int32_t x, int32_t y) { return gw_host[x] < gw_host[y]; });
-        int npad = nact;
-        while (npad % cw) c->h_simcols.p[npad++] = n;  // the all-skipped column behind the last one
+        std::stable_sort(c->h_simcols.p, c->h_simcols.p + nact, [&](int32_t x, int32_t y) {
+            return c->h_gaps[x] + c->h_indets[x] < c->h_gaps[y] + c->h_indets[y];
+        });
+        const int npad = nact;
         HIPCHK(c, c->simcols.reserve((size_t)n + 8));
         if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
         {
             ProfScope ps(c, "sim");
-            const int e = msak::launch_similarity_bx(c->stream, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
-                                                     c->ldw, c->tab.p, c->simnum.p, c->simden.p);
+            const int e = msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p, m, n,
+                                                     c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
+                                                     c->simnum.p, c->simden.p);
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
         }
         msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
         HIPCHK(c, hipGetLastError());
         return fetch_similarity(c, n, mdk_out, q_out, detail);
     }
-    const bool split = c->tuning.sim_kernel == 1;
+    const bool split = c->tuning.sim_kernel != 2;
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
@@ -823,7 +836,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();

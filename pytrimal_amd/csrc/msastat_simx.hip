@@ -17,10 +17,19 @@
 //   accumulators kept on the next grid (2B, 2u).  Anything else ends the round early.  Every commit is checked
 //   (sum < 2B, grids as assumed), so speculation can only cost time, never exactness.
 //
-// Work mapping: one wave = C columns; lane = row j of the round; the wave walks k = j0+1 .. m-1 once per round:
-// W[k][j] (lower-triangular copy, one coalesced 256-B load per k shared by the C columns), the residue code of
-// row k per column (scalar loads), one ds_read_b64 gather of {D, valid} per column, one packed multiply and four
-// packed adds.  No chain: the kernel is bound by VALU / LDS issue, not by add latency.
+// Work mapping: one wave = one column (the columns the ">= 80 % gaps" rule zeroes never get a wave).  Lane = one of
+// 64 CONSECUTIVE rows j of the round; the wave walks the column's VALID rows k behind the round's first row
+// (a compacted list: a row whose residue takes no part costs no step), one step per partner row:
+//   W[k][j]      lower-triangular copy of the weight matrix, one coalesced 256-byte buffer load per step whose
+//                row offset comes straight from the list (SGPR) -- no address arithmetic;
+//   D[a_k][a_j]  from the lane's own copy of its table column (32 VGPRs, refilled per round from LDS) indexed
+//                by the wave-uniform a_k through relative VGPR addressing -- no LDS access in the loop;
+//   one packed multiply {W, W} x {D, e} and two packed adds ({even, odd} of the numerator, of the denominator);
+//   chains that may leave their binade in this round (predicted from the last round's increment) add two more
+//   on the next grid: four instantiations of the loop.
+// No dependent chain is left: the kernel is bound by VALU issue (5.6 VALU instructions per step measured, 4 of
+// them in the loop), not by add latency.  Limits: m < 32000 (16-bit row indices, 32-bit W offsets); above that
+// the chain kernels of msastat_kernels.hip run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,10 +51,6 @@ typedef const __attribute__((address_space(1))) float *gf32p;
 typedef const __attribute__((address_space(1))) uint8_t *gu8p;
 typedef const __attribute__((address_space(3))) char *ldsp;  // the {distance, valid} table in LDS
 
-__device__ __forceinline__ uint2 ld_codes8(gu8p p) {
-    cu32p q = (cu32p)(uint64_t)p;
-    return make_uint2(q[0], q[1]);
-}
 
 template <typename P>
 __device__ __forceinline__ P uniform_ptr(P p) {  // a pointer every lane agrees on, moved to SGPRs
@@ -109,23 +114,35 @@ __device__ __forceinline__ float block_step(float s, float x) {
     return s;
 }
 
-// Row j of one column in the reference's order: k = j+1 .. m-1, lane = k within a block of 64.
-// s = {numerator sum, denominator sum}; `which` selects the sums to advance (bit 0 / bit 1).
-// (Every argument by value: a struct passed by reference would live in scratch memory and make the
-// caller's loop counters look divergent to the compiler.)
-__device__ __noinline__ f2 exact_row(gu8p cp, gf32p wup, int ldw, int m, ldsp tab, int j, int which, f2 s) {
+// The valid rows of one column, compacted (bx_compact_kernel): entry t is the t-th row whose residue takes part.
+struct ColView {
+    const __attribute__((address_space(1))) uint32_t *off;  // byte offset of that row in W (row * ldw * 4); padding: a zero row
+    const __attribute__((address_space(1))) uint16_t *row;  // its row index; padding: m
+    gu8p code;                                               // its code (8 x table row); padding: BX_SKIP
+    int nvalid;
+    gu8p colcode;                                            // the column's codes by row (codeT), BX_SKIP for a row that takes no part
+    int ldw;
+};
+
+// Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
+// tfirst .. nvalid-1 of the compacted list (tfirst = number of valid rows <= j), 64 per block (lane = partner).
+// s = {numerator sum, denominator sum}; `which` selects the sums to advance.
+// (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
+// loop counters look divergent to the compiler.)
+__device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int tfirst, int which, f2 s) {
     const int lane = threadIdx.x & 63;
-    const uint32_t cj = cp[j];
+    const uint32_t cj = cv.colcode[j];
     if (uni((int)cj) == (int)BX_SKIP) return s;
-    gf32p wr = wup + (size_t)j * ldw + lane;
-    gu8p cr = cp + lane;
+    gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
-    int kb = ((j + 1) >> 6) << 6;
-    float w = wr[kb];         // zero for k <= j and for the padding columns k >= m
-    uint32_t ck = cr[kb];     // BX_SKIP for k >= m
-    for (; kb < m; kb += 64) {
-        const float wn = wr[kb + 64];  // (one block past the end: still inside the padded row / the next row)
-        const uint32_t cn = cr[kb + 64];
+    int tb = tfirst;
+    uint32_t k = cv.row[tb + lane];   // (the lists are padded by more than two blocks: row m, skipped code)
+    uint32_t ck = cv.code[tb + lane];
+    float w = wr[k];                  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
+    for (; tb < cv.nvalid; tb += 64) {
+        const uint32_t kn = cv.row[tb + 64 + lane];
+        const uint32_t cn = cv.code[tb + 64 + lane];
+        const float wn = wr[kn];
         const f2 de = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + ck));
         if (which & 1) s0 = block_step(s0, w * de.x);
         if (which & 2) s1 = block_step(s1, w * de.y);
@@ -160,15 +177,18 @@ __device__ __forceinline__ float scan_rows(float s, float top, float ie, float i
     return sp;
 }
 
-// One chain (numerator or denominator of one column) at the end of a round of `limit` rows starting at j0.
-// Returns {the sum after every row (per lane), the new limit}: the limit shrinks when the rows behind some
-// point cannot be committed.
+// One chain (numerator or denominator of the column) at the end of a round of `limit` rows starting at row j0
+// (tbase valid rows lie before j0; vmask: the valid rows of the round).  Returns {the sum after every row (per lane), the new limit}: the limit shrinks when the rows behind
+// some point cannot be committed.
 struct Resolved {
     float sp;
     int limit;
 };
-__device__ __noinline__ Resolved resolve_chain(gu8p cp, gf32p wup, int ldw, int m, ldsp tab, int j0, int kind, float s,
-                                               float ie, float io, float ie2, float io2, int limit, bool dual) {
+__device__ __noinline__ Resolved resolve_chain(ColView cv, gf32p wup, ldsp tab, int j0, int tbase, unsigned long long vmask,
+                                               int kind, float s, float ie, float io, float ie2, float io2, int limit,
+                                               bool dual) {
+    // (row j0 + x of the round; its partners start at entry tbase + (valid rows of the round up to and including x))
+    auto tfirst = [&](int x) { return tbase + __builtin_popcountll(vmask & ((2ull << x) - 1ull)); };
     const int lane = threadIdx.x & 63;
     float B, u;
     if (!grid_of(s, B, u)) {
@@ -177,7 +197,7 @@ __device__ __noinline__ Resolved resolve_chain(gu8p cp, gf32p wup, int ldw, int 
         const unsigned long long nz = __ballot(lane < limit && ie != 0.0f);
         if (!nz) return Resolved{s, limit};
         const int x = __builtin_ctzll(nz);
-        const f2 r = exact_row(cp, wup, ldw, m, tab, j0 + x, kind ? 2 : 1, f2{s, s});
+        const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{s, s});
         const float sx = kind ? r.y : r.x;
         return Resolved{lane < x ? s : sx, x + 1};
     }
@@ -186,7 +206,7 @@ __device__ __noinline__ Resolved resolve_chain(gu8p cp, gf32p wup, int ldw, int 
     if (x >= limit) return Resolved{sp, limit};
     // row x would leave the binade: evaluate it in order
     const float before = x > 0 ? rl(sp, x - 1) : s;
-    const f2 r = exact_row(cp, wup, ldw, m, tab, j0 + x, kind ? 2 : 1, f2{before, before});
+    const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{before, before});
     const float sx = kind ? r.y : r.x;
     const float B2 = 2.0f * B;
     // without the second grid (the round did not expect this chain to cross), or after a row that spans two
@@ -200,80 +220,90 @@ __device__ __noinline__ Resolved resolve_chain(gu8p cp, gf32p wup, int ldw, int 
 }
 
 // cycle stamps of MSA_SIM_MODE=64 (diagnostics): [0] prologue, [1] round loops, [2] stitching, [3] waves, [4] rounds,
-// [5] column slots that carried the second grid, summed over rounds, [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles)
+// [5] rounds x chains that carried the second grid, [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles),
+// [8] most rounds of a wave, [9] shortened rounds
 __device__ unsigned long long g_bx_stamps[16];
-__device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): first column, cycles / 64 of the three phases, rounds, shortened rounds  // [8] most rounds of a wave, [9] shortened rounds, [10] rounds of the longest-running wave
+__device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): column, cycles / 64 of the three phases, rounds, shortened rounds
 
-// The k loop of one round.  Slot cc < ND also accumulates on the next grid (an2 / ad2): only the columns with a
-// chain that may leave its binade in this round pay for that (they are sorted to the front, see the kernel).
-template <int C, int ND>
-__device__ __forceinline__ void round_loop(ldsp tabp, gf32p wrow, size_t ldw, const gu8p (&cp)[C], int kstart, int kend,
-                                           int lane, const uint32_t (&cj8)[C], f2 (&an)[C], f2 (&an2)[C], f2 (&ad)[C],
-                                           f2 (&ad2)[C]) {
-    // uniform row pointer + lane: global loads with an SGPR base; two register sets (A, B) of 8 rows each
-    // alternate between "being loaded" and "being consumed"
-    float wA[8], wB[8];
-    uint2 cA[C], cB[C];
-    auto load8 = [&](float(&w)[8], uint2(&c)[C], int kb) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = (wrow + (size_t)(kb - kstart + i) * ldw)[lane];
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) c[cc] = ld_codes8(cp[cc] + kb);
+// The partner loop of one round: entries tstart .. tend-1 of the compacted list (valid rows only), one step per
+// partner row k:
+//   W[k][j(lane)]  one coalesced buffer load (SGPR row offset straight from the list + per-lane column offset);
+//   D[a_k][a_j]    from the lane's own copy of its table column, T[a] = D[a][a_j(lane)], held in 32 VGPRs and
+//                  indexed by the wave-uniform a_k (relative VGPR addressing: no LDS access in the loop, so the
+//                  scalar prefetch of the list is the only thing on the LGKM counter);
+//   one packed multiply {W, W} x {D, e} (e = 1 for a lane whose row takes part) and two packed adds per grid.
+// DN / DD: the numerator / denominator chain also accumulates on the next grid.
+typedef float v32f __attribute__((ext_vector_type(32)));
+
+template <bool DN, bool DD>
+__device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView cv, int tstart, int tend, uint32_t joff,
+                                           const v32f &T, float e, f2 &an, f2 &an2, f2 &ad, f2 &ad2) {
+    typedef const __attribute__((address_space(4))) uint32_t *c32;
+    // three stages, two register sets each: the list entries of group g + 2 are requested (scalar loads) while the
+    // W rows of group g + 1 are in flight (buffer loads) and group g is consumed
+    struct Entries {
+        uint32_t o[8];  // row offsets in W
+        uint2 codes;    // 8 codes
     };
-    auto consume8 = [&](const float(&w)[8], const uint2(&c)[C]) {
+    auto sload = [&](Entries &en, int t) {  // 8 entries = 32 + 8 bytes (t % 8 == 0)
+        c32 po = (c32)(uint64_t)(cv.off + t);
+        c32 pc = (c32)(uint64_t)(cv.code + t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) en.o[i] = po[i];
+        en.codes = make_uint2(pc[0], pc[1]);
+    };
+    auto bload = [&](float(&w)[8], const Entries &en) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
+    };
+    auto consume8 = [&](const float(&w)[8], const uint2 &codes) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            f2 de[C];
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const uint32_t word = i < 4 ? c[cc].x : c[cc].y;
-                const uint32_t ck = (word >> (8 * (i & 3))) & 0xFFu;
-                de[cc] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((ck << 5) + cj8[cc]));
-            }
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc) {
-                const f2 x = de[cc] * w[i];
-                const f2 xn = {x.x, x.x}, xd = {x.y, x.y};
-                an[cc] += xn;
-                ad[cc] += xd;
-                if (cc < ND) {
-                    an2[cc] += xn;
-                    ad2[cc] += xd;
-                }
-            }
+            const uint32_t word = i < 4 ? codes.x : codes.y;
+            const uint32_t ak = (word >> (8 * (i & 3) + 3)) & 0x1Fu;  // code = 8 x table row
+            const f2 x = f2{T[ak], e} * w[i];
+            const f2 xn = {x.x, x.x}, xd = {x.y, x.y};
+            an += xn;
+            ad += xd;
+            if (DN) an2 += xn;
+            if (DD) ad2 += xd;
         }
     };
-    load8(wA, cA, kstart);
+    float wA[8], wB[8];
+    Entries eA, eB;
+    uint2 cA, cB;
+    sload(eA, tstart);
+    sload(eB, tstart + 8);
+    bload(wA, eA);
+    cA = eA.codes;
 #pragma unroll 1
-    for (int kb = kstart; kb < kend; kb += 16) {  // (rows up to kend + 23 exist: zero padding, skipped codes)
-        load8(wB, cB, kb + 8);
+    for (int t = tstart; t < tend; t += 16) {  // (the lists are padded: zero row, skipped codes)
+        bload(wB, eB);
+        cB = eB.codes;
+        sload(eA, t + 16);
         consume8(wA, cA);
-        load8(wA, cA, kb + 16);
+        bload(wA, eA);
+        cA = eA.codes;
+        sload(eB, t + 24);
         consume8(wB, cB);
     }
 }
 
-template <typename T, int C>
-__device__ __forceinline__ T pick(const T (&v)[C], int idx) {  // v[idx] for a wave-uniform idx, without indexing registers
-    T r = v[0];
-#pragma unroll
-    for (int i = 1; i < C; ++i) r = idx == i ? v[i] : r;
-    return r;
-}
-
-template <int C, bool STAMP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void similarity_bx_kernel(const uint8_t *__restrict__ codeT_, int64_t ldk, int m,
-                                                                       int n, const int32_t *__restrict__ cols,
-                                                                       int ncols, const float *__restrict__ wlow_,
+template <bool STAMP>
+__global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_,
+                                                                       const uint8_t *__restrict__ vcode_,
+                                                                       const int32_t *__restrict__ nvalid,
+                                                                       const uint8_t *__restrict__ codeT_, int64_t ldk, int m,
+                                                                       int n, const int32_t *__restrict__ cols, int ncols,
+                                                                       const float *__restrict__ wlow_, uint32_t wbytes,
                                                                        const float *__restrict__ wup_, int ldw_, int r0_,
                                                                        const float *__restrict__ tab_g,
                                                                        float *__restrict__ num_out,
                                                                        float *__restrict__ den_out) {
-    const gu8p codeT = (gu8p)(uint64_t)codeT_;
-    const gf32p wlow = (gf32p)(uint64_t)wlow_, wup = (gf32p)(uint64_t)wup_;
-    __shared__ f2 tab[32 * 32];                       // {distance, both valid}[row code][column code], rows 28.. zero
-    __shared__ float spbuf[WAVES][2 * C][64];         // per chain: the sum after every row of the round
-    for (int i = threadIdx.x; i < 32 * 32; i += 64 * WAVES) {
+    const gf32p wup = (gf32p)(uint64_t)wup_;
+    __shared__ f2 tab[32 * 32];                    // {distance, both valid}[row code][column code], rows 28.. zero
+    __shared__ float spbuf[BX_WAVES][2][64];       // per chain: the sum after every row of the round
+    for (int i = threadIdx.x; i < 32 * 32; i += 64 * BX_WAVES) {
         f2 v = {0.0f, 0.0f};
         if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
         tab[i] = v;
@@ -282,156 +312,114 @@ __global__ __launch_bounds__(64 * WAVES) void similarity_bx_kernel(const uint8_t
     const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
-    const int c0 = (blockIdx.x * WAVES + wave) * C;  // position in the list of active columns
-    if (c0 >= ncols) return;
-    int colidx[C];   // the wave's columns (the list is padded with column n: an all-skipped column)
-    gu8p cp[C];
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        colidx[cc] = uni(cols[c0 + cc]);
-        cp[cc] = uniform_ptr(codeT + (size_t)colidx[cc] * ldk);
-    }
+    const int ci = blockIdx.x * BX_WAVES + wave;  // position in the list of columns
+    if (ci >= ncols) return;
+    const int col = uni(cols[ci]);
+    ColView cv;
+    cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
+    cv.row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
+    cv.code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
+    cv.nvalid = uni(nvalid[col]);
+    cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
+    cv.ldw = ldw_;
+    const int nv = cv.nvalid;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
 
-    // lane i < 2C holds the running sum of chain i (numerators 0..C-1, denominators C..2C-1) and the increment
-    // its last full round brought (the estimate behind the second-grid decision; < 0: unknown)
+    // lane 0 / 1 hold the running numerator / denominator sum and the increment their last full round brought
+    // (the estimate behind the second-grid decision; < 0: unknown)
     float sall = 0.0f, pinc = -1.0f;
-    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_dual = 0, n_short = 0, t0 = 0, rt0 = 0;
+    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_dual = 0, n_short = 0, t0c = 0, rt0 = 0;
     if (STAMP) {
-        t0 = __builtin_readcyclecounter();
+        t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
+    // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles its
+    // lane), partners come from the compacted list (only valid rows cost a step).
+    int j0 = min(r0_, m - 1);
+    int tbase = 0;  // valid rows before j0
     {
-        const int r0 = min(r0_, m - 1);
-#pragma unroll 1
-        for (int cc = 0; cc < C; ++cc) {
-            f2 s2 = {0.0f, 0.0f};
-            const gu8p p = pick(cp, cc);
-            for (int j = 0; j < r0; ++j) s2 = exact_row(p, wup, ldw_, m, tabp, j, 3, s2);
-            if (lane == cc) sall = s2.x;
-            if (lane == C + cc) sall = s2.y;
+        f2 s2 = {0.0f, 0.0f};
+        for (int j = 0; j < j0; ++j) {
+            tbase += uni((int)cv.colcode[j]) != (int)BX_SKIP;
+            s2 = exact_row(cv, wup, tabp, j, tbase, 3, s2);
         }
+        if (lane == 0) sall = s2.x;
+        if (lane == 1) sall = s2.y;
     }
     if (STAMP) {
         const unsigned long long t1 = __builtin_readcyclecounter();
-        t_pro = t1 - t0;
-        t0 = t1;
+        t_pro = t1 - t0c;
+        t0c = t1;
     }
-    int j0 = min(r0_, m - 1);
-    const int kend = (m + 7) & ~7;
-    const size_t ldw = (size_t)ldw_;
+    const int tend = (nv + 7) & ~7;
     int guard = 0;  // every round commits at least one row; a round that does not would loop forever
-    while (j0 < m - 1) {
+    while (j0 < m - 1 && tbase < nv) {
         if (++guard > m + 64) {
             sall = __uint_as_float(0x7FC00000u);  // (never reached; NaN results fail every parity test)
             break;
         }
         const int nrows = min(64 - ((j0 - r0_) & 63), m - 1 - j0);
-        // Which chains may leave their binade in this round?  Their columns go to the front slots, which also
-        // accumulate on the next grid.  A wrong "no" only shortens the round (resolve_chain), never the result.
-        int perm[C], nd = 0;
-        {
-            float Bl, ul;
-            const bool grid = grid_of(sall, Bl, ul);
-            const bool risky = !grid || pinc < 0.0f || !(sall + 1.3f * pinc * ((float)nrows * (1.0f / 64.0f)) < 2.0f * Bl);
-            const unsigned long long rb = __ballot(lane < 2 * C && risky);
-            const uint32_t colrisk = (uint32_t)(rb | (rb >> C)) & ((1u << C) - 1u);
+        // Which chains may leave their binade in this round?  They also accumulate on the next grid.  A wrong
+        // "no" only shortens the round (resolve_chain), never the result.
+        float Bl, ul;
+        const bool grid = grid_of(sall, Bl, ul);
+        const bool risky = !grid || pinc < 0.0f || !(sall + 1.3f * pinc * ((float)nrows * (1.0f / 64.0f)) < 2.0f * Bl);
+        const uint32_t rb = (uint32_t)__ballot(lane < 2 && risky);
+        const float Bn = rl(Bl, 0), un = rl(ul, 0), Bd = rl(Bl, 1), ud = rl(ul, 1);
+        f2 an = {Bn, Bn + un}, an2 = {2.0f * Bn, 2.0f * Bn + 2.0f * un};
+        f2 ad = {Bd, Bd + ud}, ad2 = {2.0f * Bd, 2.0f * Bd + 2.0f * ud};
+        const uint32_t joff = 4u * (uint32_t)(j0 + lane);
+        const uint32_t cj8 = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
+        const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
+        v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
 #pragma unroll
-            for (int cc = 0; cc < C; ++cc)
-                if (colrisk >> cc & 1u) {
-#pragma unroll
-                    for (int q = 0; q < C; ++q)
-                        if (q == nd) perm[q] = cc;
-                    ++nd;
-                }
-            int pos = nd;
-#pragma unroll
-            for (int cc = 0; cc < C; ++cc)
-                if (!(colrisk >> cc & 1u)) {
-#pragma unroll
-                    for (int q = 0; q < C; ++q)
-                        if (q == pos) perm[q] = cc;
-                    ++pos;
-                }
-        }
-        gu8p cps[C];
-        uint32_t cj8[C];
-        f2 an[C], an2[C], ad[C], ad2[C];
-        float Bn[C], un[C], Bd[C], ud[C];
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            cps[q] = pick(cp, perm[q]);
-            cj8[q] = lane < nrows ? (uint32_t)cps[q][j0 + lane] : BX_SKIP;
-            grid_of(rl(sall, perm[q]), Bn[q], un[q]);
-            grid_of(rl(sall, C + perm[q]), Bd[q], ud[q]);
-            an[q] = f2{Bn[q], Bn[q] + un[q]};
-            an2[q] = f2{2.0f * Bn[q], 2.0f * Bn[q] + 2.0f * un[q]};
-            ad[q] = f2{Bd[q], Bd[q] + ud[q]};
-            ad2[q] = f2{2.0f * Bd[q], 2.0f * Bd[q] + 2.0f * ud[q]};
-        }
-        const int kstart = (j0 + 1) & ~7;
-        const gf32p wrow = uniform_ptr(wlow + (size_t)kstart * ldw + j0);
-        switch (nd) {
-            case 0: round_loop<C, 0>(tabp, wrow, ldw, cps, kstart, kend, lane, cj8, an, an2, ad, ad2); break;
-            case 1: round_loop<C, 1>(tabp, wrow, ldw, cps, kstart, kend, lane, cj8, an, an2, ad, ad2); break;
-            case 2: round_loop<C, (C > 2 ? 2 : C)>(tabp, wrow, ldw, cps, kstart, kend, lane, cj8, an, an2, ad, ad2); break;
-            case 3: round_loop<C, (C > 3 ? 3 : C)>(tabp, wrow, ldw, cps, kstart, kend, lane, cj8, an, an2, ad, ad2); break;
-            default: round_loop<C, C>(tabp, wrow, ldw, cps, kstart, kend, lane, cj8, an, an2, ad, ad2); break;
+        for (int a = 0; a < 32; ++a)
+            T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
+        const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
+        // partners: the valid rows behind j0 (entries at or before a lane's own row read zeros: W is lower
+        // triangular here); the group of 8 that holds the first of them
+        const int tstart = tbase & ~7;
+        switch (rb & 3u) {
+            case 0: round_loop<false, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+            case 1: round_loop<true, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+            case 2: round_loop<false, true>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+            default: round_loop<true, true>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
         }
         if (STAMP) {
             const unsigned long long t1 = __builtin_readcyclecounter();
-            t_loop += t1 - t0;
-            t0 = t1;
+            t_loop += t1 - t0c;
+            t0c = t1;
             ++n_rounds;
-            n_dual += nd;
-        }
-        // per-row increments of every chain (slot order), then the chains one after the other
-        float ie[2 * C], io[2 * C], ie2[2 * C], io2[2 * C];
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            ie[q] = an[q].x - Bn[q];
-            io[q] = an[q].y - (Bn[q] + un[q]);
-            ie2[q] = an2[q].x - 2.0f * Bn[q];
-            io2[q] = an2[q].y - (2.0f * Bn[q] + 2.0f * un[q]);
-            ie[C + q] = ad[q].x - Bd[q];
-            io[C + q] = ad[q].y - (Bd[q] + ud[q]);
-            ie2[C + q] = ad2[q].x - 2.0f * Bd[q];
-            io2[C + q] = ad2[q].y - (2.0f * Bd[q] + 2.0f * ud[q]);
+            n_dual += __builtin_popcount(rb & 3u);
         }
         int limit = nrows;
-#pragma unroll 1
-        for (int ch = 0; ch < 2 * C; ++ch) {
-            float e = 0.0f, o = 0.0f, e2 = 0.0f, o2 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 2 * C; ++q)
-                if (ch == q) {
-                    e = ie[q];
-                    o = io[q];
-                    e2 = ie2[q];
-                    o2 = io2[q];
-                }
-            const int slot = ch < C ? ch : ch - C;
-            const int col = pick(perm, slot);
-            const int chain = ch < C ? col : C + col;  // the chain's lane in `sall`
-            const Resolved r = resolve_chain(pick(cps, slot), wup, ldw_, m, tabp, j0, ch < C ? 0 : 1, rl(sall, chain), e, o,
-                                             e2, o2, limit, slot < nd);
-            spbuf[wave][chain][lane] = r.sp;
+        {
+            const Resolved r = resolve_chain(cv, wup, tabp, j0, tbase, vmask, 0, rl(sall, 0), an.x - Bn, an.y - (Bn + un),
+                                             an2.x - 2.0f * Bn, an2.y - (2.0f * Bn + 2.0f * un), limit, (rb & 1u) != 0);
+            spbuf[wave][0][lane] = r.sp;
             limit = uni(r.limit);
         }
-        limit = max(uni(limit), 1);
-        if (lane < 2 * C) {
+        {
+            const Resolved r = resolve_chain(cv, wup, tabp, j0, tbase, vmask, 1, rl(sall, 1), ad.x - Bd, ad.y - (Bd + ud),
+                                             ad2.x - 2.0f * Bd, ad2.y - (2.0f * Bd + 2.0f * ud), limit, (rb & 2u) != 0);
+            spbuf[wave][1][lane] = r.sp;
+            limit = uni(r.limit);
+        }
+        limit = max(limit, 1);
+        if (lane < 2) {
             const float snew = spbuf[wave][lane][limit - 1];  // (limit >= 1: every chain commits at least one row)
-            float Bl, ul;
             // (a short round is a poor sample of the increment per row: keep the previous estimate)
-            if (!grid_of(sall, Bl, ul)) pinc = -1.0f;
+            if (!grid) pinc = -1.0f;
             else if (limit >= 16) pinc = (snew - sall) * (64.0f / (float)limit);
             sall = snew;
         }
+        if (STAMP) n_short += limit < nrows;
+        tbase += __builtin_popcountll(vmask & ((limit >= 64 ? 0ull : (1ull << limit)) - 1ull));
         j0 += limit;
         if (STAMP) {
-            n_short += limit < nrows;
             const unsigned long long t1 = __builtin_readcyclecounter();
-            t_res += t1 - t0;
-            t0 = t1;
+            t_res += t1 - t0c;
+            t0c = t1;
         }
     }
     if (STAMP && lane == 0) {
@@ -444,10 +432,10 @@ __global__ __launch_bounds__(64 * WAVES) void similarity_bx_kernel(const uint8_t
         atomicAdd(&g_bx_stamps[6], __builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
         atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
         atomicMax(&g_bx_stamps[8], n_rounds);
-        const unsigned wid = (unsigned)(c0 / C);
-        if (wid < 16384u) {
-            unsigned int *r = g_bx_rec + 8 * wid;
-            r[0] = (unsigned)colidx[0];
+        atomicAdd(&g_bx_stamps[9], n_short);
+        if (ci < 16384) {
+            unsigned int *r = g_bx_rec + 8 * ci;
+            r[0] = (unsigned)col;
             r[1] = (unsigned)(t_pro >> 6);
             r[2] = (unsigned)(t_loop >> 6);
             r[3] = (unsigned)(t_res >> 6);
@@ -455,18 +443,47 @@ __global__ __launch_bounds__(64 * WAVES) void similarity_bx_kernel(const uint8_t
             r[5] = (unsigned)n_short;
             r[6] = (unsigned)n_dual;
         }
-        atomicAdd(&g_bx_stamps[9], n_short);
     }
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) {
-        if (colidx[cc] < n) {
-            const float sn = rl(sall, cc), sd = rl(sall, C + cc);
-            if (lane == 0) {
-                num_out[colidx[cc]] = sn;
-                den_out[colidx[cc]] = sd;
-            }
+    if (col < n) {
+        const float sn = rl(sall, 0), sd = rl(sall, 1);
+        if (lane == 0) {
+            num_out[col] = sn;
+            den_out[col] = sd;
         }
     }
+}
+
+// codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
+// row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
+__global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
+                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vrow,
+                                                         uint8_t *__restrict__ vcode, int32_t *__restrict__ nvalid) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= ncols_pad) return;
+    const uint8_t *src = codeT + (size_t)col * ldk;
+    uint32_t *po = voff + (size_t)col * ldk;
+    uint16_t *pr = vrow + (size_t)col * ldk;
+    uint8_t *pc = vcode + (size_t)col * ldk;
+    int count = 0;
+    for (int kb = 0; kb < m; kb += 64) {
+        const int k = kb + lane;
+        const uint32_t code = k < m ? src[k] : BX_SKIP;
+        const unsigned long long mask = __ballot(code != BX_SKIP);
+        if (code != BX_SKIP) {
+            const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            po[pos] = (uint32_t)k * ldw4;
+            pr[pos] = (uint16_t)k;
+            pc[pos] = (uint8_t)code;
+        }
+        count += __builtin_popcountll(mask);
+    }
+    for (int64_t t = count + lane; t < ldk; t += 64) {
+        po[t] = (uint32_t)m * ldw4;  // row m of W: zeros
+        pr[t] = (uint16_t)m;         // column m of W: zeros
+        pc[t] = (uint8_t)BX_SKIP;
+    }
+    if (lane == 0) nvalid[col] = count;
 }
 
 // raw bytes -> column-major codes (64 x 64 tiles through LDS); first bad residue through atomicMin as in the
@@ -509,9 +526,11 @@ __global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__res
 
 }  // namespace
 
-int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 64; }
+// leading dimension of the per-column lists: the valid rows, then >= 192 padding entries (a block of the ordered
+// path, two prefetched groups of the round loop)
+int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the round loop reads up to 39 entries past the last one)
 int bx_cols_pad(int n) { return (n + 1 + 63) / 64 * 64; }  // at least one all-skipped column behind the last one
-size_t bx_wlow_rows(int m) { return (size_t)((m + 7) / 8 * 8 + 32); }
+size_t bx_wlow_rows(int m) { return (size_t)m + 2; }         // row m: zeros (the padding entries of the lists point there)
 
 void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
                           const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key) {
@@ -521,38 +540,29 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
     sim_encode_cm_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codeT, ldk, ncp, err_key);
 }
 
-int bx_cols_per_wave() {
-    const int c = tuning().bx_cols;
-    return (c == 1 || c == 2 || c == 4) ? c : 2;
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, uint32_t *voff, uint16_t *vrow,
+                       uint8_t *vcode, int32_t *nvalid) {
+    const int ncp = bx_cols_pad(n);
+    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, nvalid);
 }
 
-// cols: the columns to evaluate (device, ncols entries rounded up to a multiple of bx_cols_per_wave() with the
-// index n, the all-skipped column); the sums of every other column must have been zeroed by the caller.
-int launch_similarity_bx(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
-                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
+// cols: the columns to evaluate (device, ncols entries); the sums of every other column must have been zeroed
+// by the caller.  W (both triangles) must be smaller than 4 GB and m < 65535 (checked by the caller).
+int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
+                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
+                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
-    const int C = bx_cols_per_wave();
     const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : BX_R0;
-    const int waves = tuning().bx_waves == 1 ? 1 : BX_WAVES;
-    const int per_wg = waves * C;
-    const unsigned grid = (unsigned)((ncols + per_wg - 1) / per_wg);
+    const unsigned grid = (unsigned)((ncols + BX_WAVES - 1) / BX_WAVES);
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
-    const bool stamp = (tuning().sim_mode & 64) != 0;
-#define BX_LAUNCH2(CC, ST, WV)                                                                                        \
-    similarity_bx_kernel<CC, ST, WV><<<grid, 64 * WV, 0, s>>>(codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, t, num_out, den_out)
-#define BX_LAUNCH(CC)                                                   \
-    do {                                                                \
-        if (stamp && waves == 1) BX_LAUNCH2(CC, true, 1);               \
-        else if (stamp) BX_LAUNCH2(CC, true, BX_WAVES);                 \
-        else if (waves == 1) BX_LAUNCH2(CC, false, 1);                  \
-        else BX_LAUNCH2(CC, false, BX_WAVES);                           \
-    } while (0)
-    if (C == 1) BX_LAUNCH(1);
-    else if (C == 2) BX_LAUNCH(2);
-    else BX_LAUNCH(4);
-#undef BX_LAUNCH
-#undef BX_LAUNCH2
+    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
+    if ((tuning().sim_mode & 64) != 0)
+        similarity_bx_kernel<true><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup,
+                                                                  ldw, r0, t, num_out, den_out);
+    else
+        similarity_bx_kernel<false><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
+                                                                   wup, ldw, r0, t, num_out, den_out);
     return 0;
 }
 
