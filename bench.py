@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MSA statistics path (BASELINE.json metric).
 
-One "step" = one whole `AutomaticTrimmer('automated1')` trim of one synthetic 2 000-sequence x
-10 000-column protein MSA (BASELINE.json configs[2], seed 1003 + rank) whose residue bytes are
-already resident in HBM: bit-plane prep, pair counts (identity + weight matrices), selectMethod
-means, gap counts, similarity (order-preserving float32), host selection logic, masks back in
-host memory.  With N > 1 every rank trims its own alignment (alignments are independent: weak
-scaling, no data-path collective) and rank 0 gathers the kept-column masks over RCCL.
+Workloads (BASELINE.json configs; `--workload`, default C3 = the headline):
+  C3  AutomaticTrimmer('automated1') on a synthetic 2 000 x 10 000 protein MSA (seed 1003 + rank)
+  C2  ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5) on 500 x 2 000 (seed 1002 + rank)
+  C4  RepresentativeTrimmer(identity_threshold=0.5) on 5 000 x 5 000 (seed 1004 + rank)
+  C5  the batch of 64 alignments of 1 000 x 4 000 (seeds 2000..2063), AutomaticTrimmer('automated1'), through
+      `pytrimal_amd.batch.trim_batch(threads=4)`: sharded round-robin over the ranks, masks gathered over RCCL.
+One "step" = one pass of the whole path over the workload's input.  For C2-C4 the residue bytes are resident in
+HBM when the timed region starts (`value`); the same steps from host rows (pack + H2D included) are timed right
+after and reported as `value_host_rows` (SURVEY 8d's primary metric).  C5 always starts from host rows.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, HIP-event timed on the context's own stream) and `cpu_baseline` (the oracle, one host
-core, on a bounded column sample of the same alignment).
+`python bench.py --gpus N` starts N rank processes itself when it was not launched by torchrun (RANK unset): the
+parent never touches a GPU, every child is `bench.py` again with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a
+child that fails makes the parent exit non-zero.  Ranks synchronise with a barrier + device synchronisation on both
+sides of the timed steps, the time is the MAX over ranks, rank 0 prints ONE JSON line with `roofline` (dominant
+kernel, HIP-event timed on the context's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle, scalar and AVX2
+flavours, on a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,14 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
 
 WORKLOADS = {
-    # name: (m, n, base seed, trimmer method)
-    "C3": (2000, 10000, 1003, "automated1"),
-    "C2": (500, 2000, 1002, "automated1"),
-    "C5": (1000, 4000, 2000, "automated1"),
+    # name: (m, n, base seed)
+    "C3": (2000, 10000, 1003),
+    "C2": (500, 2000, 1002),
+    "C4": (5000, 5000, 1004),
+    "C5": (1000, 4000, 2000),
 }
+C5_BATCH = 64
 
 
 def algorithmic_bytes(kernel, m, n):
@@ -41,11 +52,128 @@ def algorithmic_bytes(kernel, m, n):
         "prep": 2 * m * n,
         "pairs": m * n + 8 * m * m,
         "sim": m * n + 4 * m * m + 8 * n,
-        "simnum": m * n + 4 * m * m + 4 * n,   # residues + W in, numerators out
-        "simden": m * n // 8 + 4 * m * m + 4 * n,  # validity plane + W in, denominators out
+        "simnum": m * n + 4 * m * m + 4 * n,
+        "simden": m * n // 8 + 4 * m * m + 4 * n,
         "encode": 2 * m * n,
         "idstats": 4 * m * m,
+        "cluster": 4 * m * m,
+        "overlap": m * n + 4 * m,
     }[kernel]
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: become the launcher.  Nothing here may touch a GPU (no HIP call, no
+    torch.cuda.is_available(); counting devices does not initialise them on this image)."""
+    if not args.launch_check:
+        import torch
+
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible; refusing to report a {args.gpus}-GPU number")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
+
+
+def launch_check(rank, world):
+    """CPU-only check of the launcher (tests/test_distributed.py): gloo group, one all-reduce, one JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
+def host_info():
+    info = {"nproc": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line.startswith("Model name:"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+            if line.startswith("Flags:"):
+                flags = line.split(":", 1)[1].split()
+                info["simd_flags"] = [f for f in ("sse2", "sse4_2", "avx", "avx2", "avx512f", "avx512bw") if f in flags]
+    except Exception:
+        pass
+    try:
+        info["git_sha"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                         timeout=10).stdout.strip() or None
+    except Exception:
+        info["git_sha"] = None
+    return info
+
+
+def cpu_baseline(a, trimmer_kw, ncols, value, with_similarity=True):
+    """The CPU oracle on one host core (scalar port, then the AVX2 flavour of its two pairwise passes), and the
+    scalar port on every host core, on the first `ncols` columns of the workload's alignment."""
+    import oracle
+
+    m, n = a.shape
+    ncols = min(ncols, n)
+    sample = np.ascontiguousarray(a[:, :ncols])
+    pairs = m * (m - 1) // 2
+    npass = 2 if with_similarity else 1  # pairwise passes of the workload (pair counts, similarity)
+    t0 = time.perf_counter()
+    oracle.trim(sample, **trimmer_kw)
+    scalar_s = time.perf_counter() - t0
+    flavours = {"scalar": {"kind": "port-scalar", "value": round(ncols / scalar_s, 2), "seconds": round(scalar_s, 2),
+                           "pair_columns_per_s": round(npass * pairs * ncols / scalar_s, 1), "build": "gcc -O3 (auto-vectorised SSE2)"}}
+    best = ("scalar", scalar_s)
+    if oracle.lib_avx2() is not None:
+        t0 = time.perf_counter()
+        g, _, _, _ = oracle.gaps(sample)
+        hit, dst = oracle.pair_counts(sample, avx2=True)
+        w = oracle.weights(hit, dst)
+        oracle.identities(hit, dst)
+        if with_similarity:
+            oracle.similarity(sample, w, g, *oracle.aa_matrix(), avx2=True)
+        avx2_s = time.perf_counter() - t0
+        flavours["avx2"] = {"kind": "port-avx2", "value": round(ncols / avx2_s, 2), "seconds": round(avx2_s, 2),
+                            "pair_columns_per_s": round(npass * pairs * ncols / avx2_s, 1),
+                            "build": "gcc -O3 -mavx2, intrinsics written from scratch (oracle/msa_oracle_avx2.c): gap counts + "
+                                     "both pairwise passes (pair counts, similarity) + the two float matrices; the selection "
+                                     "logic (< 1 % of a trim) is not included"}
+        if avx2_s < best[1]:
+            best = ("avx2", avx2_s)
+    out = {
+        "value": round(ncols / best[1], 2), "unit": "columns/s", "cores": 1, "kind": "port", "flavour": best[0],
+        "sample": f"all {m} sequences x first {ncols} columns of the same alignment, one thread "
+                  f"(cost per column equals the full workload's)",
+        "seconds": round(best[1], 2),
+        "pair_columns_per_s": round(npass * pairs * ncols / best[1], 1),
+        "flavours": flavours, "host": host_info(),
+        "note": "the reference's SIMD code cannot be built here (its trimAl submodule is empty); BASELINE.md quotes "
+                "2.0e9 .. 6.3e9 pair-columns/s per laptop core for it",
+    }
+    speedups = {"speedup_vs_cpu_1core": round(value / (ncols / best[1]), 1)}
+    cores = os.cpu_count() or 1
+    if cores > 1:
+        from multiprocessing.pool import ThreadPool
+
+        per = min(256, n)
+        base = [np.ascontiguousarray(a[:, i * per:(i + 1) * per]) for i in range(max(1, n // per))]
+        threads = min(cores, 48)  # the port saturates there on the 2 x 64-core host (profiles/r01_cpu_port_scaling.txt)
+        slices = [base[i % len(base)] for i in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPool(threads) as pool:
+            pool.map(lambda x: oracle.trim(x, **trimmer_kw), slices)
+        all_s = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(threads * per / all_s, 2), "unit": "columns/s", "cores": threads, "kind": "port-scalar",
+                            "sample": f"{threads} threads x {per} columns each (host reports {cores} logical CPUs), {all_s:.1f} s"}
+        speedups["speedup_vs_cpu_all_cores"] = round(value / (threads * per / all_s), 1)
+    return out, speedups
 
 
 def main():
@@ -56,125 +184,200 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=4000)
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        return launch_check(rank, world)
 
     import torch
 
-    from pytrimal_amd import _lib
+    from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
     from pytrimal_amd.matrix import SimilarityMatrix
     from pytrimal_amd.synth import synth_msa
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun even a 1-rank job uses RCCL
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=device)
 
-    m, n, seed, method = WORKLOADS[args.workload]
-    a = synth_msa(m, n, seed + rank)
-    ld = (n + 63) // 64 * 64
-    dev = torch.zeros((m, ld), dtype=torch.uint8, device=f"cuda:{local_rank}")
-    dev[:, :n] = torch.from_numpy(a).to(dev.device)
-    torch.cuda.synchronize()
-
-    ctx = _lib.Context(local_rank)
+    m, n, seed = WORKLOADS[args.workload]
     matrix = SimilarityMatrix.aa()
     vhash = np.ascontiguousarray(matrix._vhash, dtype=np.int32)
     dmat = np.ascontiguousarray(matrix._dist, dtype=np.float32)
-    params = _lib.TrimParams(_lib.METHOD_CODES[method], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0,
-                             vhash.ctypes.data, dmat.ctypes.data, len(matrix))
-    gathered = [torch.empty(n, dtype=torch.uint8, device=dev.device) for _ in range(world)] if rank == 0 else None
 
-    def step():
-        # attach drops every derived buffer: each step recomputes the whole path from the bytes
-        ctx.attach(dev.data_ptr(), m, n, ld, ord("X"))
-        keep_res, keep_seq, info = ctx.trim(params)
-        if dist is not None:
-            mask = torch.from_numpy(keep_res.view(np.uint8)).to(dev.device)
-            dist.gather(mask, gathered, dst=0)
-        return keep_res, keep_seq, info
+    def params_for(workload):
+        P = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, vhash.ctypes.data, dmat.ctypes.data,
+                            len(matrix))
+        if workload in ("C3", "C5"):
+            P.method = _lib.METHOD_CODES["automated1"]
+        elif workload == "C2":
+            P.gap_threshold = float(np.float32(1) - np.float32(0.5))  # trimAlManager::gapThreshold = 1 - kwarg
+            P.similarity_threshold = 0.5
+        elif workload == "C4":
+            P.max_identity = 0.5
+        return P
+
+    oracle_kw = {"C3": dict(method="automated1"), "C5": dict(method="automated1"),
+                 "C2": dict(gap_threshold=0.5, similarity_threshold=0.5), "C4": dict(identity_threshold=0.5)}[args.workload]
+    trimmer_repr = {"C3": "AutomaticTrimmer('automated1')", "C5": "AutomaticTrimmer('automated1')",
+                    "C2": "ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5)",
+                    "C4": "RepresentativeTrimmer(identity_threshold=0.5)"}[args.workload]
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        keep_res, keep_seq, info = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev.device)
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    kernels = {}
-    for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "simnum", "simden", "overlap"):
+    ctx = _lib.Context(local_rank)
+    params = params_for(args.workload)
+    kernels, host_rows_s, info, units_per_step = {}, None, None, None
+
+    if args.workload == "C5":
+        from pytrimal_amd.batch import trim_batch
+
+        alis = []
+        for k in range(C5_BATCH):
+            a = synth_msa(m, n, seed + k)
+            alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a]))
+        trimmer = AutomaticTrimmer("automated1", platform="hip")
+        units_per_step = C5_BATCH * n  # the whole batch, however many ranks share it: strong scaling
+
+        def step():
+            return trim_batch(trimmer, alis, device=device, threads=4)
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        # kernel times of one alignment of the batch (profiled separately: the batch runs on per-thread contexts)
+        a = synth_msa(m, n, seed + rank)
+        ctx.prof_enable(True)
+        for _ in range(3):
+            ctx.upload(a, ord("X"))
+            _, _, info = ctx.trim(params)
+        ctx.prof_enable(False)
+        kept = int(sum(sum(t.residues_mask) for t in out)) if rank == 0 else None
+    else:
+        a = synth_msa(m, n, seed + rank)
+        ld = (n + 63) // 64 * 64
+        dev = torch.zeros((m, ld), dtype=torch.uint8, device=device)
+        dev[:, :n] = torch.from_numpy(a).to(device)
+        torch.cuda.synchronize()
+        gathered = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+        units_per_step = world * n  # one alignment per rank per step: weak scaling
+
+        def finish(keep_res):
+            if dist is not None:
+                mask = torch.from_numpy(keep_res.view(np.uint8)).to(device)
+                dist.gather(mask, gathered, dst=0)
+
+        def step():
+            # attach drops every derived buffer: each step recomputes the whole path from the bytes
+            ctx.attach(dev.data_ptr(), m, n, ld, ord("X"))
+            keep_res, keep_seq, info = ctx.trim(params)
+            finish(keep_res)
+            return keep_res, keep_seq, info
+
+        def step_host_rows():
+            ctx.upload(a, ord("X"))  # pack + H2D
+            keep_res, keep_seq, info = ctx.trim(params)
+            finish(keep_res)
+            return keep_res, keep_seq, info
+
+        for _ in range(args.warmup):
+            step()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            keep_res, keep_seq, info = step()
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ctx.prof_enable(False)
+        step_host_rows()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_host_rows()
+        fence()
+        host_rows_s = max_over_ranks(time.perf_counter() - t0)
+        kept = int(info.kept_residues)
+
+    for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "simnum", "simden", "overlap", "cluster"):
         ms, launches = ctx.prof_get(name)
         if launches:
             kernels[name] = {"ms_avg": ms / launches, "launches": launches}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed  # columns/s over the whole job
-        # "sim" spans the numerator and the denominator kernel, which run side by side on two streams
+        value = units_per_step * args.steps / elapsed  # columns/s over the whole job
         top = {k: v for k, v in kernels.items() if k not in ("simnum", "simden")}
         dom = max(top, key=lambda k: top[k]["ms_avg"] * top[k]["launches"]) if top else None
         roofline = None
+        pairs = m * (m - 1) // 2
         if dom:
             alg = algorithmic_bytes(dom, m, n)
             achieved = alg / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(f"{args.workload}:{dom}")
+                    tj = json.load(f)
+                traffic = tj.get(f"{args.workload}:{dom}")
+                traffic_source = tj.get("_source", "profiles/traffic.json (builder PMC pass, not measured in this run)")
             roofline = {
-                "kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": alg, "ms_avg": round(kernels[dom]["ms_avg"], 4),
-                "note": "order-preserving fp32 accumulation: two strictly sequential sums per column (numerator and "
-                        "denominator kernels side by side); bound by per-wave issue rate and LDS latency, not HBM "
-                        "(DESIGN.md section 5)",
             }
-        # The similarity kernels are two dependent-add chains of m(m-1)/2 steps per column: their own yardstick is
-        # cycles per pair step against the issue floor of a lone wave, not bytes.
-        chain = None
-        if "simnum" in kernels and "simden" in kernels:
-            steps = m * (m - 1) // 2
-            clock_ghz = 2.4  # MI355X peak engine clock
-            chain = {
-                "pair_steps_per_column": steps,
-                "numerator": {"ns_per_step": round(kernels["simnum"]["ms_avg"] * 1e6 / steps, 3),
-                              "cycles_per_step_at_2.4GHz": round(kernels["simnum"]["ms_avg"] * 1e6 / steps * clock_ghz, 2),
-                              "floor_cycles_per_step": 4.3, "floor": "one dependent v_add_f32 per step"},
-                "denominator": {"ns_per_step": round(kernels["simden"]["ms_avg"] * 1e6 / steps, 3),
-                                "cycles_per_step_at_2.4GHz": round(kernels["simden"]["ms_avg"] * 1e6 / steps * clock_ghz, 2),
-                                "floor_cycles_per_step": 5.75,
-                                "floor": "one dependent v_add_f32_dpp per step (two lanes per column), measured in "
-                                         "isolation; with its selects and loads the loop measures 9.8"},
-            }
+            if dom in ("sim", "pairs"):
+                # the pairwise passes are VALU-issue work, not bandwidth: one "pair-column" = one (j, k, column) term
+                pcs = pairs * n / (kernels[dom]["ms_avg"] * 1e-3)
+                roofline["valu"] = {
+                    "pair_columns_per_s": round(pcs, 1),
+                    "lane_ops_peak_per_s": VALU_PEAK_LANEOPS,
+                    "pair_columns_per_lane_op_peak": round(pcs / VALU_PEAK_LANEOPS, 4),
+                    "note": ("order-preserving fp32 accumulation evaluated in parallel (binade-exact kernel, DESIGN.md section "
+                             "5b): about 5.6 VALU instructions per 64 (row, partner) terms, of which two are the sums themselves; "
+                             "bound by VALU issue, HBM is irrelevant (the path moves tens of MB)") if dom == "sim" else
+                            "bit-sliced XOR / popcount over 32 columns per word: VALU issue + load latency, not bandwidth",
+                }
         roofline_all = {}
         for kname, kv in kernels.items():
-            if kname in ("overlap", "cluster"):
-                continue
             ach = algorithmic_bytes(kname, m, n) / (kv["ms_avg"] * 1e-3) / 1e9
             roofline_all[kname] = {"ms_avg": round(kv["ms_avg"], 4), "achieved_GBs": round(ach, 2),
                                    "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5)}
+        if args.workload == "C5":
+            workload = (f"{trimmer_repr} on the batch of {C5_BATCH} synthetic {m} seq x {n} col protein MSAs (C5, seeds {seed}.."
+                        f"{seed + C5_BATCH - 1}) through trim_batch(threads=4), sharded round-robin over {world} rank(s), from "
+                        f"host rows to gathered masks")
+        else:
+            workload = (f"{trimmer_repr} on synthetic {m} seq x {n} col protein MSA ({args.workload}, seed {seed}+rank), one "
+                        f"alignment per GPU per step, residues resident in HBM")
         out = {
             "metric": "MSA columns/s (gap+similarity+identity)",
             "value": round(value, 2),
@@ -184,60 +387,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.workload == "C5" else "weak",
             "vs_baseline": None,
             "dtype": "u8/f32",
             "data": "synthetic",
             "config": {
-                "workload": f"AutomaticTrimmer('{method}') on synthetic {m} seq x {n} col protein MSA "
-                            f"({args.workload}, seed {seed}+rank), one alignment per GPU per step",
-                "m": m, "n": n, "selected_method": {1: "gappyout", 2: "strict"}.get(info.selected_method),
-                "avg_seq": round(float(info.avg_seq), 6), "max_seq": round(float(info.max_seq), 6),
-                "kept_columns": int(info.kept_residues), "parallelism": f"replicas x{world} (alignment per rank)",
+                "workload": workload, "m": m, "n": n,
+                "selected_method": {1: "gappyout", 2: "strict"}.get(info.selected_method) if info is not None else None,
+                "avg_seq": round(float(info.avg_seq), 6) if info is not None else None,
+                "max_seq": round(float(info.max_seq), 6) if info is not None else None,
+                "kept_columns": kept, "ranks": world,
+                "parallelism": (f"batch of {C5_BATCH} sharded over {world} rank(s) x 4 threads" if args.workload == "C5"
+                                else f"replicas x{world} (alignment per rank)"),
             },
             "roofline": roofline,
             "roofline_all_kernels": roofline_all,
-            "chain_latency": chain,
             "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in kernels.items()},
         }
+        if host_rows_s is not None:
+            out["value_host_rows"] = round(units_per_step * args.steps / host_rows_s, 2)
+            out["ms_per_step_host_rows"] = round(host_rows_s / args.steps * 1e3, 4)
         if not args.no_cpu_baseline and world == 1:
-            import oracle
-
-            ncols = min(args.cpu_sample_cols, n)
-            sample = np.ascontiguousarray(a[:, :ncols])
-            t0 = time.perf_counter()
-            ores, oseq, oinfo = oracle.trim(sample, method=method)
-            cpu_s = time.perf_counter() - t0
-            out["cpu_baseline"] = {
-                "value": round(ncols / cpu_s, 2), "unit": "columns/s", "cores": 1, "kind": "port",
-                "sample": f"all {m} sequences x first {ncols} columns of the same alignment, oracle.trim('{method}') "
-                          f"single thread, {cpu_s:.1f} s (cost per column equals the full workload's)",
-                "seconds": round(cpu_s, 2),
-                # two pairwise passes (pair counts, similarity) over m(m-1)/2 pairs x ncols columns: the rate to
-                # hold against the reference's published SIMD numbers (2.0e9 .. 6.3e9 per core)
-                "pair_columns_per_s": round(2 * (m * (m - 1) // 2) * ncols / cpu_s, 1),
-            }
-            out["speedup_vs_cpu_port"] = round(value / (ncols / cpu_s), 1)
-            # the same port on every host core: one column slice per thread (the C calls release the GIL)
-            cores = os.cpu_count() or 1
-            if cores > 1:
-                from multiprocessing.pool import ThreadPool
-
-                # every thread trims a 256-column slice of the same alignment (slices repeat when there are more
-                # cores than slices): the per-column cost is the full workload's, the m x m part stays at ~1 %
-                per = min(256, n)
-                base = [np.ascontiguousarray(a[:, i * per:(i + 1) * per]) for i in range(max(1, n // per))]
-                threads = min(cores, 48)  # the port saturates there on the 2 x 64-core host (profiles/r01_cpu_port_scaling.txt)
-                slices = [base[i % len(base)] for i in range(threads)]
-                t0 = time.perf_counter()
-                with ThreadPool(threads) as pool:
-                    pool.map(lambda x: oracle.trim(x, method=method), slices)
-                all_s = time.perf_counter() - t0
-                out["cpu_baseline"]["all_cores"] = {
-                    "value": round(threads * per / all_s, 2), "unit": "columns/s", "cores": threads,
-                    "sample": f"{threads} threads x {per} columns each (host reports {cores} logical CPUs; more threads do not add throughput), {all_s:.1f} s",
-                }
-                out["speedup_vs_cpu_port_all_cores"] = round(value / (threads * per / all_s), 1)
+            sample = synth_msa(m, n, seed) if args.workload == "C5" else a
+            ncols = args.cpu_sample_cols if args.workload != "C4" else min(args.cpu_sample_cols, 600)
+            base, speedups = cpu_baseline(sample, oracle_kw, ncols, value, with_similarity=args.workload != "C4")
+            out["cpu_baseline"] = base
+            out.update(speedups)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

@@ -172,7 +172,23 @@ typedef struct {
     int32_t kept_residues, kept_sequences;
     msa_err_detail err;
     float ms_device;          /* device time of the statistics kernels of this call (HIP events) */
+    /* Warnings of the call, MSA_W_* bits: what trimAl would hand to its report manager as a WarningCode and the
+     * reference turns into a Python RuntimeWarning (reference src/trimal/source/reportsystem.cpp:132-173).  The
+     * host binding raises one RuntimeWarning per bit; warn_row is the first sequence concerned (or -1). */
+    uint32_t warnings;
+    int32_t warn_row;
 } msa_trim_info;
+
+enum {
+    /* the trimming left sequences composed only of gaps, which were removed (Cleaner::removeAllGapsSeqsAndCols,
+     * cleaner.pxd:40; trimAl WarningCode RemovingOnlyGapsSequence [R]) */
+    MSA_W_ONLY_GAPS_SEQUENCES = 1u << 0,
+    /* every column was removed: the trimmed alignment is empty */
+    MSA_W_NO_COLUMNS_LEFT = 1u << 1,
+    /* a pair of sequences shares no column in which either holds a residue: its identity is undefined and taken
+     * as 0 (hit / dst with dst = 0, Cleaner::calculateSeqIdentity, cleaner.pxd:42) */
+    MSA_W_UNDEFINED_IDENTITY = 1u << 2
+};
 
 /* keep_res[n], keep_seq[m]: the saveResidues / saveSequences masks (alignment.pxd:29-30) as
  * 0/1 bytes, i.e. TrimmedAlignment.residues_mask / sequences_mask (_trimal.pyx:1085-1121). */

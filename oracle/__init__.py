@@ -180,12 +180,30 @@ def cutpoint_2nd_slope(hist, m, n, max_gaps):
     return lib().orc_gaps_cutpoint_2nd_slope(_p(hist), m, n, max_gaps)
 
 
-def pair_counts(a, indet=ord("X")):
+_AVX2 = None
+
+
+def lib_avx2():
+    """The AVX2 flavour of the two pairwise passes (msa_oracle_avx2.c), or None when the host CPU has no AVX2.
+    Same results as the scalar functions, bit for bit; it exists for the CPU baseline of bench.py."""
+    global _AVX2
+    if _AVX2 is None:
+        path = os.path.join(_HERE, "libmsa_oracle_avx2.so")
+        src = os.path.join(_HERE, "msa_oracle_avx2.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", _HERE, "libmsa_oracle_avx2.so"], check=True, capture_output=True)
+        L = ctypes.CDLL(path)
+        _AVX2 = L if L.orc_avx2_supported() else False
+    return _AVX2 or None
+
+
+def pair_counts(a, indet=ord("X"), avx2=False):
     a = pack(a)
     m, n = a.shape
     hit = np.zeros((m, m), dtype=np.uint32)
     dst = np.zeros((m, m), dtype=np.uint32)
-    lib().orc_pair_counts(_p(a), m, n, n, ctypes.c_uint8(indet), _p(hit), _p(dst))
+    fn = lib_avx2().orc_pair_counts_avx2 if avx2 else lib().orc_pair_counts
+    fn(_p(a), m, n, n, ctypes.c_uint8(indet), _p(hit), _p(dst))
     return hit, dst
 
 
@@ -203,7 +221,7 @@ def weights(hit, dst):
     return out
 
 
-def similarity(a, w, gaps_w, vhash, dist, indet=ord("X")):
+def similarity(a, w, gaps_w, vhash, dist, indet=ord("X"), avx2=False):
     """-> (mdk f32[n], q f32[n]).  Raises OracleError(E_INCORRECT_SYMBOL / E_UNDEFINED_SYMBOL)."""
     a = pack(a)
     m, n = a.shape
@@ -214,8 +232,9 @@ def similarity(a, w, gaps_w, vhash, dist, indet=ord("X")):
     mdk = np.zeros(n, dtype=np.float32)
     q = np.zeros(n, dtype=np.float32)
     err = np.zeros(3, dtype=np.int32)
-    rc = lib().orc_similarity(_p(a), m, n, n, ctypes.c_uint8(indet), _p(w), _p(gw), _p(vhash), _p(dist),
-                              dist.shape[0], _p(mdk), _p(q), _p(err))
+    fn = lib_avx2().orc_similarity_avx2 if avx2 else lib().orc_similarity
+    rc = fn(_p(a), m, n, n, ctypes.c_uint8(indet), _p(w), _p(gw), _p(vhash), _p(dist), dist.shape[0], _p(mdk), _p(q),
+            _p(err))
     if rc:
         raise OracleError(rc, tuple(int(x) for x in err))
     return mdk, q
@@ -371,6 +390,17 @@ def trim(a, method=None, gap_threshold=None, gap_absolute_threshold=None, simila
     if rc:
         raise OracleError(rc, tuple(info.err))
     return save_res != -1, save_seq != -1, info
+
+
+def terminal_only(a, residues_mask, sequences_mask, reading=0):
+    """`TrimmedAlignment.terminal_only` (Cleaner::removeOnlyTerminal, _trimal.pyx:1144-1157; [R], see the C source):
+    -> the new residues mask, or None when no column is free of gaps (upstream reports an error)."""
+    a = pack(a)
+    m, n = a.shape
+    save_res = np.where(np.asarray(residues_mask, dtype=bool), np.arange(n), -1).astype(np.int32)
+    save_seq = np.where(np.asarray(sequences_mask, dtype=bool), np.arange(m), -1).astype(np.int32)
+    ok = lib().orc_terminal_only(_p(a), m, n, n, _p(save_seq), _p(save_res), int(reading))
+    return (save_res != -1) if ok else None
 
 
 # --- tiny readers for the fixtures (tests only) ---------------------------------------------

@@ -536,6 +536,38 @@ void orc_remove_all_gaps(const uint8_t *a, int m, int n, int ld, int32_t *save_s
     }
 }
 
+/* Cleaner::removeOnlyTerminal (cleaner.pxd:38, called by TrimmedAlignment.terminal_only, _trimal.pyx:1144-1157).
+ * The body is not in the reference tree: [R] both readings are restated, the product follows reading 0.
+ *   reading 0 [R, the recollection of upstream Cleaner.cpp]: the gap statistics of the alignment (its kept
+ *     sequences, every original column) give the first and the last column WITHOUT gaps; every column between
+ *     the two (inclusive) is restored, the columns outside keep the trimmer's decision.  Returns 0 (and changes
+ *     nothing) when no column is free of gaps -- upstream reports an error there.
+ *   reading 1 (round 1 of this repository): the boundaries are the first and the last KEPT column.
+ * save_res is updated in place (-1 dropped, else the column index); returns 1 on success. */
+int orc_terminal_only(const uint8_t *a, int m, int n, int ld, const int32_t *save_seq, int32_t *save_res, int reading) {
+    int left = n, right = -1;
+    if (reading == 0) {
+        for (int c = 0; c < n; c++) {
+            int gaps = 0;
+            for (int i = 0; i < m; i++)
+                if (save_seq[i] != -1 && a[(size_t)i * ld + c] == '-') gaps++;
+            if (gaps == 0) {
+                if (left == n) left = c;
+                right = c;
+            }
+        }
+    } else {
+        for (int c = 0; c < n; c++)
+            if (save_res[c] != -1) {
+                if (left == n) left = c;
+                right = c;
+            }
+    }
+    if (left > right) return 0;
+    for (int c = left; c <= right; c++) save_res[c] = c;
+    return 1;
+}
+
 /* Cleaner::removeDuplicates as patched by patches/Cleaner.cpp.patch:1-14: the EARLIER of two
  * identical rows is dropped [pinned by ENOG411BWBU.noduplicateseqs.fasta]. */
 void orc_remove_duplicates(const uint8_t *a, int m, int n, int ld, int32_t *save_seq) {

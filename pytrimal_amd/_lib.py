@@ -82,7 +82,12 @@ class TrimInfo(ctypes.Structure):
         ("kept_sequences", ctypes.c_int32),
         ("err", ErrDetail),
         ("ms_device", ctypes.c_float),
+        ("warnings", ctypes.c_uint32),
+        ("warn_row", ctypes.c_int32),
     ]
+
+
+W_ONLY_GAPS_SEQUENCES, W_NO_COLUMNS_LEFT, W_UNDEFINED_IDENTITY = 1, 2, 4
 
 
 _lib = None

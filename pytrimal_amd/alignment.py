@@ -368,13 +368,28 @@ class TrimmedAlignment(Alignment):
         return Alignment._from_parts(self._names, self._matrix.copy(), self._datatype)
 
     def terminal_only(self):
-        """Get a trimmed alignment where only the terminal residues are removed
-        (``Cleaner::removeOnlyTerminal``, ``_trimal.pyx:1144-1157``): every column between the
-        first and the last kept column is restored."""
+        """Get a trimmed alignment where only the terminal residues are removed.
+
+        ``Cleaner::removeOnlyTerminal`` (``/root/reference/src/pytrimal/_trimal.pyx:1144-1157``,
+        ``include/trimal/cleaner.pxd:38``).  Its body is not in the reference tree; this follows the recalled
+        upstream behaviour [R]: the gap statistics of the kept sequences over every
+        original column give the first and the last column without gaps, every column between the two is
+        restored and the columns outside keep the trimmer's decision.  `RuntimeError` when no column is free of
+        gaps (upstream reports an error there).  The gap counts come from the HIP path (`msa_gaps`), like every
+        other statistic of this package.
+        """
+        from . import _lib
+
+        rows = self._matrix[np.flatnonzero(self._seq_mask)]
         res = self._res_mask.copy()
-        kept = np.flatnonzero(res)
-        if kept.size:
-            res[kept[0]:kept[-1] + 1] = True
+        free = np.zeros(0, dtype=np.int64)
+        if rows.size:
+            ctx = _lib.thread_context()
+            ctx.upload(rows, ord("X"))
+            free = np.flatnonzero(ctx.gaps() == 0)
+        if free.size == 0:
+            raise RuntimeError("the alignment has no column without gaps: terminal-only trimming is not possible")
+        res[free[0]:free[-1] + 1] = True
         return TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, res)
 
     def copy(self):

@@ -20,6 +20,16 @@ import torch.distributed as dist
 from .alignment import Alignment, TrimmedAlignment
 
 
+_POOLS = {}  # worker threads are kept: each owns a device context (stream, buffers) worth reusing across calls
+
+
+def _pool(threads):
+    pool = _POOLS.get(threads)
+    if pool is None:
+        pool = _POOLS[threads] = ThreadPool(threads)
+    return pool
+
+
 def shard_indices(n_items, world_size, rank):
     """Static round-robin: item i belongs to rank i % world_size."""
     return list(range(rank, n_items, world_size))
@@ -69,8 +79,7 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
         return np.array(t.residues_mask, dtype=bool), np.array(t.sequences_mask, dtype=bool)
 
     if threads > 1 and len(mine) > 1:
-        with ThreadPool(min(threads, len(mine))) as pool:
-            local = pool.map(one, mine)
+        local = _pool(min(threads, len(mine))).map(one, mine, chunksize=1)
     else:
         local = [one(i) for i in mine]
     if not distributed or world == 1:

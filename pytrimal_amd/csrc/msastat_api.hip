@@ -115,6 +115,9 @@ struct msa_ctx {
     DevBuf<float> q, mdk, simnum, simden;
     DevBuf<unsigned long long> errkey;
     DevBuf<int> errflag;
+    DevBuf<int> pairflag;          // set by the pair pass when some pair has dst = 0 (undefined identity)
+    PinBuf<int> h_pairflag;
+    bool pairflag_pending = false;
     DevBuf<uint32_t> col_ok;
     DevBuf<int32_t> good, row_cnt, col_cnt, lengths, pairs, equal;
     DevBuf<uint8_t> keep_res_d, keep_seq_d;
@@ -222,6 +225,7 @@ void prof_collect(msa_ctx *c) {
 
 void invalidate(msa_ctx *c) {
     c->have_planes = c->have_gaps = c->have_ident = c->have_w = false;
+    c->pairflag_pending = false;
     c->h_gaps.clear();
     c->gaps_staged = 0;
     c->planes_pending = false;
@@ -326,13 +330,19 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         HIPCHK(c, hipMemsetAsync(c->hit.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->dst.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
     }
+    HIPCHK(c, c->pairflag.reserve(1));
+    HIPCHK(c, c->h_pairflag.reserve(1));
+    HIPCHK(c, hipMemsetAsync(c->pairflag.p, 0, sizeof(int), c->stream));
     {
         ProfScope ps(c, "pairs");
         msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
                                  want_counts ? c->hit.p : nullptr, want_counts ? c->dst.p : nullptr,
-                                 need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr);
+                                 need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr,
+                                 c->pairflag.p);
     }
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_pairflag.p, c->pairflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->pairflag_pending = true;  // (read after the next synchronisation of the stream)
     if (need_ident) c->have_ident = true;
     if (need_w) c->have_w = true;
     return MSA_OK;
@@ -562,7 +572,7 @@ int overlap(msa_ctx *c, float residue_overlap, float *out) {
 
 // Cleaner::removeAllGapsSeqsAndCols: first sequences (over kept columns), then columns (over
 // the updated sequences).
-int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
+int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     const int m = c->m, n = c->n;
     HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
@@ -578,7 +588,13 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq) {
     SYNC(c);
     bool all_rows = true;
     for (int i = 0; i < m; ++i) {
-        if (keep_seq[i] && c->h_i32.p[i] == 0) keep_seq[i] = 0;
+        if (keep_seq[i] && c->h_i32.p[i] == 0) {
+            keep_seq[i] = 0;
+            if (info) {
+                if (!(info->warnings & MSA_W_ONLY_GAPS_SEQUENCES)) info->warn_row = i;
+                info->warnings |= MSA_W_ONLY_GAPS_SEQUENCES;
+            }
+        }
         all_rows &= keep_seq[i] != 0;
     }
     if (all_rows && (int)c->h_gaps.size() == n) {
@@ -838,7 +854,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
-    c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->col_ok.release();
+    c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
@@ -1005,6 +1021,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
+    info->warn_row = -1;
     const int m = c->m, n = c->n;
     std::fill(keep_res, keep_res + n, 1);
     std::fill(keep_seq, keep_seq + m, 1);
@@ -1136,11 +1153,16 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             return MSA_E_INVALID;
         }
     }
-    rc = remove_all_gaps(c, keep_res, keep_seq);
+    rc = remove_all_gaps(c, keep_res, keep_seq, info);
     if (rc) return rc;
     trace.mark("remove all-gap");
     info->kept_residues = static_cast<int32_t>(std::count(keep_res, keep_res + n, 1));
     info->kept_sequences = static_cast<int32_t>(std::count(keep_seq, keep_seq + m, 1));
+    if (info->kept_residues == 0) info->warnings |= MSA_W_NO_COLUMNS_LEFT;
+    if (c->pairflag_pending) {  // (remove_all_gaps synchronised the stream: the pair pass's flag has landed)
+        c->pairflag_pending = false;
+        if (c->h_pairflag.p[0]) info->warnings |= MSA_W_UNDEFINED_IDENTITY;
+    }
     return MSA_OK;
 }
 

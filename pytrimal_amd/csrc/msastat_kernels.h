@@ -35,7 +35,7 @@ void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t
 void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
                        int32_t *indets);
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat, float *wlow);
+                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag);
 // binade-exact similarity kernel (msastat_simx.hip)
 int64_t bx_ldk(int m);
 int bx_cols_pad(int n);

@@ -140,7 +140,8 @@ template <int TI, int TJ>
 __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
                                                          int m, int ldw, uint32_t *__restrict__ hit_out,
                                                          uint32_t *__restrict__ dst_out, float *__restrict__ ident,
-                                                         float *__restrict__ wmat, float *__restrict__ wlow) {
+                                                         float *__restrict__ wmat, float *__restrict__ wlow,
+                                                         int *__restrict__ undef_flag) {
     const int lane = threadIdx.x;
     const int i0 = blockIdx.x * TI;  // uniform
     const int j0 = blockIdx.y * (64 * TJ);
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
                 dst_out[(size_t)i * m + j] = d;
                 dst_out[(size_t)j * m + i] = d;
             }
+            if (!diag && d == 0u && undef_flag) atomicOr(undef_flag, 1);  // no column holds a residue of either row
             if (ident || wmat) {
                 const float r = d ? (float)h / (float)d : 0.0f;
                 if (ident) {
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(64 * DEN_WAVES) void sim_den_kernel(const uint32_t 
             const float *pre = wmat + (size_t)(j + 2) * (size_t)ldw;
             for (int off = (j + 2) / 8 * 8 + (threadIdx.x * 8); off < ldw; off += (int)blockDim.x * 8) {
                 const uint32_t voff = (uint32_t)off * 4u;
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(1024u), "v"(voff), "s"(pre) : "m0", "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(1024u), "v"(voff), "s"(pre) : "m0", "memory");
             }
         }
         // Two SGPR buffers of 16 steps: A = masks s[36:51], W s[52:67]; B = masks s[68:83], W s[84:99].
@@ -1439,7 +1441,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
     };
     {
         const float *src = wrow_of(0) + q0_of(0) * (NK_ROUND_OCTS * 8);
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(lane15x4), "s"(src) : "m0", "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(wstage_base), "v"(lane15x4), "s"(src) : "m0", "memory");
     }
     // One round: cq = this round's codes; wsrc_next = W source of the next round; last_of_row: the table slice of
     // row j+1 is staged at the end; prefetch(): further loads for the next round, issued after the wait.
@@ -1456,7 +1458,7 @@ __device__ __forceinline__ void nk_producer(const int P, unsigned char *smem, co
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         const uint32_t wdst = wstage_base + (uint32_t)((r + 1) & 1) * 256u;
         // (the instruction's immediate offset would also move the LDS address: the source is a full pointer)
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(wsrc_next) : "m0", "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(wdst), "v"(lane15x4), "s"(wsrc_next) : "m0", "memory");
         prefetch();
         // address bytes: [lane * 4][code][row parity][0]
         const uint32_t vlane = (uint32_t)lane * 4u + ((uint32_t)(j & 1) << 16);
@@ -2096,17 +2098,17 @@ void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 }
 
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat, float *wlow) {
+                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag) {
     // Two rows "j" per lane reuse the wave-uniform "i" words twice, but halve the number of waves: worth it only
     // once the upper triangle still holds several waves per SIMD (m >= ~3000); m_pad is a multiple of 128.
     constexpr int TI = PAIR_TI;
     const long waves2 = (long)((m + TI - 1) / TI) * (m_pad / 128) / 2;
     if (waves2 >= 8192) {
         dim3 grid((m + TI - 1) / TI, m_pad / 128);
-        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow);
+        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag);
     } else {
         dim3 grid((m + TI - 1) / TI, m_pad / 64);
-        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow);
+        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag);
     }
 }
 

@@ -8,6 +8,7 @@ instead; the only compute platform of this package is ``"hip"``.
 """
 import ctypes
 import functools
+import warnings
 
 import numpy as np
 
@@ -24,8 +25,38 @@ def _default_matrix(kind):
     return SimilarityMatrix.nt(degenerated=(kind == "ntdeg"))
 
 
-_HIP_RUNTIME_SUPPORT = _lib.device_count() > 0
-_BEST_PLATFORM = "hip" if _HIP_RUNTIME_SUPPORT else None
+@functools.lru_cache(maxsize=None)
+def _best_platform():
+    """"hip" when a device is visible, else `None`.  Resolved on first use (a trimmer is constructed), never at
+    import: loading the HIP library and counting devices initialises the GPU runtime, and a process that merely
+    imports the package must stay free to fork workers or to import torch first (see `_lib`)."""
+    return "hip" if _lib.device_count() > 0 else None
+
+
+def __getattr__(name):
+    # the reference's module-level constants (`_trimal._SSE2_RUNTIME_SUPPORT` style), evaluated lazily
+    if name == "_BEST_PLATFORM":
+        return _best_platform()
+    if name == "_HIP_RUNTIME_SUPPORT":
+        return _best_platform() == "hip"
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+def _raise_warnings(info, names):
+    """The `MSA_W_*` bits of `msa_trim_info.warnings` as `RuntimeWarning`, the category the reference gives to
+    trimAl's warnings (``/root/reference/src/trimal/source/reportsystem.cpp:132-173``)."""
+    w = info.warnings
+    if not w:
+        return
+    if w & _lib.W_ONLY_GAPS_SEQUENCES:
+        first = names[info.warn_row].decode("ascii", "replace") if 0 <= info.warn_row < len(names) else "?"
+        warnings.warn(f"removing sequences composed only by gaps after the trimming (first: {first!r})",
+                      RuntimeWarning, stacklevel=3)
+    if w & _lib.W_NO_COLUMNS_LEFT:
+        warnings.warn("the trimming removed every column of the alignment", RuntimeWarning, stacklevel=3)
+    if w & _lib.W_UNDEFINED_IDENTITY:
+        warnings.warn("some pairs of sequences share no residue column: their identity is taken as 0",
+                      RuntimeWarning, stacklevel=3)
 
 
 def _check_range(value, name, lo, hi, cast=float):
@@ -54,7 +85,7 @@ class BaseTrimmer:
 
     def __init__(self, *, platform="detect"):
         if platform == "detect":
-            self._platform = _BEST_PLATFORM
+            self._platform = _best_platform()
         elif platform == "hip":
             if not _lib.device_count():
                 raise RuntimeError("Cannot run HIP kernels on this machine (no gfx950 device or library missing)")
@@ -67,7 +98,7 @@ class BaseTrimmer:
             raise TypeError(f"expected str or None, found {type(platform).__name__}")
 
     def __repr__(self):
-        arg = f"platform={self.platform!r}" if self._platform != _BEST_PLATFORM else ""
+        arg = f"platform={self.platform!r}" if self._platform != _best_platform() else ""
         return f"{type(self).__name__}({arg})"
 
     def __getstate__(self):
@@ -127,7 +158,8 @@ class BaseTrimmer:
         else:
             ctx = _lib.thread_context()
             ctx.upload(dense, indet)
-            keep_res, keep_seq, _info = ctx.trim(params)
+            keep_res, keep_seq, info = ctx.trim(params)
+            _raise_warnings(info, names)
         return TrimmedAlignment._from_parts(names, dense, alignment._datatype, keep_seq, keep_res)
 
 
@@ -149,7 +181,7 @@ class AutomaticTrimmer(BaseTrimmer):
 
     def __repr__(self):
         args = [repr(self.method)]
-        if self._platform != _BEST_PLATFORM:
+        if self._platform != _best_platform():
             args.append(f"platform={self.platform!r}")
         return f"{type(self).__name__}({', '.join(args)})"
 
@@ -215,7 +247,7 @@ class ManualTrimmer(BaseTrimmer):
             args.append(f"gap_window={self._gap_window!r}")
         if self._similarity_window != -1:
             args.append(f"similarity_window={self._similarity_window!r}")
-        if self._platform != _BEST_PLATFORM:
+        if self._platform != _best_platform():
             args.append(f"platform={self.platform!r}")
         return f"{type(self).__name__}({', '.join(args)})"
 
@@ -262,7 +294,7 @@ class OverlapTrimmer(BaseTrimmer):
 
     def __repr__(self):
         args = [repr(self._sequence_overlap), repr(self._residue_overlap)]
-        if self._platform != _BEST_PLATFORM:
+        if self._platform != _best_platform():
             args.append(f"platform={self.platform!r}")
         return f"{type(self).__name__}({', '.join(args)})"
 
@@ -301,7 +333,7 @@ class RepresentativeTrimmer(BaseTrimmer):
             args.append(f"clusters={self._clusters!r}")
         elif self._identity_threshold != -1:
             args.append(f"identity_threshold={self._identity_threshold!r}")
-        if self._platform != _BEST_PLATFORM:
+        if self._platform != _best_platform():
             args.append(f"platform={self.platform!r}")
         return f"{type(self).__name__}({', '.join(args)})"
 

@@ -186,8 +186,7 @@ def test_trimmed_alignment_masks():
         TrimmedAlignment([b"a"], ["AC"], sequences_mask=[True, False])
     with pytest.raises(ValueError):
         TrimmedAlignment([b"a"], ["AC"], residues_mask=[True])
-    term = TrimmedAlignment([b"a"], ["ACDEFG"], residues_mask=[False, True, False, True, True, False]).terminal_only()
-    assert term.residues_mask == [False, True, True, True, True, False]
+    # (terminal_only needs the gap statistics, i.e. the device: tests/test_gpu_trimmers.py)
     c = t.copy()
     assert c.residues_mask == t.residues_mask and list(c.sequences) == list(t.sequences)
 

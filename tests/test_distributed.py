@@ -87,3 +87,21 @@ def test_two_rank_batch_matches_single_process():
     for g, w in zip(got, want):
         assert g[0] == w.names and g[1] == list(w.sequences)
         assert g[2] == w.residues_mask and g[3] == w.sequences_mask
+
+
+def test_bench_launcher_spawns_the_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (never touching a GPU in the
+    parent); `--launch-check` replaces the GPU workload by a gloo all-reduce so that this runs on a CPU-only host."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2

@@ -1,0 +1,116 @@
+"""BASELINE.json configurations C2-C5 at FULL size through the public API (and `trim_batch`), against the golden
+masks of tests/golden/configs.npz (made by tests/golden/make_golden_configs.py with the CPU oracle; the oracle takes
+seconds to minutes at these sizes, the HIP path milliseconds).  Mirrors the reference's golden-file tests
+(``/root/reference/src/pytrimal/tests/_base.py:15-20``): same inputs, masks compared bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, RepresentativeTrimmer, _lib
+from pytrimal_amd.matrix import SimilarityMatrix
+from pytrimal_amd.synth import synth_msa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "configs.npz"))
+
+
+def ali_of(a):
+    return Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+
+
+def check_masks(golden, key, trimmed, m, n):
+    res = np.unpackbits(golden[f"{key}.res"])[:n].astype(bool)
+    seq = np.unpackbits(golden[f"{key}.seq"])[:m].astype(bool)
+    assert trimmed.residues_mask == res.tolist(), f"{key}: kept-column mask differs from the golden vector"
+    assert trimmed.sequences_mask == seq.tolist(), f"{key}: kept-sequence mask differs from the golden vector"
+
+
+def q_bits(a):
+    m = SimilarityMatrix.aa()
+    ctx = _lib.Context(0)
+    try:
+        ctx.upload(a, ord("X"))
+        _, q = ctx.similarity(np.ascontiguousarray(m._vhash, dtype=np.int32), np.ascontiguousarray(m._dist, dtype=np.float32))
+    finally:
+        ctx.close()
+    return q.view(np.uint32)
+
+
+def test_c2_manual_trim_golden(golden):
+    a = synth_msa(500, 2000, 1002)
+    t = ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5, platform="hip").trim(ali_of(a))
+    check_masks(golden, "C2", t, 500, 2000)
+    assert np.array_equal(q_bits(a), golden["C2.q_bits"]), "similarity quotient must be bit-exact"
+
+
+def test_c3_trim_golden(golden):
+    a = synth_msa(2000, 10000, 1003)
+    t = AutomaticTrimmer("automated1", platform="hip").trim(ali_of(a))
+    check_masks(golden, "C3", t, 2000, 10000)
+    assert np.array_equal(q_bits(a), golden["C3.q_bits"]), "similarity quotient must be bit-exact"
+    # selectMethod means and the cut points through the C ABI
+    ctx = _lib.Context(0)
+    m = SimilarityMatrix.aa()
+    vhash, dist = np.ascontiguousarray(m._vhash, dtype=np.int32), np.ascontiguousarray(m._dist, dtype=np.float32)
+    ctx.upload(a, ord("X"))
+    p = _lib.TrimParams(_lib.METHOD_CODES["automated1"], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0,
+                        vhash.ctypes.data, dist.ctypes.data, len(m))
+    _, _, info = ctx.trim(p)
+    ctx.close()
+    assert np.array([info.avg_seq, info.max_seq], dtype=np.float32).view(np.uint32).tolist() == golden["C3.avgmax_bits"].tolist()
+    assert [info.selected_method, info.gap_cut] == golden["C3.cuts"].tolist()
+    assert np.array([info.sim_cut], dtype=np.float32).view(np.uint32).tolist() == golden["C3.simcut_bits"].tolist()
+
+
+def test_c4_representative_golden(golden):
+    a = synth_msa(5000, 5000, 1004)
+    t = RepresentativeTrimmer(identity_threshold=0.5, platform="hip").trim(ali_of(a))
+    check_masks(golden, "C4", t, 5000, 5000)
+
+
+def test_c5_batch_golden(golden):
+    """The 64 alignments of config 5 through `trim_batch(threads=4)` (one process, no process group: the whole
+    batch is this rank's shard) and, for the first eight, one by one: the batch driver must not change results."""
+    from pytrimal_amd.batch import trim_batch
+
+    alis = [ali_of(synth_msa(1000, 4000, 2000 + k)) for k in range(64)]
+    trimmer = AutomaticTrimmer("automated1", platform="hip")
+    out = trim_batch(trimmer, alis, threads=4)
+    assert len(out) == 64
+    for k, t in enumerate(out):
+        check_masks(golden, f"C5.{k}", t, 1000, 4000)
+    for k in range(8):
+        single = trimmer.trim(alis[k])
+        assert single.residues_mask == out[k].residues_mask and single.sequences_mask == out[k].sequences_mask
+
+
+def test_batch_module_in_a_fresh_process():
+    """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
+    package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`
+    still comes before the HIP library is loaded."""
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import pytrimal_amd
+from pytrimal_amd import _lib
+assert _lib._lib is None, 'importing the package loaded the HIP library'
+import pytrimal_amd.batch as b
+import torch
+assert torch.cuda.is_available(), 'torch lost the GPU'
+from pytrimal_amd import Alignment, AutomaticTrimmer
+from pytrimal_amd.synth import synth_msa
+alis = [Alignment([b's%d' % i for i in range(40)], [bytes(r) for r in synth_msa(40, 300, s)]) for s in (1, 2, 3)]
+out = b.trim_batch(AutomaticTrimmer('strict', platform='hip'), alis, threads=2)
+assert len(out) == 3 and all(len(t.residues_mask) == 300 for t in out)
+print('ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

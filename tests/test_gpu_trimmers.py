@@ -222,6 +222,57 @@ def test_threads_are_independent(enog_ali):
         assert_matches_oracle(t, oracle.pack(list(ali.sequences)), method="strict")
 
 
+def test_trimal_warnings_become_runtime_warnings():
+    """The `MSA_W_*` bits of `msa_trim_info.warnings` surface as `RuntimeWarning`, the category the reference
+    gives to trimAl's warnings (src/trimal/source/reportsystem.cpp:132-173)."""
+    # the only residues of the third sequence sit in a gappy column: trimming it away leaves gaps only
+    ali = Alignment([b"a", b"b", b"c"], ["ACDEF-", "ACDEF-", "-----W"])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        t = ManualTrimmer(gap_threshold=0.5, platform=PLATFORM).trim(ali)
+    assert t.sequences_mask == [True, True, False]
+    assert any(issubclass(w.category, RuntimeWarning) and "only by gaps" in str(w.message) and "'c'" in str(w.message)
+               for w in caught)
+    # two sequences without a single residue: no column counts for the pair, its identity is undefined
+    ali = Alignment([b"a", b"b", b"c"], ["ACDEFGHIKLMNPQ", "--------------", "----X---------"])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        RepresentativeTrimmer(identity_threshold=0.9, platform=PLATFORM).trim(ali)
+    assert any(issubclass(w.category, RuntimeWarning) and "identity" in str(w.message) for w in caught)
+    # and nothing is raised for an ordinary alignment
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        AutomaticTrimmer("gappyout", platform=PLATFORM).trim(Alignment(EXAMPLE_001_NAMES, EXAMPLE_001))
+
+
+def test_terminal_only_against_oracle(enog_ali):
+    """`TrimmedAlignment.terminal_only` (Cleaner::removeOnlyTerminal, _trimal.pyx:1144-1157; semantics [R], see
+    oracle/msa_oracle.c): ENOG after two trimmers, the synthetic edge alignment, and the no-gap single sequence."""
+    from conftest import edge_msa
+    from pytrimal_amd import TrimmedAlignment
+
+    cases = [AutomaticTrimmer("strict", platform=PLATFORM).trim(enog_ali),
+             OverlapTrimmer(80, 0.8, platform=PLATFORM).trim(enog_ali)]
+    e = edge_msa(40, 300, 5)
+    e[:, 60:240][:, ::7] = np.where(e[:, 60:240][:, ::7] == ord("-"), ord("A"), e[:, 60:240][:, ::7])  # some gap-free columns
+    cases.append(ManualTrimmer(gap_threshold=0.9, platform=PLATFORM).trim(
+        Alignment([b"s%d" % i for i in range(e.shape[0])], [bytes(r) for r in e])))
+    cases.append(TrimmedAlignment([b"a"], ["ACDEFG"], residues_mask=[False, True, False, True, True, False]))
+    for t in cases:
+        a = oracle.pack(list(t.original_alignment().sequences))
+        want = oracle.terminal_only(a, t.residues_mask, t.sequences_mask, reading=0)
+        if want is None:
+            with pytest.raises(RuntimeError):
+                t.terminal_only()
+            continue
+        got = t.terminal_only()
+        assert got.residues_mask == [bool(x) for x in want]
+        assert got.sequences_mask == t.sequences_mask
+    assert cases[-1].terminal_only().residues_mask == [True] * 6  # a sequence without gaps: everything comes back
+    with pytest.raises(RuntimeError):  # no column without gaps
+        TrimmedAlignment([b"a", b"b"], ["A-C", "-D-"], residues_mask=[True, False, True]).terminal_only()
+
+
 @pytest.mark.parametrize("clusters", [3, 40, 400])
 def test_clusters_device_search(monkeypatch, clusters):
     """clusters=K with the threshold search probing the device clustering (the default from 2000 sequences on;

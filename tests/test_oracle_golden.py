@@ -202,3 +202,43 @@ def test_alignment_type_detection():
     assert oracle.alignment_type(oracle.pack(OVERLAP_EXAMPLE)) == 4
     assert oracle.alignment_type(oracle.pack(["ACGTACGTAC", "ACGT-CGTAC"])) == 1
     assert oracle.alignment_type(oracle.pack(["ACGUACGUAC", "ACGU-CGUAC"])) == 2
+
+
+def test_terminal_only_readings():
+    """The two readings of Cleaner::removeOnlyTerminal the oracle restates ([R]; the product follows reading 0)."""
+    a = oracle.pack(["A-CDEF-H", "ABC-EFGH", "ABCDEFG-"])
+    keep = np.array([1, 0, 1, 0, 0, 1, 0, 1], dtype=bool)
+    seqs = np.ones(3, dtype=bool)
+    # columns without gaps: 0, 2, 4, 5 -> everything from 0 to 5 is restored, 6 and 7 keep the trimmer's decision
+    assert oracle.terminal_only(a, keep, seqs, reading=0).tolist() == [True] * 6 + [False, True]
+    # first / last kept column: 0 .. 7
+    assert oracle.terminal_only(a, keep, seqs, reading=1).tolist() == [True] * 8
+    # dropping the second sequence makes column 3 gap free and column 1 not
+    assert oracle.terminal_only(a, keep, np.array([1, 0, 1], dtype=bool), reading=0).tolist() == [True] * 6 + [False, True]
+    assert oracle.terminal_only(oracle.pack(["A-", "-B"]), [True, False], [True, True], reading=0) is None
+
+
+@pytest.mark.skipif(oracle.lib_avx2() is None, reason="host CPU without AVX2")
+@pytest.mark.parametrize("shape", [(2, 5), (37, 301), (130, 64), (64, 8200)])
+def test_avx2_flavour_equals_scalar(shape):
+    """The AVX2 pair counts and similarity (the CPU baseline's SIMD flavour) against the scalar restatement:
+    integers equal, float32 sums bit-identical, errors at the same residue."""
+    m, n = shape
+    a = synth_msa(m, n, 77 + m)
+    hit, dst = oracle.pair_counts(a)
+    hit2, dst2 = oracle.pair_counts(a, avx2=True)
+    assert np.array_equal(hit, hit2) and np.array_equal(dst, dst2)
+    g, _, _, _ = oracle.gaps(a)
+    w = oracle.weights(hit, dst)
+    mdk, q = oracle.similarity(a, w, g, *oracle.aa_matrix())
+    mdk2, q2 = oracle.similarity(a, w, g, *oracle.aa_matrix(), avx2=True)
+    assert np.array_equal(q.view(np.uint32), q2.view(np.uint32))
+    assert np.array_equal(mdk.view(np.uint32), mdk2.view(np.uint32))
+    if n > 20:
+        b = a.copy()
+        b[m // 2, 17] = ord("B")  # not in BLOSUM62's alphabet
+        b[0, 19] = ord("?")
+        for flavour in (False, True):
+            with pytest.raises(oracle.OracleError) as e:
+                oracle.similarity(b, w, None, *oracle.aa_matrix(), avx2=flavour)
+            assert e.value.detail[:2] == (m // 2, 17)
