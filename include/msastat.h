@@ -139,6 +139,13 @@ float msa_cutpoint_clusters(const float *ident, const int32_t *lengths, int32_t 
 int msa_fasta_scan(const uint8_t *data, int64_t len, int32_t *m_out, int32_t *n_out);
 int msa_fasta_fill(const uint8_t *data, int64_t len, int32_t m, int32_t n, uint8_t *matrix, int64_t *name_off,
                    int32_t *name_len, const uint8_t *valid, msa_err_detail *detail);
+/* The same pair for Clustal text (`Alignment.load(file, "clustal")`, reference _trimal.pyx:517-601,834-850 and
+ * trimAl's clustal_state, format_handling.pxd:11-32): interleaved blocks of `name residues [count]` lines behind
+ * a header line; blank lines and conservation lines (leading blank) are skipped; the sequences are the names of
+ * the first block, in that order.  Same outputs and error codes as the FASTA pair. */
+int msa_clustal_scan(const uint8_t *data, int64_t len, int32_t *m_out, int32_t *n_out);
+int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int32_t n, uint8_t *matrix, int64_t *name_off,
+                     int32_t *name_len, const uint8_t *valid, msa_err_detail *detail);
 
 /* ---- whole trim: trimAlManager::clean_alignment (manager.pxd:88) as configured by the four
  *      `_configure_manager` methods (_trimal.pyx:1479-1497,1651-1659,1766-1769,1859-1862) ------ */

@@ -83,10 +83,13 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "libmsa_oracle.so")
+    # MSA_ORACLE_ASAN=1: the AddressSanitizer / UBSan build (run the CPU suite under LD_PRELOAD=libasan.so; GPU
+    # sanitizers are not available on the pool, so the CPU restatement is what gets this check)
+    name = "libmsa_oracle_asan.so" if os.environ.get("MSA_ORACLE_ASAN") else "libmsa_oracle.so"
+    path = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "msa_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "libmsa_oracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, name], check=True, capture_output=True)
     L = ctypes.CDLL(path)
     L.orc_gaps_cutpoint.restype = ctypes.c_double
     L.orc_sim_cutpoint.restype = ctypes.c_double

@@ -43,7 +43,7 @@ EXPORTS = [
     "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
     "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_prof_get", "msa_prof_reset",
-    "msa_prof_enable", "msa_fasta_scan", "msa_fasta_fill",
+    "msa_prof_enable", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
 ]
 
 
@@ -131,6 +131,8 @@ def load():
         L.msa_overlap.argtypes = [vp, f32, vp]
         L.msa_fasta_scan.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         L.msa_fasta_fill.argtypes = [vp, ctypes.c_int64, i32, i32, vp, vp, vp, vp, ctypes.POINTER(ErrDetail)]
+        L.msa_clustal_scan.argtypes = L.msa_fasta_scan.argtypes
+        L.msa_clustal_fill.argtypes = L.msa_fasta_fill.argtypes
         L.msa_window_i32.argtypes = [vp, i32, i32, vp]
         L.msa_window_f32.argtypes = [vp, i32, i32, vp]
         L.msa_gaps_cutpoint.argtypes = [vp, i32, i32, f32, f32]

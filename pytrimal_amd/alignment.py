@@ -246,11 +246,11 @@ class Alignment:
         if fmt is None:
             fmt = _sniff_format(data)
         fmt = fmt.lower()
-        if fmt == "fasta":
-            fast = _load_fasta_native(cls, data, file)
+        if fmt in ("fasta", "clustal"):
+            fast = _load_native(cls, data, file, fmt)
             if fast is not None:
                 return fast
-            names, seqs = _parse_fasta(data)
+            names, seqs = (_parse_fasta if fmt == "fasta" else _parse_clustal)(data)
         elif fmt in _PARSERS:
             try:
                 names, seqs = _PARSERS[fmt](data)
@@ -399,10 +399,11 @@ class TrimmedAlignment(Alignment):
 
 # --- minimal readers --------------------------------------------------------------------------
 
-def _load_fasta_native(cls, data, file):
-    """FASTA text -> Alignment through the native ingest of libmsastat (`msa_fasta_scan` / `msa_fasta_fill`):
-    one pass to size the matrix, one to fill it and validate the residues, no per-sequence Python objects
-    except the names.  Returns None when the library is not built (the pure-Python parser takes over)."""
+def _load_native(cls, data, file, fmt):
+    """FASTA / Clustal text -> Alignment through the native ingest of libmsastat (`msa_fasta_scan` / `msa_fasta_fill`,
+    `msa_clustal_scan` / `msa_clustal_fill`): one pass to size the matrix, one to fill it and validate the residues,
+    no per-sequence Python objects except the names.  Returns None when the library is not built or does not
+    recognise the text (the pure-Python parser takes over and reports the error)."""
     import ctypes
 
     from . import _lib
@@ -413,18 +414,23 @@ def _load_fasta_native(cls, data, file):
         return None
     buf = np.frombuffer(data, dtype=np.uint8)
     m, n = ctypes.c_int32(0), ctypes.c_int32(0)
-    if L.msa_fasta_scan(buf.ctypes.data, buf.size, ctypes.byref(m), ctypes.byref(n)) != 0:
+    scan, fill = (L.msa_fasta_scan, L.msa_fasta_fill) if fmt == "fasta" else (L.msa_clustal_scan, L.msa_clustal_fill)
+    if scan(buf.ctypes.data, buf.size, ctypes.byref(m), ctypes.byref(n)) != 0:
         return None
     m, n = m.value, n.value
     if m == 0:
+        if fmt != "fasta":
+            return None
         raise RuntimeError(f"Failed to load alignment from {file!r}.")
     matrix = np.empty((m, n), dtype=np.uint8)
     off = np.empty(m, dtype=np.int64)
     ln = np.empty(m, dtype=np.int32)
     valid = _VALID.view(np.uint8)
     detail = _lib.ErrDetail()
-    rc = L.msa_fasta_fill(buf.ctypes.data, buf.size, m, n, matrix.ctypes.data, off.ctypes.data, ln.ctypes.data,
-                          valid.ctypes.data, ctypes.byref(detail))
+    rc = fill(buf.ctypes.data, buf.size, m, n, matrix.ctypes.data, off.ctypes.data, ln.ctypes.data, valid.ctypes.data,
+              ctypes.byref(detail))
+    if rc not in (0, _lib.E_LENGTH_MISMATCH, _lib.E_BAD_RESIDUE):
+        return None
     names = [bytes(data[o:o + k]) for o, k in zip(off.tolist(), ln.tolist())]
     if rc == _lib.E_LENGTH_MISMATCH:
         raise ValueError(f"Sequence length mismatch in sequence {detail.row}: {detail.col} != {n}")

@@ -936,6 +936,7 @@ int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n
 int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     int rc = ensure_gaps(c, true);
     if (rc) return rc;
     if (gaps_out) std::copy(c->h_gaps.begin(), c->h_gaps.end(), gaps_out);
@@ -946,6 +947,7 @@ int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
 int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     int rc = run_pairs(c, false, false, true);
     if (rc) return rc;
     const size_t bytes = (size_t)c->m * c->m * sizeof(uint32_t);
@@ -958,6 +960,7 @@ int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
 int msa_identities(msa_ctx *c, float *ident, float *w) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     int rc = run_pairs(c, true, true, false);
     if (rc) return rc;
     const size_t row = (size_t)c->m * sizeof(float);
@@ -979,6 +982,7 @@ int msa_identities(msa_ctx *c, float *ident, float *w) {
 int msa_identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
     if (!c || !c->raw || !avg_seq || !max_seq || c->m < 2 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     return identity_stats(c, avg_seq, max_seq);
 }
 
@@ -993,6 +997,7 @@ int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t 
 int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
     if (!c || !c->raw || !spurious_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    TuneScope tune(c);
     return overlap(c, residue_overlap, spurious_out);
 }
 

@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <string_view>
+#include <unordered_set>
 #include <vector>
 
 #include "msastat.h"
@@ -524,6 +526,124 @@ extern "C" int msa_fasta_fill(const uint8_t *data, int64_t len, int32_t m, int32
     close_row();
     if (rc == MSA_OK && row + 1 != m) return MSA_E_INVALID;
     return rc;
+}
+
+// --------------------------------------------------------------------------------------------
+// Clustal ingest (Alignment.load(..., "clustal")): interleaved blocks -> dense residue matrix
+// --------------------------------------------------------------------------------------------
+namespace {
+// Calls line(name_begin, name_end, res_begin, res_end) for every data line: not the header (first line), not
+// blank, not a conservation line (one that starts with a blank); fields are separated by blanks, the first is
+// the sequence name, the second its residues of this block, anything behind (a running count) is ignored.
+template <class Line>
+void clustal_walk(const uint8_t *data, int64_t len, Line &&line) {
+    const uint8_t *p = data, *end = data + len;
+    bool first = true;
+    while (p < end) {
+        const uint8_t *eol = static_cast<const uint8_t *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!eol) eol = end;
+        const uint8_t *a = p;
+        p = eol + 1;
+        if (first) {
+            first = false;
+            continue;
+        }
+        if (a == eol || fasta_space(*a)) continue;
+        const uint8_t *ne = a;
+        while (ne < eol && !fasta_space(*ne)) ++ne;
+        const uint8_t *rb = ne;
+        while (rb < eol && fasta_space(*rb)) ++rb;
+        if (rb == eol) continue;  // a lone field: not a data line
+        const uint8_t *re = rb;
+        while (re < eol && !fasta_space(*re)) ++re;
+        line(a, ne, rb, re);
+    }
+}
+inline bool same_name(const uint8_t *a, const uint8_t *ae, const uint8_t *b, int32_t blen) {
+    return ae - a == blen && std::memcmp(a, b, static_cast<size_t>(blen)) == 0;
+}
+}  // namespace
+
+extern "C" int msa_clustal_scan(const uint8_t *data, int64_t len, int32_t *m_out, int32_t *n_out) {
+    if (!data || len < 0 || !m_out || !n_out) return MSA_E_INVALID;
+    // the sequences are the names of the first block (it ends when any of its names comes back); the width is
+    // what the first sequence collects over all blocks
+    std::unordered_set<std::string_view> seen;
+    const uint8_t *first = nullptr;
+    int32_t first_len = 0;
+    int64_t m = 0, n = 0;
+    bool first_block = true;
+    clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
+        const std::string_view name(reinterpret_cast<const char *>(a), static_cast<size_t>(ae - a));
+        if (!first) {
+            first = a;
+            first_len = static_cast<int32_t>(ae - a);
+        }
+        if (first_block) {
+            if (seen.insert(name).second) ++m;
+            else first_block = false;
+        }
+        if (same_name(a, ae, first, first_len)) n += re - rb;
+    });
+    if (m > INT32_MAX || n > INT32_MAX) return MSA_E_INVALID;
+    *m_out = static_cast<int32_t>(m);
+    *n_out = static_cast<int32_t>(n);
+    return MSA_OK;
+}
+
+extern "C" int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int32_t n, uint8_t *matrix,
+                                int64_t *name_off, int32_t *name_len, const uint8_t *valid, msa_err_detail *detail) {
+    if (!data || len < 0 || m < 0 || n < 0 || (!matrix && (int64_t)m * n > 0) || !name_off || !name_len) return MSA_E_INVALID;
+    std::vector<int64_t> col(static_cast<size_t>(m), 0);
+    int32_t known = 0, expect = 0;  // names seen so far; the row the next line should belong to (block order)
+    int rc = MSA_OK;
+    auto fail = [&](int code, int64_t r, int64_t c, int byte) {
+        if (rc != MSA_OK) return;
+        rc = code;
+        if (detail) {
+            detail->row = static_cast<int32_t>(r);
+            detail->col = static_cast<int32_t>(c);
+            detail->byte = byte;
+        }
+    };
+    clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
+        if (rc != MSA_OK) return;
+        int32_t row = -1;
+        if (expect < known && same_name(a, ae, data + name_off[expect], name_len[expect])) {
+            row = expect;  // the usual case: every block lists the sequences in the same order
+        } else {
+            for (int32_t r = 0; r < known && row < 0; ++r)
+                if (same_name(a, ae, data + name_off[r], name_len[r])) row = r;
+            if (row < 0) {
+                if (known >= m) {  // a name the scan did not count (it appears after the first block only)
+                    fail(MSA_E_INVALID, known, 0, 0);
+                    return;
+                }
+                row = known++;
+                name_off[row] = a - data;
+                name_len[row] = static_cast<int32_t>(ae - a);
+            }
+        }
+        expect = row + 1 < m ? row + 1 : 0;
+        uint8_t *dst = matrix + static_cast<size_t>(row) * static_cast<size_t>(n);
+        for (const uint8_t *q = rb; q < re; ++q) {
+            const int64_t c = col[row]++;
+            if (c >= n) continue;  // reported as a length mismatch below
+            if (valid && !valid[*q]) {
+                fail(MSA_E_BAD_RESIDUE, row, c, *q);
+                return;
+            }
+            dst[c] = *q;
+        }
+    });
+    if (rc != MSA_OK) return rc;
+    if (known != m) return MSA_E_INVALID;
+    for (int32_t r = 0; r < m; ++r)
+        if (col[r] != n) {
+            fail(MSA_E_LENGTH_MISMATCH, r, col[r], 0);
+            return rc;
+        }
+    return MSA_OK;
 }
 
 extern "C" {

@@ -167,16 +167,19 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
             const uint32_t *q = pi + off + t;  // wave-uniform address -> scalar loads
             const uint32_t a0 = q[0], a1 = q[ps], a2 = q[2 * ps], a3 = q[3 * ps], a4 = q[4 * ps], a5 = q[5 * ps],
                            a6 = q[6 * ps], vi = q[7 * ps];
+            const uint32_t nvi = ~vi;  // (scalar) columns in which row i holds no residue never count as hits
 #pragma unroll
             for (int u = 0; u < TJ; ++u) {
-                uint32_t d = a0 ^ b[u][0];
+                // d = "differs or not counted": one three-input boolean per plane, and hits are what is left --
+                // counted as misses (32 per chunk minus the hits), which saves the and-not in front of the popcount
+                uint32_t d = nvi | (a0 ^ b[u][0]);
                 d |= a1 ^ b[u][1];
                 d |= a2 ^ b[u][2];
                 d |= a3 ^ b[u][3];
                 d |= a4 ^ b[u][4];
                 d |= a5 ^ b[u][5];
                 d |= a6 ^ b[u][6];
-                hit[u][t] += __builtin_popcount(~d & vi);
+                hit[u][t] += __builtin_popcount(d);
                 dst[u][t] += __builtin_popcount(vi | b[u][7]);
             }
         }
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
             const int i = i0 + t;
             if (i >= m) break;
             const bool diag = (i == j);
-            const uint32_t h = diag ? 0u : hit[u][t], d = diag ? 0u : dst[u][t];
+            // (hit[][] counted the misses of all 32 * nchunk columns; the columns behind n are gaps in every row)
+            const uint32_t h = diag ? 0u : 32u * (uint32_t)nchunk - hit[u][t], d = diag ? 0u : dst[u][t];
             if (hit_out) {
                 hit_out[(size_t)i * m + j] = h;
                 hit_out[(size_t)j * m + i] = h;
@@ -2069,6 +2073,7 @@ Tuning tuning_from_env() {
     t.bx_cols = num("MSA_BX_COLS", 0);
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);
+    t.pair_ti = num("MSA_PAIR_TI", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {
@@ -2101,15 +2106,23 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
                         uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag) {
     // Two rows "j" per lane reuse the wave-uniform "i" words twice, but halve the number of waves: worth it only
     // once the upper triangle still holds several waves per SIMD (m >= ~3000); m_pad is a multiple of 128.
-    constexpr int TI = PAIR_TI;
-    const long waves2 = (long)((m + TI - 1) / TI) * (m_pad / 128) / 2;
-    if (waves2 >= 8192) {
-        dim3 grid((m + TI - 1) / TI, m_pad / 128);
-        pair_counts_kernel<TI, 2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag);
+    const int ti = tuning().pair_ti == 16 || tuning().pair_ti == 32 ? tuning().pair_ti : PAIR_TI;
+    const long waves2 = (long)((m + ti - 1) / ti) * (m_pad / 128) / 2;
+    const bool two = waves2 >= 8192;
+    dim3 grid((m + ti - 1) / ti, two ? m_pad / 128 : m_pad / 64);
+#define PAIR_LAUNCH(TI_, TJ_) \
+    pair_counts_kernel<TI_, TJ_><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag)
+    if (ti == 32) {
+        if (two) PAIR_LAUNCH(32, 2);
+        else PAIR_LAUNCH(32, 1);
+    } else if (ti == 16) {
+        if (two) PAIR_LAUNCH(16, 2);
+        else PAIR_LAUNCH(16, 1);
     } else {
-        dim3 grid((m + TI - 1) / TI, m_pad / 64);
-        pair_counts_kernel<TI, 1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag);
+        if (two) PAIR_LAUNCH(8, 2);
+        else PAIR_LAUNCH(8, 1);
     }
+#undef PAIR_LAUNCH
 }
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,

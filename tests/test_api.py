@@ -239,7 +239,7 @@ FASTA_CASES = [
 def test_native_fasta_ingest_matches_python_parser(text):
     from pytrimal_amd import alignment as A
 
-    fast = A._load_fasta_native(Alignment, text, "<test>")
+    fast = A._load_native(Alignment, text, "<test>", "fasta")
     assert fast is not None, "libmsastat_hip.so must be built (host functions need no device)"
     names, seqs = A._parse_fasta(text)
     slow = Alignment(names, seqs)
@@ -253,7 +253,7 @@ def test_native_fasta_ingest_on_fixture():
 
     with open(data_path("ENOG411BWBU.seq40.res60.fasta"), "rb") as f:
         text = f.read()
-    fast = A._load_fasta_native(Alignment, text, "<fixture>")
+    fast = A._load_native(Alignment, text, "<fixture>", "fasta")
     names, seqs = A._parse_fasta(text)
     assert fast.names == names and list(fast.sequences) == [s.decode() for s in seqs]
     assert len(fast.sequences) == 209 and len(fast.residues) == 1227
@@ -392,3 +392,42 @@ def test_trimmed_alignment_dumps_only_kept_cells():
         back = Alignment.load(io.BytesIO(t.dumps(fmt).encode()), fmt)
         assert list(back.sequences) == expect, fmt
         assert back.names == [n for n, k in zip(names, keep_seq) if k]
+
+
+def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
+    """`msa_clustal_scan` / `msa_clustal_fill` (C ABI, host code) against the line-splitting parser they replace:
+    the reference's fixture, the 6 x 46 example in three blocks with counts and conservation lines, blocks whose
+    order changes, and the error cases."""
+    from conftest import EXAMPLE_001
+    from pytrimal_amd import _lib, alignment as al
+
+    try:
+        _lib.load()
+    except RuntimeError:
+        pytest.skip("libmsastat_hip.so is not built")
+
+    def both(text):
+        names, seqs = al._parse_clustal(text)
+        native = al._load_native(Alignment, text, "<memory>", "clustal")
+        assert native is not None, "the native ingest declined a text the parser accepts"
+        assert native.names == names and [s.encode() for s in native.sequences] == seqs
+        return native
+
+    with open(data_path("example.001.gt90.w3.clw"), "rb") as f:
+        both(f.read())
+    blocks = []
+    for lo in (0, 20, 40):
+        rows = [b"%-12s%s %d" % (n, s[lo:lo + 20].encode(), min(46, lo + 20)) for n, s in zip(EXAMPLE_001_NAMES, EXAMPLE_001)]
+        blocks.append(b"\n".join(rows) + b"\n" + b" " * 12 + b"*  : ." + b"\n")
+    text = b"CLUSTAL W (1.83) multiple sequence alignment\n\n\n" + b"\n".join(blocks)
+    ali = both(text)
+    assert ali.names == EXAMPLE_001_NAMES and list(ali.sequences) == EXAMPLE_001
+    # second block in another order, CRLF line ends, tabs
+    swapped = b"CLUSTAL\r\n\r\nb\tAC-D\r\na\tACGT\r\n\r\na\tTT\r\nb\tGG\r\n"
+    ali = both(swapped)
+    assert ali.names == [b"b", b"a"] and list(ali.sequences) == ["AC-DGG", "ACGTTT"]
+    # rows of different lengths, and a byte that is no residue
+    with pytest.raises(ValueError):
+        Alignment.load(io.BytesIO(b"CLUSTAL\n\na ACGT\nb AC\n"), "clustal")
+    with pytest.raises(ValueError):
+        Alignment.load(io.BytesIO(b"CLUSTAL\n\na AC!T\nb ACGT\n"), "clustal")
