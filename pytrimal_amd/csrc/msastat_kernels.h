@@ -20,6 +20,7 @@ struct Tuning {
     int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)
     int bx_r0 = -1;            // MSA_BX_R0: rows evaluated in order before the first round (-1 = default)
     int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
+    int bx_compact = 0;        // MSA_BX_COMPACT=1: the rows of a round are consecutive valid rows (gather loads of W)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
 };
 Tuning tuning_from_env();

@@ -2074,6 +2074,7 @@ Tuning tuning_from_env() {
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);
     t.pair_ti = num("MSA_PAIR_TI", 0);
+    t.bx_compact = num("MSA_BX_COMPACT", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

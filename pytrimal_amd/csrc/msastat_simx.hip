@@ -122,6 +122,7 @@ struct ColView {
     int nvalid;
     gu8p colcode;                                            // the column's codes by row (codeT), BX_SKIP for a row that takes no part
     int ldw;
+    int compact;  // lanes of a round are consecutive entries of the compacted list (else consecutive rows)
 };
 
 // Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
@@ -131,6 +132,7 @@ struct ColView {
 // loop counters look divergent to the compiler.)
 __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int tfirst, int which, f2 s) {
     const int lane = threadIdx.x & 63;
+    if (cv.compact) j = uni((int)cv.row[j]);  // (a round's rows are list entries there)
     const uint32_t cj = cv.colcode[j];
     if (uni((int)cj) == (int)BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
@@ -239,8 +241,7 @@ template <bool DN, bool DD>
 __device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView cv, int tstart, int tend, uint32_t joff,
                                            const v32f &T, float e, f2 &an, f2 &an2, f2 &ad, f2 &ad2) {
     typedef const __attribute__((address_space(4))) uint32_t *c32;
-    // three stages, two register sets each: the list entries of group g + 2 are requested (scalar loads) while the
-    // W rows of group g + 1 are in flight (buffer loads) and group g is consumed
+    // the list entries of the group after next arrive by scalar loads while two groups of W rows are in flight
     struct Entries {
         uint32_t o[8];  // row offsets in W
         uint2 codes;    // 8 codes
@@ -256,12 +257,15 @@ __device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
     };
-    auto consume8 = [&](const float(&w)[8], const uint2 &codes) {
+    // consume the 8 rows of a group and, row by row, put the group after next into the registers just freed:
+    // every W row is requested 16 steps before its use with 16 registers in all
+    auto consume_reload = [&](float(&w)[8], const uint2 &codes, const Entries &next) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t word = i < 4 ? codes.x : codes.y;
             const uint32_t ak = (word >> (8 * (i & 3) + 3)) & 0x1Fu;  // code = 8 x table row
             const f2 x = f2{T[ak], e} * w[i];
+            w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[i], 0));
             const f2 xn = {x.x, x.x}, xd = {x.y, x.y};
             an += xn;
             ad += xd;
@@ -276,16 +280,18 @@ __device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView
     sload(eB, tstart + 8);
     bload(wA, eA);
     cA = eA.codes;
+    bload(wB, eB);
+    cB = eB.codes;
+    sload(eA, tstart + 16);
+    sload(eB, tstart + 24);
 #pragma unroll 1
     for (int t = tstart; t < tend; t += 16) {  // (the lists are padded: zero row, skipped codes)
-        bload(wB, eB);
-        cB = eB.codes;
-        sload(eA, t + 16);
-        consume8(wA, cA);
-        bload(wA, eA);
+        consume_reload(wA, cA, eA);
         cA = eA.codes;
-        sload(eB, t + 24);
-        consume8(wB, cB);
+        sload(eA, t + 32);
+        consume_reload(wB, cB, eB);
+        cB = eB.codes;
+        sload(eB, t + 40);
     }
 }
 
@@ -293,10 +299,10 @@ template <bool STAMP>
 __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_,
                                                                        const uint8_t *__restrict__ vcode_,
                                                                        const int32_t *__restrict__ nvalid,
-                                                                       const uint8_t *__restrict__ codeT_, int64_t ldk, int m,
+                                                                       const uint8_t *__restrict__ codeT_, int64_t ldk, int m_,
                                                                        int n, const int32_t *__restrict__ cols, int ncols,
                                                                        const float *__restrict__ wlow_, uint32_t wbytes,
-                                                                       const float *__restrict__ wup_, int ldw_, int r0_,
+                                                                       const float *__restrict__ wup_, int ldw_, int r0_, int compact_,
                                                                        const float *__restrict__ tab_g,
                                                                        float *__restrict__ num_out,
                                                                        float *__restrict__ den_out) {
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
     cv.nvalid = uni(nvalid[col]);
     cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
     cv.ldw = ldw_;
+    cv.compact = compact_;
     const int nv = cv.nvalid;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
 
@@ -334,13 +341,16 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
     // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles its
-    // lane), partners come from the compacted list (only valid rows cost a step).
-    int j0 = min(r0_, m - 1);
+    // lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes are
+    // consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
+    // consecutive floats): "row" j then means list entry j, m the number of valid rows, and every row is valid.
+    const int m = compact_ ? nv : m_;
+    int j0 = min(r0_, max(m - 1, 0));
     int tbase = 0;  // valid rows before j0
     {
         f2 s2 = {0.0f, 0.0f};
         for (int j = 0; j < j0; ++j) {
-            tbase += uni((int)cv.colcode[j]) != (int)BX_SKIP;
+            tbase += compact_ ? 1 : (uni((int)cv.colcode[j]) != (int)BX_SKIP);
             s2 = exact_row(cv, wup, tabp, j, tbase, 3, s2);
         }
         if (lane == 0) sall = s2.x;
@@ -368,8 +378,8 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
         const float Bn = rl(Bl, 0), un = rl(ul, 0), Bd = rl(Bl, 1), ud = rl(ul, 1);
         f2 an = {Bn, Bn + un}, an2 = {2.0f * Bn, 2.0f * Bn + 2.0f * un};
         f2 ad = {Bd, Bd + ud}, ad2 = {2.0f * Bd, 2.0f * Bd + 2.0f * ud};
-        const uint32_t joff = 4u * (uint32_t)(j0 + lane);
-        const uint32_t cj8 = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
+        const uint32_t joff = 4u * (compact_ ? (uint32_t)cv.row[j0 + lane] : (uint32_t)(j0 + lane));
+        const uint32_t cj8 = lane < nrows ? (uint32_t)(compact_ ? cv.code[j0 + lane] : cv.colcode[j0 + lane]) : BX_SKIP;
         const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
         v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
 #pragma unroll
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__res
 
 // leading dimension of the per-column lists: the valid rows, then >= 192 padding entries (a block of the ordered
 // path, two prefetched groups of the round loop)
-int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the round loop reads up to 39 entries past the last one)
+int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the round loop reads up to 55 entries past the last one)
 int bx_cols_pad(int n) { return (n + 1 + 63) / 64 * 64; }  // at least one all-skipped column behind the last one
 size_t bx_wlow_rows(int m) { return (size_t)m + 2; }         // row m: zeros (the padding entries of the lists point there)
 
@@ -553,16 +563,17 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
                          const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
     const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : BX_R0;
+    const int compact = tuning().bx_compact > 0 ? 1 : 0;
     const unsigned grid = (unsigned)((ncols + BX_WAVES - 1) / BX_WAVES);
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
     const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
     if ((tuning().sim_mode & 64) != 0)
         similarity_bx_kernel<true><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup,
-                                                                  ldw, r0, t, num_out, den_out);
+                                                                  ldw, r0, compact, t, num_out, den_out);
     else
         similarity_bx_kernel<false><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
-                                                                   wup, ldw, r0, t, num_out, den_out);
+                                                                   wup, ldw, r0, compact, t, num_out, den_out);
     return 0;
 }
 

@@ -31,7 +31,7 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COLS", "MSA_BX_R0"):
+        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -293,11 +293,19 @@ def test_similarity_kernel_variants(ctx_with, kernel, shape):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(m, n, 4242 + m))
 
 
-@pytest.mark.parametrize("cols", ["1", "2", "4"])
+@pytest.mark.parametrize("compact", ["0", "1"])
 @pytest.mark.parametrize("r0", ["0", "3", "8", "40"])
-def test_binade_kernel_shapes(ctx_with, cols, r0):
-    """Columns per wave and the number of rows evaluated in order before the first round must not matter."""
-    _sim_parity(ctx_with(MSA_BX_COLS=cols, MSA_BX_R0=r0), synth_msa(300, 150, 31))
+def test_binade_kernel_shapes(ctx_with, compact, r0):
+    """The lane layout (consecutive rows / consecutive valid rows) and the number of rows evaluated in order before
+    the first round must not matter."""
+    _sim_parity(ctx_with(MSA_BX_COMPACT=compact, MSA_BX_R0=r0), synth_msa(300, 150, 31))
+    _sim_parity(ctx_with(MSA_BX_COMPACT=compact, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+
+
+@pytest.mark.parametrize("shape", [(2, 70), (65, 64), (640, 257), (2100, 72), (9000, 8)])
+def test_binade_kernel_compact_lanes(ctx_with, shape):
+    m, n = shape
+    _sim_parity(ctx_with(MSA_BX_COMPACT="1"), synth_msa(m, n, 4242 + m))
 
 
 @pytest.mark.parametrize("kernel", ["chain", "pc"])
