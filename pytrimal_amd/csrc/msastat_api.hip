@@ -463,17 +463,29 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             msak::launch_sim_encode_cm(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
             msak::launch_bx_compact(c->stream, c->codeT.p, m, n, c->ldw, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p);
         }
-        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first
-        // (their waves run longest)
+        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first (their
+        // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
+        // goes with the lightest, the second with the second to last, ...
         const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
-        HIPCHK(c, c->h_simcols.reserve((size_t)n + 8));
+        const int q = msak::bx_cols_per_wave();
+        HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 16));
+        int32_t *order = c->h_simcols.p + n + 8, *list = c->h_simcols.p;
         int nact = 0;
         for (int j = 0; j < n; ++j)
-            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) c->h_simcols.p[nact++] = j;
-        std::stable_sort(c->h_simcols.p, c->h_simcols.p + nact, [&](int32_t x, int32_t y) {
+            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) order[nact++] = j;
+        std::stable_sort(order, order + nact, [&](int32_t x, int32_t y) {
             return c->h_gaps[x] + c->h_indets[x] < c->h_gaps[y] + c->h_indets[y];
         });
-        const int npad = nact;
+        int npad = 0;
+        if (q == 2) {
+            for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
+                list[npad++] = order[i];
+                list[npad++] = i < k ? order[k] : n;  // (an odd count leaves the middle column alone: column n is all skipped)
+            }
+        } else {
+            for (int i = 0; i < nact; ++i) list[npad++] = order[i];
+            while (npad % q) list[npad++] = n;
+        }
         HIPCHK(c, c->simcols.reserve((size_t)n + 8));
         if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));

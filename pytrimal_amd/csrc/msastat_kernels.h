@@ -44,6 +44,7 @@ int bx_cols_pad(int n);
 size_t bx_wlow_rows(int m);
 void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
                           const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key);
+int bx_cols_per_wave();
 void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, uint32_t *voff, uint16_t *vrow,
                        uint8_t *vcode, int32_t *nvalid);
 int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,

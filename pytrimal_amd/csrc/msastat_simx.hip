@@ -45,6 +45,8 @@ typedef const __attribute__((address_space(4))) uint32_t *cu32p;  // constant ad
 constexpr uint32_t BX_SKIP = 224;  // code (8 x table row) of a residue that takes no part: row / column 28 of the table is zero
 constexpr int BX_R0 = 8;           // rows evaluated in the reference's order before the first round
 constexpr int BX_WAVES = 4;        // waves per workgroup (they only share the table in LDS)
+constexpr int BX_Q = 1;            // columns per wave, advanced in turn.  2 (the host then pairs a heavy column with a
+                                   // light one, all waves resident from the start) measured 6.2 instead of 5.1 ms at C3
 
 // explicit address spaces: global loads (not flat) everywhere, scalar loads for wave-uniform addresses
 typedef const __attribute__((address_space(1))) float *gf32p;
@@ -318,118 +320,134 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
     const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
-    const int ci = blockIdx.x * BX_WAVES + wave;  // position in the list of columns
-    if (ci >= ncols) return;
-    const int col = uni(cols[ci]);
-    ColView cv;
-    cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
-    cv.row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
-    cv.code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
-    cv.nvalid = uni(nvalid[col]);
-    cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
-    cv.ldw = ldw_;
-    cv.compact = compact_;
-    const int nv = cv.nvalid;
+    const int ci = blockIdx.x * BX_WAVES + wave;  // the wave's group of BX_Q columns in the list
+    if (ci * BX_Q >= ncols) return;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
+    // A wave owns BX_Q columns and advances them in turn, one round each (BX_Q = 1 in production).
+    ColView cv[BX_Q];
+    int colid[BX_Q], mrows[BX_Q], j0[BX_Q], tbase[BX_Q];
+#pragma unroll
+    for (int q = 0; q < BX_Q; ++q) {
+        const int col = uni(cols[ci * BX_Q + q]);  // (the list is padded with column n: an all-skipped column)
+        colid[q] = col;
+        cv[q].off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
+        cv[q].row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
+        cv[q].code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
+        cv[q].nvalid = uni(nvalid[col]);
+        cv[q].colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
+        cv[q].ldw = ldw_;
+        cv[q].compact = compact_;
+        // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles
+        // its lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes
+        // are consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
+        // consecutive floats): "row" j then means list entry j, m the number of valid rows, every row is valid.
+        mrows[q] = compact_ ? cv[q].nvalid : m_;
+        j0[q] = min(r0_, max(mrows[q] - 1, 0));
+        tbase[q] = 0;  // valid rows before j0
+    }
 
-    // lane 0 / 1 hold the running numerator / denominator sum and the increment their last full round brought
-    // (the estimate behind the second-grid decision; < 0: unknown)
+    // lanes 2q / 2q+1 hold the running numerator / denominator sum of column q and the increment their last full
+    // round brought (the estimate behind the second-grid decision; < 0: unknown)
     float sall = 0.0f, pinc = -1.0f;
     unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_dual = 0, n_short = 0, t0c = 0, rt0 = 0;
     if (STAMP) {
         t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
-    // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles its
-    // lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes are
-    // consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
-    // consecutive floats): "row" j then means list entry j, m the number of valid rows, and every row is valid.
-    const int m = compact_ ? nv : m_;
-    int j0 = min(r0_, max(m - 1, 0));
-    int tbase = 0;  // valid rows before j0
-    {
+#pragma unroll
+    for (int q = 0; q < BX_Q; ++q) {
         f2 s2 = {0.0f, 0.0f};
-        for (int j = 0; j < j0; ++j) {
-            tbase += compact_ ? 1 : (uni((int)cv.colcode[j]) != (int)BX_SKIP);
-            s2 = exact_row(cv, wup, tabp, j, tbase, 3, s2);
+        for (int j = 0; j < j0[q]; ++j) {
+            tbase[q] += compact_ ? 1 : (uni((int)cv[q].colcode[j]) != (int)BX_SKIP);
+            s2 = exact_row(cv[q], wup, tabp, j, tbase[q], 3, s2);
         }
-        if (lane == 0) sall = s2.x;
-        if (lane == 1) sall = s2.y;
+        if (lane == 2 * q) sall = s2.x;
+        if (lane == 2 * q + 1) sall = s2.y;
     }
     if (STAMP) {
         const unsigned long long t1 = __builtin_readcyclecounter();
         t_pro = t1 - t0c;
         t0c = t1;
     }
-    const int tend = (nv + 7) & ~7;
     int guard = 0;  // every round commits at least one row; a round that does not would loop forever
-    while (j0 < m - 1 && tbase < nv) {
-        if (++guard > m + 64) {
+    bool more = true;
+    while (more) {
+        more = false;
+        if (++guard > m_ + 64) {
             sall = __uint_as_float(0x7FC00000u);  // (never reached; NaN results fail every parity test)
             break;
         }
-        const int nrows = min(64 - ((j0 - r0_) & 63), m - 1 - j0);
-        // Which chains may leave their binade in this round?  They also accumulate on the next grid.  A wrong
-        // "no" only shortens the round (resolve_chain), never the result.
-        float Bl, ul;
-        const bool grid = grid_of(sall, Bl, ul);
-        const bool risky = !grid || pinc < 0.0f || !(sall + 1.3f * pinc * ((float)nrows * (1.0f / 64.0f)) < 2.0f * Bl);
-        const uint32_t rb = (uint32_t)__ballot(lane < 2 && risky);
-        const float Bn = rl(Bl, 0), un = rl(ul, 0), Bd = rl(Bl, 1), ud = rl(ul, 1);
-        f2 an = {Bn, Bn + un}, an2 = {2.0f * Bn, 2.0f * Bn + 2.0f * un};
-        f2 ad = {Bd, Bd + ud}, ad2 = {2.0f * Bd, 2.0f * Bd + 2.0f * ud};
-        const uint32_t joff = 4u * (compact_ ? (uint32_t)cv.row[j0 + lane] : (uint32_t)(j0 + lane));
-        const uint32_t cj8 = lane < nrows ? (uint32_t)(compact_ ? cv.code[j0 + lane] : cv.colcode[j0 + lane]) : BX_SKIP;
-        const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
-        v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
 #pragma unroll
-        for (int a = 0; a < 32; ++a)
-            T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
-        const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
-        // partners: the valid rows behind j0 (entries at or before a lane's own row read zeros: W is lower
-        // triangular here); the group of 8 that holds the first of them
-        const int tstart = tbase & ~7;
-        switch (rb & 3u) {
-            case 0: round_loop<false, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-            case 1: round_loop<true, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-            case 2: round_loop<false, true>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-            default: round_loop<true, true>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-        }
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_loop += t1 - t0c;
-            t0c = t1;
-            ++n_rounds;
-            n_dual += __builtin_popcount(rb & 3u);
-        }
-        int limit = nrows;
-        {
-            const Resolved r = resolve_chain(cv, wup, tabp, j0, tbase, vmask, 0, rl(sall, 0), an.x - Bn, an.y - (Bn + un),
-                                             an2.x - 2.0f * Bn, an2.y - (2.0f * Bn + 2.0f * un), limit, (rb & 1u) != 0);
-            spbuf[wave][0][lane] = r.sp;
-            limit = uni(r.limit);
-        }
-        {
-            const Resolved r = resolve_chain(cv, wup, tabp, j0, tbase, vmask, 1, rl(sall, 1), ad.x - Bd, ad.y - (Bd + ud),
-                                             ad2.x - 2.0f * Bd, ad2.y - (2.0f * Bd + 2.0f * ud), limit, (rb & 2u) != 0);
-            spbuf[wave][1][lane] = r.sp;
-            limit = uni(r.limit);
-        }
-        limit = max(limit, 1);
-        if (lane < 2) {
-            const float snew = spbuf[wave][lane][limit - 1];  // (limit >= 1: every chain commits at least one row)
-            // (a short round is a poor sample of the increment per row: keep the previous estimate)
-            if (!grid) pinc = -1.0f;
-            else if (limit >= 16) pinc = (snew - sall) * (64.0f / (float)limit);
-            sall = snew;
-        }
-        if (STAMP) n_short += limit < nrows;
-        tbase += __builtin_popcountll(vmask & ((limit >= 64 ? 0ull : (1ull << limit)) - 1ull));
-        j0 += limit;
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_res += t1 - t0c;
-            t0c = t1;
+        for (int q = 0; q < BX_Q; ++q) {
+            const int nv = cv[q].nvalid, m = mrows[q];
+            if (!(j0[q] < m - 1 && tbase[q] < nv)) continue;
+            more = true;
+            const int nrows = min(64 - ((j0[q] - r0_) & 63), m - 1 - j0[q]);
+            // Which chains may leave their binade in this round?  They also accumulate on the next grid.  A wrong
+            // "no" only shortens the round (resolve_chain), never the result.
+            float Bl, ul;
+            const bool grid = grid_of(sall, Bl, ul);
+            const bool risky = !grid || pinc < 0.0f || !(sall + 1.3f * pinc * ((float)nrows * (1.0f / 64.0f)) < 2.0f * Bl);
+            const uint32_t rb = (uint32_t)(__ballot(risky) >> (2 * q)) & 3u;
+            const float Bn = rl(Bl, 2 * q), un = rl(ul, 2 * q), Bd = rl(Bl, 2 * q + 1), ud = rl(ul, 2 * q + 1);
+            f2 an = {Bn, Bn + un}, an2 = {2.0f * Bn, 2.0f * Bn + 2.0f * un};
+            f2 ad = {Bd, Bd + ud}, ad2 = {2.0f * Bd, 2.0f * Bd + 2.0f * ud};
+            const uint32_t joff = 4u * (compact_ ? (uint32_t)cv[q].row[j0[q] + lane] : (uint32_t)(j0[q] + lane));
+            const uint32_t cj8 =
+                lane < nrows ? (uint32_t)(compact_ ? cv[q].code[j0[q] + lane] : cv[q].colcode[j0[q] + lane]) : BX_SKIP;
+            const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
+            v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
+#pragma unroll
+            for (int a = 0; a < 32; ++a)
+                T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
+            const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
+            // partners: the valid rows behind j0 (entries at or before a lane's own row read zeros: W is lower
+            // triangular here); the group of 8 that holds the first of them
+            const int tstart = tbase[q] & ~7, tend = (nv + 7) & ~7;
+            switch (rb) {
+                case 0: round_loop<false, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                case 1: round_loop<true, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                case 2: round_loop<false, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                default: round_loop<true, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+            }
+            if (STAMP) {
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                t_loop += t1 - t0c;
+                t0c = t1;
+                ++n_rounds;
+                n_dual += __builtin_popcount(rb);
+            }
+            int limit = nrows;
+            {
+                const Resolved r = resolve_chain(cv[q], wup, tabp, j0[q], tbase[q], vmask, 0, rl(sall, 2 * q), an.x - Bn,
+                                                 an.y - (Bn + un), an2.x - 2.0f * Bn, an2.y - (2.0f * Bn + 2.0f * un), limit,
+                                                 (rb & 1u) != 0);
+                spbuf[wave][0][lane] = r.sp;
+                limit = uni(r.limit);
+            }
+            {
+                const Resolved r = resolve_chain(cv[q], wup, tabp, j0[q], tbase[q], vmask, 1, rl(sall, 2 * q + 1), ad.x - Bd,
+                                                 ad.y - (Bd + ud), ad2.x - 2.0f * Bd, ad2.y - (2.0f * Bd + 2.0f * ud), limit,
+                                                 (rb & 2u) != 0);
+                spbuf[wave][1][lane] = r.sp;
+                limit = uni(r.limit);
+            }
+            limit = max(limit, 1);
+            if ((lane >> 1) == q) {
+                const float snew = spbuf[wave][lane & 1][limit - 1];  // (limit >= 1: every chain commits at least one row)
+                // (a short round is a poor sample of the increment per row: keep the previous estimate)
+                if (!grid) pinc = -1.0f;
+                else if (limit >= 16) pinc = (snew - sall) * (64.0f / (float)limit);
+                sall = snew;
+            }
+            if (STAMP) n_short += limit < nrows;
+            tbase[q] += __builtin_popcountll(vmask & ((limit >= 64 ? 0ull : (1ull << limit)) - 1ull));
+            j0[q] += limit;
+            if (STAMP) {
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                t_res += t1 - t0c;
+                t0c = t1;
+            }
         }
     }
     if (STAMP && lane == 0) {
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
         atomicAdd(&g_bx_stamps[9], n_short);
         if (ci < 16384) {
             unsigned int *r = g_bx_rec + 8 * ci;
-            r[0] = (unsigned)col;
+            r[0] = (unsigned)colid[0];
             r[1] = (unsigned)(t_pro >> 6);
             r[2] = (unsigned)(t_loop >> 6);
             r[3] = (unsigned)(t_res >> 6);
@@ -454,11 +472,14 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
             r[6] = (unsigned)n_dual;
         }
     }
-    if (col < n) {
-        const float sn = rl(sall, 0), sd = rl(sall, 1);
-        if (lane == 0) {
-            num_out[col] = sn;
-            den_out[col] = sd;
+#pragma unroll
+    for (int q = 0; q < BX_Q; ++q) {
+        if (colid[q] < n) {
+            const float sn = rl(sall, 2 * q), sd = rl(sall, 2 * q + 1);
+            if (lane == 0) {
+                num_out[colid[q]] = sn;
+                den_out[colid[q]] = sd;
+            }
         }
     }
 }
@@ -556,15 +577,18 @@ void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ld
     bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, nvalid);
 }
 
-// cols: the columns to evaluate (device, ncols entries); the sums of every other column must have been zeroed
-// by the caller.  W (both triangles) must be smaller than 4 GB and m < 65535 (checked by the caller).
+int bx_cols_per_wave() { return BX_Q; }
+
+// cols: the columns to evaluate (device, ncols entries, a multiple of bx_cols_per_wave(): consecutive entries share a
+// wave; pad with the index n, the all-skipped column); the sums of every other column must have been zeroed by the
+// caller.  W (both triangles) must be smaller than 4 GB and m < 65535 (checked by the caller).
 int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
                          const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
     const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : BX_R0;
     const int compact = tuning().bx_compact > 0 ? 1 : 0;
-    const unsigned grid = (unsigned)((ncols + BX_WAVES - 1) / BX_WAVES);
+    const unsigned grid = (unsigned)((ncols / BX_Q + BX_WAVES - 1) / BX_WAVES);  // ncols is a multiple of BX_Q
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
     const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round-2 profiles: bench lines, rocprofv3 kernel stats and PMC HBM traffic per workload, SQ counters of C3.
+# Output under gpurun_out/r02/; tools/summarise_profiles_r02.py turns it into profiles/r02_*.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r02
+rm -rf $OUT; mkdir -p $OUT
+cd $ROOT
+for w in C3 C2 C4 C5; do
+  timeout 900 python bench.py --steps 10 --warmup 2 --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w rc=$?"
+done
+export TMPDIR=/tmp
+cd /tmp
+for w in C3 C2 C4 C5; do
+  steps=3; [ $w = C5 ] && steps=1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --workload $w > $OUT/stats_$w.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$w -- python3 $ROOT/bench.py --steps $steps --warmup 1 --no-cpu-baseline --workload $w > $OUT/fetch_$w.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$w -- python3 $ROOT/bench.py --steps $steps --warmup 1 --no-cpu-baseline --workload $w > $OUT/write_$w.log 2>&1
+  echo "profiled $w"
+done
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/sq1_C3 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq1_C3.log 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAVES SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/sq2_C3 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq2_C3.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1_C4 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload C4 > $OUT/sq1_C4.log 2>&1
+ls $OUT | head -40
+# keep only the small csv files (the merge back is limited to 64 MiB)
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
+du -sh $OUT
