@@ -21,6 +21,7 @@ struct Tuning {
     int bx_r0 = -1;            // MSA_BX_R0: rows evaluated in order before the first round (-1 = default)
     int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
     int bx_compact = 0;        // MSA_BX_COMPACT=1: the rows of a round are consecutive valid rows (gather loads of W)
+    int bx_asm = 0;            // MSA_BX_ASM=1: the round loop with the table read folded into the multiply (inline asm; experimental)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
 };
 Tuning tuning_from_env();

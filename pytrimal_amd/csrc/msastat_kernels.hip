@@ -2075,6 +2075,7 @@ Tuning tuning_from_env() {
     t.bx_waves = num("MSA_BX_WAVES", 0);
     t.pair_ti = num("MSA_PAIR_TI", 0);
     t.bx_compact = num("MSA_BX_COMPACT", 0);
+    t.bx_asm = num("MSA_BX_ASM", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

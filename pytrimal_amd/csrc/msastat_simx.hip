@@ -297,8 +297,106 @@ __device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView
     }
 }
 
-template <bool STAMP>
-__global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_,
+// ---- the same loop with the table read folded into the multiply --------------------------------------------
+// The compiler turns T[a_k] into s_set_gpr_idx_on / v_mov_b32 (relative source) / s_set_gpr_idx_off in front of the
+// packed multiply: four VALU instructions per step.  Here the lane's table column is a 32-register value pinned to
+// v[64:95] (physical-register constraints on every asm statement that touches it, so the compiler itself keeps it
+// there and out of everybody's way), the multiply reads v[64 + a_k] through the relative-source mode, four steps
+// under one s_set_gpr_idx_on, and EXEC holds only the lanes whose row takes part, so that the denominator term is
+// W itself: v_mul_f32 + two packed adds = three VALU instructions per step.  EXPERIMENTAL (MSA_BX_ASM=1, parity-tested):
+// per wave it is 18 % faster, but the pinned table fragments the register file -- at the 96 registers that five
+// waves per SIMD allow the allocator spills inside one of the loop versions, at 117 registers the occupancy drops
+// to four waves; either way the kernel as a whole does not gain (4.98 vs 5.27 ms at best, 6.5 ms at worst).
+
+// the lane's table column D[0..28][a_j] (stride 256 B in the LDS table); entries 29..31 are zero
+__device__ __forceinline__ v32f fill_table_regs(uint32_t lds_addr) {
+    v32f T;
+    asm volatile(
+        "ds_read_b32 v64, %1 offset:0\n\tds_read_b32 v65, %1 offset:256\n\tds_read_b32 v66, %1 offset:512\n\t"
+        "ds_read_b32 v67, %1 offset:768\n\tds_read_b32 v68, %1 offset:1024\n\tds_read_b32 v69, %1 offset:1280\n\t"
+        "ds_read_b32 v70, %1 offset:1536\n\tds_read_b32 v71, %1 offset:1792\n\tds_read_b32 v72, %1 offset:2048\n\t"
+        "ds_read_b32 v73, %1 offset:2304\n\tds_read_b32 v74, %1 offset:2560\n\tds_read_b32 v75, %1 offset:2816\n\t"
+        "ds_read_b32 v76, %1 offset:3072\n\tds_read_b32 v77, %1 offset:3328\n\tds_read_b32 v78, %1 offset:3584\n\t"
+        "ds_read_b32 v79, %1 offset:3840\n\tds_read_b32 v80, %1 offset:4096\n\tds_read_b32 v81, %1 offset:4352\n\t"
+        "ds_read_b32 v82, %1 offset:4608\n\tds_read_b32 v83, %1 offset:4864\n\tds_read_b32 v84, %1 offset:5120\n\t"
+        "ds_read_b32 v85, %1 offset:5376\n\tds_read_b32 v86, %1 offset:5632\n\tds_read_b32 v87, %1 offset:5888\n\t"
+        "ds_read_b32 v88, %1 offset:6144\n\tds_read_b32 v89, %1 offset:6400\n\tds_read_b32 v90, %1 offset:6656\n\t"
+        "ds_read_b32 v91, %1 offset:6912\n\tds_read_b32 v92, %1 offset:7168\n\t"
+        "v_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\ts_waitcnt lgkmcnt(0)"
+        : "={v[64:95]}"(T)
+        : "v"(lds_addr)
+        : "memory");
+    return T;
+}
+
+template <bool DN, bool DD>
+__device__ __forceinline__ void round_loop_asm(__amdgpu_buffer_rsrc_t wrsrc, ColView cv, int tstart, int tend, uint32_t joff,
+                                               const v32f &T, f2 &an, f2 &an2, f2 &ad, f2 &ad2) {
+    typedef const __attribute__((address_space(4))) uint32_t *c32;
+    struct Entries {
+        uint32_t o[8];  // row offsets in W
+        uint2 codes;    // 8 codes
+    };
+    auto sload = [&](Entries &en, int t) {
+        c32 po = (c32)(uint64_t)(cv.off + t);
+        c32 pc = (c32)(uint64_t)(cv.code + t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) en.o[i] = po[i];
+        en.codes = make_uint2(pc[0], pc[1]);
+    };
+    auto bload = [&](float(&w)[8], const Entries &en) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
+    };
+    auto consume_reload = [&](float(&w)[8], const uint2 &codes, const Entries &next) {
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+            const uint32_t word = h ? codes.y : codes.x;
+            const uint32_t k0 = (word >> 3) & 0x1Fu, k1 = (word >> 11) & 0x1Fu, k2 = (word >> 19) & 0x1Fu, k3 = word >> 27;
+            float x0, x1, x2, x3;
+            asm volatile(
+                "s_set_gpr_idx_on %[k0], gpr_idx(SRC1)\n\tv_mul_f32 %[x0], %[w0], v64\n\t"
+                "s_set_gpr_idx_idx %[k1]\n\tv_mul_f32 %[x1], %[w1], v64\n\t"
+                "s_set_gpr_idx_idx %[k2]\n\tv_mul_f32 %[x2], %[w2], v64\n\t"
+                "s_set_gpr_idx_idx %[k3]\n\tv_mul_f32 %[x3], %[w3], v64\n\t"
+                "s_set_gpr_idx_off"
+                : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3)
+                : [w0] "v"(w[h]), [w1] "v"(w[h + 1]), [w2] "v"(w[h + 2]), [w3] "v"(w[h + 3]), [k0] "s"(k0), [k1] "s"(k1),
+                  [k2] "s"(k2), [k3] "s"(k3), "{v[64:95]}"(T)
+                : "m0");
+            const float xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2 xn = {xs[i], xs[i]}, xd = {w[h + i], w[h + i]};
+                w[h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[h + i], 0));
+                an += xn;
+                ad += xd;
+                if (DN) an2 += xn;
+                if (DD) ad2 += xd;
+            }
+        }
+    };
+    // one group of 8 W rows in flight (8 steps of prefetch: more does not pay here and the registers are needed)
+    float w[8];
+    Entries e0, e1;
+    uint2 codes;
+    sload(e0, tstart);
+    sload(e1, tstart + 8);
+    bload(w, e0);
+    codes = e0.codes;
+#pragma unroll 1
+    for (int t = tstart; t < tend; t += 16) {
+        consume_reload(w, codes, e1);
+        codes = e1.codes;
+        sload(e0, t + 16);
+        consume_reload(w, codes, e0);
+        codes = e0.codes;
+        sload(e1, t + 24);
+    }
+}
+
+template <bool STAMP, bool ASM>
+__device__ __forceinline__ void similarity_bx_body(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_,
                                                                        const uint8_t *__restrict__ vcode_,
                                                                        const int32_t *__restrict__ nvalid,
                                                                        const uint8_t *__restrict__ codeT_, int64_t ldk, int m_,
@@ -396,19 +494,32 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
             const uint32_t cj8 =
                 lane < nrows ? (uint32_t)(compact_ ? cv[q].code[j0[q] + lane] : cv[q].colcode[j0[q] + lane]) : BX_SKIP;
             const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
-            v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
-#pragma unroll
-            for (int a = 0; a < 32; ++a)
-                T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
-            const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
             // partners: the valid rows behind j0 (entries at or before a lane's own row read zeros: W is lower
             // triangular here); the group of 8 that holds the first of them
             const int tstart = tbase[q] & ~7, tend = (nv + 7) & ~7;
-            switch (rb) {
-                case 0: round_loop<false, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                case 1: round_loop<true, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                case 2: round_loop<false, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                default: round_loop<true, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+            if (ASM) {
+                // EXEC = the lanes whose row takes part (the others keep their accumulators: increment 0)
+                const v32f T = fill_table_regs((uint32_t)(uintptr_t)tabp + cj8);
+                if (cj8 != BX_SKIP) {
+                    switch (rb) {
+                        case 0: round_loop_asm<false, false>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
+                        case 1: round_loop_asm<true, false>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
+                        case 2: round_loop_asm<false, true>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
+                        default: round_loop_asm<true, true>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
+                    }
+                }
+            } else {
+                v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
+#pragma unroll
+                for (int a = 0; a < 32; ++a)
+                    T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
+                const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
+                switch (rb) {
+                    case 0: round_loop<false, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                    case 1: round_loop<true, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                    case 2: round_loop<false, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                    default: round_loop<true, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
+                }
             }
             if (STAMP) {
                 const unsigned long long t1 = __builtin_readcyclecounter();
@@ -482,6 +593,26 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint
             }
         }
     }
+}
+
+// Two entry points over the same body: the loop with the folded table read needs 96 VGPRs to keep five waves per
+// SIMD and is compiled under that limit; the compiler-built loop must not be squeezed (its indexed table would spill).
+template <bool STAMP>
+__global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
+                 const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m_, int n,
+                 const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
+                 const float *__restrict__ wup_, int ldw_, int r0_, int compact_, const float *__restrict__ tab_g,
+                 float *__restrict__ num_out, float *__restrict__ den_out) {
+    similarity_bx_body<STAMP, false>(voff_, vrow_, vcode_, nvalid, codeT_, ldk, m_, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, compact_, tab_g, num_out, den_out);
+}
+template <bool STAMP>
+__global__ __launch_bounds__(64 * BX_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_bx_asm_kernel(
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
+                 const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m_, int n,
+                 const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
+                 const float *__restrict__ wup_, int ldw_, int r0_, int compact_, const float *__restrict__ tab_g,
+                 float *__restrict__ num_out, float *__restrict__ den_out) {
+    similarity_bx_body<STAMP, true>(voff_, vrow_, vcode_, nvalid, codeT_, ldk, m_, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, compact_, tab_g, num_out, den_out);
 }
 
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
@@ -592,12 +723,15 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
     const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
-    if ((tuning().sim_mode & 64) != 0)
-        similarity_bx_kernel<true><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup,
-                                                                  ldw, r0, compact, t, num_out, den_out);
-    else
-        similarity_bx_kernel<false><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
-                                                                   wup, ldw, r0, compact, t, num_out, den_out);
+    const bool stamp = (tuning().sim_mode & 64) != 0, use_asm = tuning().bx_asm != 0;
+#define BX_LAUNCH(KERNEL)                                                                                              \
+    KERNEL<<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup, ldw, r0, \
+                                          compact, t, num_out, den_out)
+    if (stamp && use_asm) BX_LAUNCH(similarity_bx_asm_kernel<true>);
+    else if (stamp) BX_LAUNCH(similarity_bx_kernel<true>);
+    else if (use_asm) BX_LAUNCH(similarity_bx_asm_kernel<false>);
+    else BX_LAUNCH(similarity_bx_kernel<false>);
+#undef BX_LAUNCH
     return 0;
 }
 

@@ -31,7 +31,7 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0"):
+        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -306,6 +306,17 @@ def test_binade_kernel_shapes(ctx_with, compact, r0):
 def test_binade_kernel_compact_lanes(ctx_with, shape):
     m, n = shape
     _sim_parity(ctx_with(MSA_BX_COMPACT="1"), synth_msa(m, n, 4242 + m))
+
+
+@pytest.mark.parametrize("asm", ["0", "1"])
+@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (300, 150), (640, 257), (2100, 72), (4040, 20)])
+def test_binade_kernel_loop_variants(ctx_with, asm, shape):
+    """The round loop as the compiler builds it and with the table read folded into the multiply (inline asm,
+    fixed table registers, EXEC limited to the rows that take part)."""
+    m, n = shape
+    _sim_parity(ctx_with(MSA_BX_ASM=asm), synth_msa(m, n, 977 + m))
+    if m == 300:
+        _sim_parity(ctx_with(MSA_BX_ASM=asm), _conserved_case(200, 70, 5))
 
 
 @pytest.mark.parametrize("kernel", ["chain", "pc"])
