@@ -58,10 +58,10 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
 
-    Within a rank the shard is trimmed by `threads` threads (`trim` is re-entrant, one device context
-    per thread): the similarity kernels of one alignment occupy 95 of the 256 CUs (each chain workgroup
-    claims a CU), so alignments in flight side by side raise the throughput of a GPU until the CUs are
-    taken (1000 x 4000 alignments: 1.2 / 2.2 / 2.8 / 3.2 M columns/s with 1 / 2 / 3 / 4 threads).
+    Within a rank the shard is trimmed by `threads` worker threads (`trim` is re-entrant, one device context and
+    stream per thread; the pool is kept between calls): one 1000 x 4000 alignment does not fill the chip and the
+    host side of a trim (list building, selection logic, synchronisations) is serial, so alignments in flight side
+    by side raise the throughput of a GPU (config 5, 64 alignments on one GPU: 5.1 M columns/s with 4 threads).
 
     `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
     which have no device).
