@@ -415,7 +415,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     if (npos < 1 || npos > 28) return MSA_E_INVALID;
     int rc = run_pairs(c, false, true, false);
     if (rc) return rc;
-    rc = ensure_gaps(c, c->tuning.sim_kernel == 0);  // (the binade-exact kernel's column list is built on the host)
+    rc = ensure_gaps(c, c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 3);  // (the binade-exact kernel's column list is built on the host)
     if (rc) return rc;
     const int m = c->m, n = c->n;
     // tables
@@ -445,7 +445,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // kernel.  All three are bit-exact and parity-tested against each other and the oracle.
     // (its compacted lists hold 16-bit row indices and 32-bit W offsets: larger alignments take the chain kernels)
     const bool bx_fits = m < 32000;
-    if (c->tuning.sim_kernel == 0 && bx_fits) {
+    if ((c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 3) && bx_fits) {
         const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
         HIPCHK(c, c->codeT.reserve(lsz));
         HIPCHK(c, c->bx_off.reserve(lsz));
@@ -492,9 +492,9 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
         {
             ProfScope ps(c, "sim");
-            const int e = msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p, m, n,
-                                                     c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
-                                                     c->simnum.p, c->simden.p);
+            const auto launch = c->tuning.sim_kernel == 3 ? msak::launch_similarity_bx : msak::launch_similarity_lg;
+            const int e = launch(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p,
+                                 npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
         }
         msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);

@@ -8,7 +8,8 @@ namespace msak {
 // Diagnostic switches (environment variables MSA_*), read ONCE when a context is created and handed to the
 // launch wrappers through a thread-local pointer for the duration of an API call (contexts are per thread).
 struct Tuning {
-    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact (default), 1 "chain" numerator + denominator kernels, 2 "pc"
+    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact with per-lane grids (default), 3 "bx" its one-grid-per-round predecessor,
+                               // 1 "chain" numerator + denominator kernels, 2 "pc"
     int sim_tcols = 0;         // MSA_SIM_TCOLS: column-tile width of the chain kernels (0 = 64)
     int sim_mode = 0;          // MSA_SIM_MODE: in-kernel stamps / ablations of the chain kernels
     int sim_tp = 1;            // MSA_SIM_TP=0: column-per-lane producers
@@ -53,6 +54,9 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
                          const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr);
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
+                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
+                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 bool sim_num_transposed(int tcols);
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                         const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols);

@@ -615,6 +615,265 @@ __global__ __launch_bounds__(64 * BX_WAVES) __attribute__((amdgpu_waves_per_eu(5
     similarity_bx_body<STAMP, true>(voff_, vrow_, vcode_, nvalid, codeT_, ldk, m_, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, compact_, tab_g, num_out, den_out);
 }
 
+// ---- per-lane grids ------------------------------------------------------------------------------------------
+// The kernel above fixes ONE grid per chain and round (the binade of the sum at the round's first row) and pays for
+// every binade crossing: a second pair of accumulators for predicted crossings, a round cut short for the others
+// (the early rounds, where the sum doubles every few rows, are walked three to four times).  Nothing in the scheme
+// needs the lanes of a round to agree on a grid: a lane's accumulators only have to start on the grid of the sum
+// IN FRONT OF ITS OWN ROW.  That sum is not known before the round, but it is predictable to a fraction of a row:
+//     increment of row j  ~  c * (valid rows behind j) * G[a_j],   G[a] = sum_b h_b D[b][a]
+// (h = the column's residue frequencies; G = 1 for the denominator; c = the ratio measured on the previous round,
+// on the ordered first row for the first round).  Every lane starts on the grid of its predicted sum, the round
+// loop has a single version (two packed adds per step, no second grid), every round covers its 64 rows, and the
+// stitching commits segment by segment: lanes whose grid is the binade the sum really is in are scanned as before;
+// a row whose sum leaves the binade (the crossing row, ~9 per chain at m = 2000) or whose prediction was wrong
+// (measured: none on the synthetic alignments) is evaluated in the reference's order.  A wrong prediction costs
+// one ordered row, never exactness: every commit is checked against the true sum.
+constexpr int LG_R0 = 1;  // rows evaluated in order before the first round (at least up to the first valid row)
+
+__device__ __forceinline__ float unif(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+
+// scan_rows over an arbitrary set of lanes
+__device__ __forceinline__ float scan_lanes(float s, float top, float ie, float io, unsigned long long segm, int lane, int &cross) {
+    const bool in = ((segm >> lane) & 1ull) != 0ull;
+    const float a = in ? ie : 0.0f;
+    const float P = wave_prefix(a);
+    unsigned long long ties = __ballot(in && ie != io);
+    float corr = 0.0f;
+    while (ties) {
+        const int t = __builtin_ctzll(ties);
+        ties &= ties - 1;
+        const float at = rl(a, t);
+        const float st = s + ((rl(P, t) - at) + rl(corr, t));
+        if (!(st < top)) break;
+        const float chosen = (__float_as_uint(st) & 1u) ? rl(io, t) : at;
+        const float delta = chosen - at;
+        if (lane >= t) corr += delta;
+    }
+    const float sp = s + (P + corr);
+    const unsigned long long x = __ballot(in && !(sp < top));
+    cross = x ? __builtin_ctzll(x) : 64;
+    return sp;
+}
+
+// One chain at the end of a round: s before the round's first row; per lane the grid it accumulated on (Bl; 0 =
+// plain sums from zero) and its increments for an even / odd sum.  Commits every row of vmask; returns the sum
+// behind the round and the number of rows that went through the ordered path.
+struct ResolvedLg {
+    float s;
+    int ordered;
+};
+__device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, int tbase, unsigned long long vall,
+                                              unsigned long long vmask, int kind, float s, float Bl, float ie, float io) {
+    const int lane = threadIdx.x & 63;
+    // (row j0 + x: its partners start at entry tbase + (valid rows of the round up to and including x))
+    auto tfirst = [&](int x) { return tbase + __builtin_popcountll(vall & ((2ull << x) - 1ull)); };
+    auto ordered_row = [&](int x, float from) {
+        const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{from, from});
+        return unif(kind ? r.y : r.x);
+    };
+    // a lane on plain sums that added nothing has only zero terms: it commits whatever the sum is
+    const unsigned long long plain = __ballot(Bl == 0.0f), nonzero = __ballot(ie != 0.0f);
+    unsigned long long todo = vmask & ~(plain & ~nonzero);
+    int ordered = 0;
+    while (todo) {
+        const int f = __builtin_ctzll(todo);
+        const float Bf = rl(Bl, f);
+        float B, u;
+        const bool g = grid_of(s, B, u);
+        if (Bf == 0.0f || !g || B != Bf) {  // not the grid the sum is on: this row in order
+            s = ordered_row(f, s);
+            ++ordered;
+            todo &= todo - 1;
+            continue;
+        }
+        const unsigned long long segm = __ballot(Bl == Bf) & todo;
+        int x;
+        const float sp = scan_lanes(s, 2.0f * B, ie, io, segm, lane, x);
+        if (x >= 64) {
+            s = rl(sp, 63 - __builtin_clzll(segm));
+            todo &= ~segm;
+            continue;
+        }
+        // row x would leave the binade: commit the rows before it, evaluate it in order
+        const unsigned long long before = segm & ((1ull << x) - 1ull);
+        s = ordered_row(x, before ? rl(sp, 63 - __builtin_clzll(before)) : s);
+        ++ordered;
+        todo &= ~(segm & ((2ull << x) - 1ull));
+    }
+    return ResolvedLg{s, ordered};
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
+    const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m, int n,
+    const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
+    const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g, float *__restrict__ num_out,
+    float *__restrict__ den_out) {
+    const gf32p wup = (gf32p)(uint64_t)wup_;
+    __shared__ f2 tab[32 * 32];              // {distance, both valid}[row code][column code], rows 28.. zero
+    __shared__ uint32_t hist[BX_WAVES][32];  // residue counts of the wave's column
+    __shared__ float gtab[BX_WAVES][32];     // G[a] = mean over the column's valid rows of D[.][a]
+    for (int i = threadIdx.x; i < 32 * 32; i += 64 * BX_WAVES) {
+        f2 v = {0.0f, 0.0f};
+        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
+        tab[i] = v;
+    }
+    if (threadIdx.x < BX_WAVES * 32) (&hist[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+    const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    const int ci = blockIdx.x * BX_WAVES + wave;
+    if (ci >= ncols) return;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
+    const int col = uni(cols[ci]);
+    ColView cv;
+    cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
+    cv.row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
+    cv.code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
+    cv.nvalid = uni(nvalid[col]);
+    cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
+    cv.ldw = ldw_;
+    cv.compact = 0;
+    const int nv = cv.nvalid;
+    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t0c = 0, rt0 = 0;
+    if (STAMP) {
+        t0c = __builtin_readcyclecounter();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // the column's residue frequencies -> G
+    for (int t = lane; t < nv; t += 64) atomicAdd(&hist[wave][cv.code[t] >> 3], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (lane < 32) {
+        float g = 0.0f;
+        for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
+        gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    // the first rows in the reference's order: at least up to the first row that takes part
+    f2 s2 = {0.0f, 0.0f};
+    float qn0 = 0.0f, qd0 = 0.0f;
+    int jstart = 0, tb = 0;
+    {
+        bool seen = false;
+        while (jstart < m - 1 && tb < nv && (jstart < r0_ || !seen)) {
+            const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
+            if (cj != BX_SKIP) {
+                ++tb;
+                seen = true;
+                const float rem = (float)(nv - tb);
+                qd0 += rem;
+                qn0 += rem * gtab[wave][cj >> 3];
+                s2 = exact_row(cv, wup, tabp, jstart, tb, 3, s2);
+            }
+            ++jstart;
+        }
+    }
+    float sn = unif(s2.x), sd = unif(s2.y);
+    qn0 = unif(qn0);
+    qd0 = unif(qd0);
+    // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
+    float cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
+    float cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
+    if (STAMP) {
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        t_pro = t1 - t0c;
+        t0c = t1;
+    }
+    int j0 = jstart & ~63;
+    int first = jstart - j0;  // the round's lanes before it were evaluated above
+    int tbase;                // valid rows before j0
+    {
+        const int r = j0 + lane;
+        const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
+        tbase = tb - __builtin_popcountll(__ballot(v));
+    }
+    for (; j0 < m - 1 && tbase < nv; j0 += 64) {
+        const int nrows = min(64, m - 1 - j0);
+        const uint32_t craw = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
+        const unsigned long long vall = __ballot(craw != BX_SKIP);
+        const uint32_t cj8 = lane >= first ? craw : BX_SKIP;
+        const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
+        first = 0;
+        // predicted sum in front of every row -> the lane's grid
+        const int behind = nv - (tbase + __builtin_popcountll(vall & ((2ull << lane) - 1ull)));
+        const bool takes = cj8 != BX_SKIP;
+        const float qd = takes ? (float)behind : 0.0f;
+        const float qn = takes ? (float)behind * gtab[wave][cj8 >> 3] : 0.0f;
+        float Bn, Bd, Qn, Qd;
+        {
+            const float Pd = wave_prefix(qd), Pn = wave_prefix(qn);
+            float un, ud;
+            grid_of(sn + cn * (Pn - qn), Bn, un);
+            grid_of(sd + cd * (Pd - qd), Bd, ud);
+            Qn = rl(Pn, 63);
+            Qd = rl(Pd, 63);
+        }
+        // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
+        f2 an = {Bn, Bn + Bn * 0x1p-23f}, ad = {Bd, Bd + Bd * 0x1p-23f}, an2 = {0.0f, 0.0f}, ad2 = {0.0f, 0.0f};
+        const uint32_t joff = 4u * (uint32_t)(j0 + lane);
+        const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
+        {
+            v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
+#pragma unroll
+            for (int a = 0; a < 32; ++a)
+                T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
+            const float e = takes ? 1.0f : 0.0f;
+            round_loop<false, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2);
+        }
+        if (STAMP) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            t_loop += t1 - t0c;
+            t0c = t1;
+            ++n_rounds;
+        }
+        const ResolvedLg rn = resolve_lg(cv, wup, tabp, j0, tbase, vall, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
+        const ResolvedLg rd = resolve_lg(cv, wup, tabp, j0, tbase, vall, vmask, 1, sd, Bd, ad.x - Bd, ad.y - (Bd + Bd * 0x1p-23f));
+        const float sn1 = unif(rn.s), sd1 = unif(rd.s);
+        if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);
+        if (sd1 > sd && Qd > 0.0f) cd = unif((sd1 - sd) / Qd);
+        sn = sn1;
+        sd = sd1;
+        tbase += __builtin_popcountll(vall);
+        if (STAMP) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            t_res += t1 - t0c;
+            t0c = t1;
+            n_ordered += (unsigned)(rn.ordered + rd.ordered);
+        }
+    }
+    if (STAMP && lane == 0) {
+        atomicAdd(&g_bx_stamps[0], t_pro);
+        atomicAdd(&g_bx_stamps[1], t_loop);
+        atomicAdd(&g_bx_stamps[2], t_res);
+        atomicAdd(&g_bx_stamps[3], 1ull);
+        atomicAdd(&g_bx_stamps[4], n_rounds);
+        atomicAdd(&g_bx_stamps[6], __builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
+        atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
+        atomicMax(&g_bx_stamps[8], n_rounds);
+        atomicAdd(&g_bx_stamps[10], n_ordered);
+        if (ci < 16384) {
+            unsigned int *r = g_bx_rec + 8 * ci;
+            r[0] = (unsigned)col;
+            r[1] = (unsigned)(t_pro >> 6);
+            r[2] = (unsigned)(t_loop >> 6);
+            r[3] = (unsigned)(t_res >> 6);
+            r[4] = (unsigned)n_rounds;
+            r[5] = 0;
+            r[6] = (unsigned)n_ordered;
+        }
+    }
+    if (col < n && lane == 0) {
+        num_out[col] = sn;
+        den_out[col] = sd;
+    }
+}
+
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
 // row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
@@ -732,6 +991,25 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     else if (use_asm) BX_LAUNCH(similarity_bx_asm_kernel<false>);
     else BX_LAUNCH(similarity_bx_kernel<false>);
 #undef BX_LAUNCH
+    return 0;
+}
+
+// the same contract as launch_similarity_bx; the kernel with per-lane grids (the default)
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
+                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
+                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
+    const int64_t ldk = bx_ldk(m);
+    const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0;
+    const unsigned grid = (unsigned)((ncols + BX_WAVES - 1) / BX_WAVES);
+    if (grid == 0) return 0;
+    const float *t = static_cast<const float *>(tab);
+    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
+    if (tuning().sim_mode & 64)
+        similarity_lg_kernel<true><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
+                                                                  wup, ldw, r0, t, num_out, den_out);
+    else
+        similarity_lg_kernel<false><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
+                                                                   wup, ldw, r0, t, num_out, den_out);
     return 0;
 }
 

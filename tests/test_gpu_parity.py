@@ -281,7 +281,9 @@ def _sim_parity(ctx, a, indet=ord("X")):
     assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
 
 
-KERNELS = ["", "chain", "pc"]  # binade-exact (default), numerator + denominator chain kernels, single chain
+# binade-exact with per-lane grids (default), its one-grid-per-round predecessor, numerator + denominator chain
+# kernels, single chain
+KERNELS = ["", "bx", "chain", "pc"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -298,14 +300,34 @@ def test_similarity_kernel_variants(ctx_with, kernel, shape):
 def test_binade_kernel_shapes(ctx_with, compact, r0):
     """The lane layout (consecutive rows / consecutive valid rows) and the number of rows evaluated in order before
     the first round must not matter."""
-    _sim_parity(ctx_with(MSA_BX_COMPACT=compact, MSA_BX_R0=r0), synth_msa(300, 150, 31))
-    _sim_parity(ctx_with(MSA_BX_COMPACT=compact, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT=compact, MSA_BX_R0=r0), synth_msa(300, 150, 31))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT=compact, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+
+
+@pytest.mark.parametrize("r0", ["0", "1", "3", "8", "40", "64", "70", "200"])
+def test_lane_grid_kernel_ordered_prefix(ctx_with, r0):
+    """Per-lane grids: the number of rows evaluated in order before the first round (which then starts in the middle
+    of a 64-row block, or several blocks in) must not matter."""
+    _sim_parity(ctx_with(MSA_BX_R0=r0), synth_msa(300, 150, 31))
+    _sim_parity(ctx_with(MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+
+
+def test_lane_grid_kernel_adversarial_predictions(ctx):
+    """Columns whose sums the per-lane predictor cannot foresee: the top half of the rows identical sequences (all
+    their mutual weights zero, then a jump), a block of gaps in the middle of every column, residues sorted by row."""
+    r = np.random.default_rng(5)
+    a = synth_msa(400, 96, 123)
+    a[:200, :] = a[0, :]                       # W = 0 among the first 200 rows
+    a[120:260, 10:40] = ord("-")               # no valid row for 140 rows
+    a[:, 50:60] = np.sort(a[:, 50:60], axis=0)  # residues (and gaps) sorted along the column
+    a[r.random(a.shape) < 0.01] = ord("X")
+    _sim_parity(ctx, np.ascontiguousarray(a))
 
 
 @pytest.mark.parametrize("shape", [(2, 70), (65, 64), (640, 257), (2100, 72), (9000, 8)])
 def test_binade_kernel_compact_lanes(ctx_with, shape):
     m, n = shape
-    _sim_parity(ctx_with(MSA_BX_COMPACT="1"), synth_msa(m, n, 4242 + m))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT="1"), synth_msa(m, n, 4242 + m))
 
 
 @pytest.mark.parametrize("asm", ["0", "1"])
@@ -314,9 +336,9 @@ def test_binade_kernel_loop_variants(ctx_with, asm, shape):
     """The round loop as the compiler builds it and with the table read folded into the multiply (inline asm,
     fixed table registers, EXEC limited to the rows that take part)."""
     m, n = shape
-    _sim_parity(ctx_with(MSA_BX_ASM=asm), synth_msa(m, n, 977 + m))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_ASM=asm), synth_msa(m, n, 977 + m))
     if m == 300:
-        _sim_parity(ctx_with(MSA_BX_ASM=asm), _conserved_case(200, 70, 5))
+        _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_ASM=asm), _conserved_case(200, 70, 5))
 
 
 @pytest.mark.parametrize("kernel", ["chain", "pc"])
@@ -332,13 +354,13 @@ def test_similarity_above_resident_limit(ctx_with, kernel):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2100, 72, 77))
 
 
-@pytest.mark.parametrize("kernel", ["", "chain"])
+@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
 def test_similarity_36_round_resident_kernel(ctx_with, kernel):
     """2016 < m <= 4032: the 36-round instantiation of the resident numerator kernel."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2017, 33, 79))
 
 
-@pytest.mark.parametrize("kernel", ["", "chain"])
+@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
 def test_similarity_streaming_numerator(ctx_with, kernel):
     """m > 4032: the chain numerator kernel streams its codes two rounds ahead."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(4040, 20, 80))
@@ -355,13 +377,13 @@ def test_similarity_fallback_kernels(ctx_with, switch, shape):
     _sim_parity(ctx_with(MSA_SIM_KERNEL="chain", **{name: value}), synth_msa(m, n, 515 + m))
 
 
-@pytest.mark.parametrize("kernel", ["", "chain"])
+@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
 def test_similarity_many_rows_few_columns(ctx_with, kernel):
     """m = 9000, a single partial column tile."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(9000, 8, 81))
 
 
-@pytest.mark.parametrize("kernel", ["", "chain"])
+@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
 def test_similarity_at_resident_limit(ctx_with, kernel):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2016, 40, 78))
 
@@ -432,7 +454,7 @@ def test_nucleotide_statistics(ctx, degenerate):
     assert err is None
 
 
-@pytest.mark.parametrize("kernel", ["", "chain"])
+@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
 def test_wide_alignment_many_workgroups(ctx_with, kernel):
     """Many more column tiles than CUs (the chain workgroups take a CU each): several waves of workgroups."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(60, 40000, 4321))

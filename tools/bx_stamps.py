@@ -17,11 +17,11 @@ dist = np.ascontiguousarray(mat._dist, dtype=np.float32)
 lib = _lib.load()
 lib.msa_debug_bx_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.msa_debug_bx_records.argtypes = [ctypes.c_void_p, ctypes.c_int]
-COLS = os.environ.get("BX_STAMP_COMPACT", "0,1").split(",")
-R0S = os.environ.get("BX_STAMP_R0", "8").split(",")
+COLS = os.environ.get("BX_STAMP_COMPACT", "0").split(",")
+R0S = os.environ.get("BX_STAMP_R0", "").split(",")
 for cols in COLS:
     for r0 in R0S:
-        os.environ.update(MSA_SIM_MODE="64", MSA_BX_COMPACT=cols, MSA_BX_R0=r0)
+        os.environ.update(MSA_SIM_MODE="64", MSA_BX_COMPACT=cols, **({"MSA_BX_R0": r0} if r0 != "" else {}))
         wv = os.environ.get("MSA_BX_ASM", "")
         ctx = _lib.Context(0)
         ctx.upload(a, ord("X"))
@@ -36,7 +36,7 @@ for cols in COLS:
         lib.msa_debug_bx_stamps(buf, 1)
         ms, k = ctx.prof_get("sim")
         w = max(buf[3], 1)
-        print(json.dumps({"asm": wv, "compact": int(cols), "r0": int(r0), "sim_ms": round(ms / max(k, 1), 3), "waves": buf[3],
+        print(json.dumps({"asm": wv, "compact": int(cols), "r0": r0, "ordered_rows_per_wave": round(buf[10] / w, 1), "sim_ms": round(ms / max(k, 1), 3), "waves": buf[3],
                           "rounds_per_wave": round(buf[4] / w, 1), "dual_chains_per_round": round(buf[5] / max(buf[4], 1), 2),
                           "max_rounds": buf[8], "shortened_per_wave": round(buf[9] / w, 2), "wave_ms_avg": round(buf[6] / w / 1e5, 3), "longest_wave_kcycles": round(buf[7] / 1e3, 1),
                           "clock_GHz": round((buf[0] + buf[1] + buf[2]) / max(buf[6], 1) / 10, 3), "kcycles_per_wave": {
