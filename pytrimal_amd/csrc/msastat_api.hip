@@ -99,10 +99,12 @@ struct msa_ctx {
     DevBuf<uint8_t> codeT;     // column-major similarity codes of that kernel
     DevBuf<uint32_t> bx_off;   // ... and the compacted lists of every column's valid rows: W row offset,
     DevBuf<uint16_t> bx_row;   //     row index,
-    DevBuf<uint8_t> bx_code;   //     code
+    DevBuf<uint8_t> bx_code;   //     code,
+    DevBuf<uint16_t> bx_trow;  //     byte offset of the residue's row in a [row][64 lanes] float table
     DevBuf<int32_t> bx_nvalid;
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
     PinBuf<int32_t> h_simcols;
+    std::vector<int32_t> sort_order, sort_bins;  // scratch of the column ordering
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
@@ -413,6 +415,12 @@ int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_de
 int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed,
                float *mdk_out, float *q_out, msa_err_detail *detail) {
     if (npos < 1 || npos > 28) return MSA_E_INVALID;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {  // MSA_TRACE=1: host time since the call began
+        if (c->tuning.trace)
+            std::fprintf(stderr, "[similarity] %-20s at %8.1f us\n", what,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     int rc = run_pairs(c, false, true, false);
     if (rc) return rc;
     rc = ensure_gaps(c, c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 3);  // (the binade-exact kernel's column list is built on the host)
@@ -451,6 +459,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, c->bx_off.reserve(lsz));
         HIPCHK(c, c->bx_row.reserve(lsz));
         HIPCHK(c, c->bx_code.reserve(lsz));
+        HIPCHK(c, c->bx_trow.reserve(lsz));
         HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
         HIPCHK(c, c->errkey.reserve(1));
         HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
@@ -461,21 +470,31 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         {
             ProfScope pe(c, "encode");
             msak::launch_sim_encode_cm(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
-            msak::launch_bx_compact(c->stream, c->codeT.p, m, n, c->ldw, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p);
+            msak::launch_bx_compact(c->stream, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p,
+                                    c->bx_nvalid.p);
         }
+        mark("lists enqueued");
         // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first (their
         // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
         // goes with the lightest, the second with the second to last, ...
         const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
         const int q = msak::bx_cols_per_wave();
         HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 16));
-        int32_t *order = c->h_simcols.p + n + 8, *list = c->h_simcols.p;
+        // (counting sort by the number of rows that take no part, stable, in ordinary memory: the pinned staging
+        // buffer is only written once, front to back)
+        int32_t *list = c->h_simcols.p;
+        std::vector<int32_t> &order = c->sort_order, &bins = c->sort_bins;
+        order.resize((size_t)n + 1);
+        bins.assign((size_t)m + 2, 0);
         int nact = 0;
         for (int j = 0; j < n; ++j)
-            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) order[nact++] = j;
-        std::stable_sort(order, order + nact, [&](int32_t x, int32_t y) {
-            return c->h_gaps[x] + c->h_indets[x] < c->h_gaps[y] + c->h_indets[y];
-        });
+            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) ++bins[std::min(c->h_gaps[j] + c->h_indets[j], m) + 1];
+        for (int g = 0; g <= m; ++g) bins[g + 1] += bins[g];
+        for (int j = 0; j < n; ++j)
+            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) {
+                order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
+                ++nact;
+            }
         int npad = 0;
         if (q == 2) {
             for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
@@ -486,20 +505,28 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             for (int i = 0; i < nact; ++i) list[npad++] = order[i];
             while (npad % q) list[npad++] = n;
         }
+        mark("columns sorted");
         HIPCHK(c, c->simcols.reserve((size_t)n + 8));
         if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
         {
             ProfScope ps(c, "sim");
-            const auto launch = c->tuning.sim_kernel == 3 ? msak::launch_similarity_bx : msak::launch_similarity_lg;
-            const int e = launch(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p,
-                                 npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
+            const int e = c->tuning.sim_kernel == 3
+                              ? msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p,
+                                                           m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
+                                                           c->simnum.p, c->simden.p)
+                              : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, npos,
+                                                           c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
+                                                           c->ldw, c->tab.p, c->simnum.p, c->simden.p);
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
         }
         msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
         HIPCHK(c, hipGetLastError());
-        return fetch_similarity(c, n, mdk_out, q_out, detail);
+        mark("kernel enqueued");
+        rc = fetch_similarity(c, n, mdk_out, q_out, detail);
+        mark("results fetched");
+        return rc;
     }
     const bool split = c->tuning.sim_kernel != 2;
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
@@ -864,7 +891,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();

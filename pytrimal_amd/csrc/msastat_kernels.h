@@ -23,6 +23,8 @@ struct Tuning {
     int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
     int bx_compact = 0;        // MSA_BX_COMPACT=1: the rows of a round are consecutive valid rows (gather loads of W)
     int bx_asm = 0;            // MSA_BX_ASM=1: the round loop with the table read folded into the multiply (inline asm; experimental)
+    int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
+    int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, with MSA_SIM_MODE=64 only; 2: four waves per workgroup)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
 };
 Tuning tuning_from_env();
@@ -47,16 +49,16 @@ size_t bx_wlow_rows(int m);
 void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
                           const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key);
 int bx_cols_per_wave();
-void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, uint32_t *voff, uint16_t *vrow,
-                       uint8_t *vcode, int32_t *nvalid);
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vrow,
+                       uint8_t *vcode, uint16_t *vtrow, int32_t *nvalid);
 int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
                          const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr);
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
-                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
-                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
+                         int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
+                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 bool sim_num_transposed(int tcols);
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                         const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols);

@@ -2076,6 +2076,8 @@ Tuning tuning_from_env() {
     t.pair_ti = num("MSA_PAIR_TI", 0);
     t.bx_compact = num("MSA_BX_COMPACT", 0);
     t.bx_asm = num("MSA_BX_ASM", 0);
+    t.lg_regs = num("MSA_LG_REGS", 0);
+    t.lg_dbg = num("MSA_LG_DBG", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

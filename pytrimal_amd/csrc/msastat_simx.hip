@@ -125,6 +125,7 @@ struct ColView {
     gu8p colcode;                                            // the column's codes by row (codeT), BX_SKIP for a row that takes no part
     int ldw;
     int compact;  // lanes of a round are consecutive entries of the compacted list (else consecutive rows)
+    int lastpad;  // the last entry of the lists (padding)
 };
 
 // Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
@@ -132,6 +133,29 @@ struct ColView {
 // s = {numerator sum, denominator sum}; `which` selects the sums to advance.
 // (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
 // loop counters look divergent to the compiler.)
+// 256 consecutive terms (x[i]: term 64 i + lane) added to s in order: one test for all of them, else block by block
+__device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
+    float B, u;
+    if (grid_of(s, B, u)) {
+        const float Bo = B + u;
+        float tot = 0.0f;
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float re = (B + x[i]) - B, ro = (Bo + x[i]) - Bo;
+            tie |= re != ro;
+            tot += re;  // (multiples of u; exact while the sum stays in the binade, and a sum that does not fails the test)
+        }
+        if (__ballot(tie) == 0ull) {
+            const float sn = s + wave_sum(tot);
+            if (sn < 2.0f * B) return sn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = block_step(s, x[i]);
+    return s;
+}
+
 __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int tfirst, int which, f2 s) {
     const int lane = threadIdx.x & 63;
     if (cv.compact) j = uni((int)cv.row[j]);  // (a round's rows are list entries there)
@@ -139,19 +163,40 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
     if (uni((int)cj) == (int)BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
+    // Chunks of four blocks: one latency of the W gather and of the table gather per 256 terms (the LDS is busy with
+    // the round loops of the other waves), list entries a chunk ahead.  Entries behind the lists' padding are
+    // clamped onto its last entry.
+    auto entries = [&](int t, uint32_t(&k)[4], uint32_t(&c)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = min(t + 64 * i + lane, cv.lastpad);
+            k[i] = cv.row[e];
+            c[i] = cv.code[e];
+        }
+    };
+    auto values = [&](const uint32_t(&k)[4], const uint32_t(&c)[4], float(&w)[4], f2(&de)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w[i] = wr[k[i]];  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
+            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
+        }
+    };
+    uint32_t k[4], c[4];
     int tb = tfirst;
-    uint32_t k = cv.row[tb + lane];   // (the lists are padded by more than two blocks: row m, skipped code)
-    uint32_t ck = cv.code[tb + lane];
-    float w = wr[k];                  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
-    for (; tb < cv.nvalid; tb += 64) {
-        const uint32_t kn = cv.row[tb + 64 + lane];
-        const uint32_t cn = cv.code[tb + 64 + lane];
-        const float wn = wr[kn];
-        const f2 de = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + ck));
-        if (which & 1) s0 = block_step(s0, w * de.x);
-        if (which & 2) s1 = block_step(s1, w * de.y);
-        w = wn;
-        ck = cn;
+    entries(tb, k, c);
+    for (; tb < cv.nvalid; tb += 256) {
+        float w[4];
+        f2 de[4];
+        values(k, c, w, de);          // four W gathers and four table gathers in flight together
+        entries(tb + 256, k, c);      // the next chunk's entries meanwhile
+        if (which & 1) {
+            const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
+            s0 = chunk_step(s0, x);
+        }
+        if (which & 2) {
+            const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
+            s1 = chunk_step(s1, x);
+        }
     }
     return f2{s0, s1};
 }
@@ -435,6 +480,7 @@ __device__ __forceinline__ void similarity_bx_body(const uint32_t *__restrict__ 
         cv[q].colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
         cv[q].ldw = ldw_;
         cv[q].compact = compact_;
+        cv[q].lastpad = (int)ldk - 1;
         // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles
         // its lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes
         // are consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
@@ -664,15 +710,22 @@ __device__ __forceinline__ float scan_lanes(float s, float top, float ie, float 
 struct ResolvedLg {
     float s;
     int ordered;
+    unsigned long long t_ordered;  // STAMP: cycles spent in the ordered rows
 };
+template <bool STAMP>
 __device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, int tbase, unsigned long long vall,
                                               unsigned long long vmask, int kind, float s, float Bl, float ie, float io) {
     const int lane = threadIdx.x & 63;
     // (row j0 + x: its partners start at entry tbase + (valid rows of the round up to and including x))
     auto tfirst = [&](int x) { return tbase + __builtin_popcountll(vall & ((2ull << x) - 1ull)); };
+    unsigned long long t_ordered = 0;
     auto ordered_row = [&](int x, float from) {
+        unsigned long long t0 = 0;
+        if (STAMP) t0 = __builtin_readcyclecounter();
         const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{from, from});
-        return unif(kind ? r.y : r.x);
+        const float v = unif(kind ? r.y : r.x);
+        if (STAMP) t_ordered += __builtin_readcyclecounter() - t0;
+        return v;
     };
     // a lane on plain sums that added nothing has only zero terms: it commits whatever the sum is
     const unsigned long long plain = __ballot(Bl == 0.0f), nonzero = __ballot(ie != 0.0f);
@@ -703,31 +756,145 @@ __device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab
         ++ordered;
         todo &= ~(segm & ((2ull << x) - 1ull));
     }
-    return ResolvedLg{s, ordered};
+    return ResolvedLg{s, ordered, t_ordered};
 }
 
-template <bool STAMP>
-__global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
+// The round loop with the lane's table column in LDS instead of 32 registers.  Per wave and round a [row][lane]
+// float table (row a, lane l: D[a][a_j(l)]; the row behind the alphabet is zero) is written once; a step reads
+// row a_k with ds_read_addtid_b32 (address = M0 + 4 lane: no address register, no VALU), M0 = the row's byte offset
+// straight from the compacted list (16-bit entries) + the wave's table base.  A step is then
+//     SALU  s_bfe (the entry), s_add (M0)            VALU  v_mul (W x D), two packed adds
+//     LDS   one 256-byte row                          VMEM  one 256-byte row of W
+// against 4 VALU + 3 SALU with the table in registers (s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off in front of
+// the multiply), and 32 registers are free: 6 waves per SIMD, bound by the LDS allocation.  The denominator term
+// is W itself (a lane whose row takes no part is ignored when the round is stitched).
+// LDS reads and the scalar list loads share the LGKM counter and scalar loads return out of order, so the loop
+// waits with lgkmcnt(0) once per 16 steps, at a point where everything outstanding was issued 16 steps earlier.
+struct LgEntries {
+    uint32_t o[16];  // row offsets in W
+    uint32_t c[8];   // 16 table-row offsets (u16 each)
+};
+struct LgD {
+    float d[16];
+};
+
+__device__ __forceinline__ void lg_issue_rows(LgD &D, const LgEntries &en, uint32_t base) {
+    uint32_t t0, t1;
+    // (an instruction between the M0 write and the LDS instruction that reads it: the hazard needs one wait state)
+    asm volatile(
+        "s_bfe_u32 %[t0], %[c0], 0x100000\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c0], 0x100010\n\tds_read_addtid_b32 %[d0]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c1], 0x100000\n\tds_read_addtid_b32 %[d1]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c1], 0x100010\n\tds_read_addtid_b32 %[d2]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c2], 0x100000\n\tds_read_addtid_b32 %[d3]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c2], 0x100010\n\tds_read_addtid_b32 %[d4]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c3], 0x100000\n\tds_read_addtid_b32 %[d5]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c3], 0x100010\n\tds_read_addtid_b32 %[d6]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c4], 0x100000\n\tds_read_addtid_b32 %[d7]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c4], 0x100010\n\tds_read_addtid_b32 %[d8]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c5], 0x100000\n\tds_read_addtid_b32 %[d9]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c5], 0x100010\n\tds_read_addtid_b32 %[d10]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c6], 0x100000\n\tds_read_addtid_b32 %[d11]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c6], 0x100010\n\tds_read_addtid_b32 %[d12]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_bfe_u32 %[t0], %[c7], 0x100000\n\tds_read_addtid_b32 %[d13]\n\t"
+        "s_add_u32 m0, %[t0], %[base]\n\ts_bfe_u32 %[t1], %[c7], 0x100010\n\tds_read_addtid_b32 %[d14]\n\t"
+        "s_add_u32 m0, %[t1], %[base]\n\ts_nop 0\n\tds_read_addtid_b32 %[d15]"
+        : [d0] "=&v"(D.d[0]), [d1] "=&v"(D.d[1]), [d2] "=&v"(D.d[2]), [d3] "=&v"(D.d[3]), [d4] "=&v"(D.d[4]), [d5] "=&v"(D.d[5]),
+          [d6] "=&v"(D.d[6]), [d7] "=&v"(D.d[7]), [d8] "=&v"(D.d[8]), [d9] "=&v"(D.d[9]), [d10] "=&v"(D.d[10]),
+          [d11] "=&v"(D.d[11]), [d12] "=&v"(D.d[12]), [d13] "=&v"(D.d[13]), [d14] "=&v"(D.d[14]), [d15] "=&v"(D.d[15]),
+          [t0] "=&s"(t0), [t1] "=&s"(t1)
+        : [c0] "s"(en.c[0]), [c1] "s"(en.c[1]), [c2] "s"(en.c[2]), [c3] "s"(en.c[3]), [c4] "s"(en.c[4]), [c5] "s"(en.c[5]),
+          [c6] "s"(en.c[6]), [c7] "s"(en.c[7]), [base] "s"(base)
+        : "m0", "scc", "memory");
+}
+// everything on the LGKM counter has arrived; the rows read above may be used behind this point
+__device__ __forceinline__ void lg_wait_rows(LgD &D) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(D.d[0]), "+v"(D.d[1]), "+v"(D.d[2]), "+v"(D.d[3]), "+v"(D.d[4]), "+v"(D.d[5]), "+v"(D.d[6]), "+v"(D.d[7]),
+                   "+v"(D.d[8]), "+v"(D.d[9]), "+v"(D.d[10]), "+v"(D.d[11]), "+v"(D.d[12]), "+v"(D.d[13]), "+v"(D.d[14]),
+                   "+v"(D.d[15])
+                 :
+                 : "memory");
+}
+
+template <bool NOLOAD>  // NOLOAD (diagnostics, MSA_LG_DBG=1): the W rows are not reloaded -- what the W stream costs
+__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const __attribute__((address_space(1))) uint32_t *off,
+                                               const __attribute__((address_space(1))) uint16_t *trow, int tstart, int tend,
+                                               uint32_t joff, uint32_t base, f2 &an, f2 &ad) {
+    typedef const __attribute__((address_space(4))) uint32_t *c32;
+    auto sload = [&](LgEntries &en, int t) {  // 16 entries = 64 + 32 bytes (t % 16 == 0)
+        c32 po = (c32)(uint64_t)(off + t);
+        c32 pc = (c32)(uint64_t)(trow + t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) en.o[i] = po[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) en.c[i] = pc[i];
+    };
+    auto bload = [&](float(&w)[16], const LgEntries &en) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
+    };
+    // 16 steps; every W row is requested 16 steps before its use
+    auto consume_reload = [&](float(&w)[16], const LgD &D, const LgEntries &next) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = w[i] * D.d[i];
+            const f2 xn = {x, x}, xd = {w[i], w[i]};
+            if (!NOLOAD) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[i], 0));
+            an += xn;
+            ad += xd;
+        }
+    };
+    float w[16];
+    LgEntries eA, eB;
+    LgD dA, dB;
+    sload(eA, tstart);
+    sload(eB, tstart + 16);
+    bload(w, eA);
+    lg_issue_rows(dA, eA, base);
+#pragma unroll 1
+    for (int t = tstart; t < tend; t += 32) {  // (the lists are padded: zero row of W, zero row of the table)
+        lg_wait_rows(dA);  // rows t .. t+15 and the entries t+16 .. t+31
+        lg_issue_rows(dB, eB, base);
+        sload(eA, t + 32);
+        __builtin_amdgcn_sched_barrier(0);  // (the scalar loads must not sink towards their use: the next wait would stall on them)
+        consume_reload(w, dA, eB);
+        lg_wait_rows(dB);
+        lg_issue_rows(dA, eA, base);
+        sload(eB, t + 48);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_reload(w, dB, eA);
+    }
+    lg_wait_rows(dA);  // (nothing may stay in flight into the caller's LDS traffic)
+}
+
+constexpr int LG_WAVES_MAX = 8;  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
+
+// LDST: the lane's table column lives in LDS (round_loop_lds; `nr` rows per wave behind the static arrays, within
+// the first 64 KB: M0 holds 16 bits) instead of 32 registers (round_loop).
+template <bool STAMP, bool LDST>
+__device__ __forceinline__ void similarity_lg_body(
     const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
-    const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m, int n,
-    const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
-    const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g, float *__restrict__ num_out,
-    float *__restrict__ den_out) {
+    const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_,
+    int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,
+    uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
+    float *__restrict__ num_out, float *__restrict__ den_out) {
     const gf32p wup = (gf32p)(uint64_t)wup_;
-    __shared__ f2 tab[32 * 32];              // {distance, both valid}[row code][column code], rows 28.. zero
-    __shared__ uint32_t hist[BX_WAVES][32];  // residue counts of the wave's column
-    __shared__ float gtab[BX_WAVES][32];     // G[a] = mean over the column's valid rows of D[.][a]
-    for (int i = threadIdx.x; i < 32 * 32; i += 64 * BX_WAVES) {
+    __shared__ f2 tab[32 * 32];                  // {distance, both valid}[row code][column code], rows 28.. zero
+    __shared__ uint32_t hist[LG_WAVES_MAX][32];  // residue counts of the wave's column
+    __shared__ float gtab[LG_WAVES_MAX][32];     // G[a] = mean over the column's valid rows of D[.][a]
+    extern __shared__ float ltab[];              // LDST: [wave][nr][64 lanes]
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
         f2 v = {0.0f, 0.0f};
         if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
         tab[i] = v;
     }
-    if (threadIdx.x < BX_WAVES * 32) (&hist[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x < LG_WAVES_MAX * 32) (&hist[0][0])[threadIdx.x] = 0u;
     __syncthreads();
     const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
-    const int ci = blockIdx.x * BX_WAVES + wave;
+    const int ci = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (ci >= ncols) return;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
     const int col = uni(cols[ci]);
@@ -739,8 +906,11 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
     cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
     cv.ldw = ldw_;
     cv.compact = 0;
+    cv.lastpad = (int)ldk - 1;
+    const __attribute__((address_space(1))) uint16_t *vtrow =
+        uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
     const int nv = cv.nvalid;
-    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t0c = 0, rt0 = 0;
+    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0;
     if (STAMP) {
         t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
@@ -761,7 +931,7 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
     int jstart = 0, tb = 0;
     {
         bool seen = false;
-        while (jstart < m - 1 && tb < nv && (jstart < r0_ || !seen)) {
+        while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
             const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
             if (cj != BX_SKIP) {
                 ++tb;
@@ -817,9 +987,19 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
         // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
         f2 an = {Bn, Bn + Bn * 0x1p-23f}, ad = {Bd, Bd + Bd * 0x1p-23f}, an2 = {0.0f, 0.0f}, ad2 = {0.0f, 0.0f};
         const uint32_t joff = 4u * (uint32_t)(j0 + lane);
-        const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
-        {
-            v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
+        if (LDST) {
+            // the lane's table column into the wave's [row][lane] table (zeros for a row that takes no part: column 28)
+            float *lt = ltab + (size_t)wave * nr * 64 + lane;
+            for (int a = 0; a < nr; ++a)
+                lt[a * 64] = (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x;
+            const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(ltab + (size_t)wave * nr * 64);
+            if (STAMP && (r0_ & 0x10000))
+                round_loop_lds<true>(wrsrc, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+            else
+                round_loop_lds<false>(wrsrc, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+        } else {
+            const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
+            v32f T;  // the lane's table column
 #pragma unroll
             for (int a = 0; a < 32; ++a)
                 T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
@@ -832,8 +1012,10 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
             t0c = t1;
             ++n_rounds;
         }
-        const ResolvedLg rn = resolve_lg(cv, wup, tabp, j0, tbase, vall, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
-        const ResolvedLg rd = resolve_lg(cv, wup, tabp, j0, tbase, vall, vmask, 1, sd, Bd, ad.x - Bd, ad.y - (Bd + Bd * 0x1p-23f));
+        // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
+        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
+        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
+                                         takes ? ad.y - (Bd + Bd * 0x1p-23f) : 0.0f);
         const float sn1 = unif(rn.s), sd1 = unif(rd.s);
         if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);
         if (sd1 > sd && Qd > 0.0f) cd = unif((sd1 - sd) / Qd);
@@ -845,6 +1027,7 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
             t_res += t1 - t0c;
             t0c = t1;
             n_ordered += (unsigned)(rn.ordered + rd.ordered);
+            t_ord += rn.t_ordered + rd.t_ordered;
         }
     }
     if (STAMP && lane == 0) {
@@ -857,6 +1040,7 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
         atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
         atomicMax(&g_bx_stamps[8], n_rounds);
         atomicAdd(&g_bx_stamps[10], n_ordered);
+        atomicAdd(&g_bx_stamps[11], t_ord);
         if (ci < 16384) {
             unsigned int *r = g_bx_rec + 8 * ci;
             r[0] = (unsigned)col;
@@ -874,11 +1058,33 @@ __global__ __launch_bounds__(64 * BX_WAVES) void similarity_lg_kernel(
     }
 }
 
+// Two entry points over the same body: with the table in LDS the kernel is compiled for six waves per SIMD (80
+// registers; the LDS allocation admits 24 waves per CU for a 20-letter alphabet); the register-table version must
+// not be squeezed (its indexed table would go to scratch memory).
+#define LG_PARAMS                                                                                                      \
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,      \
+        const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, \
+        int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
+        uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
+        float *__restrict__ num_out, float *__restrict__ den_out
+#define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, tab_g, num_out, den_out
+template <bool STAMP>
+__global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(6, 6))) void similarity_lg_kernel(LG_PARAMS) {
+    similarity_lg_body<STAMP, true>(LG_ARGS);
+}
+template <bool STAMP>
+__global__ __launch_bounds__(64 * LG_WAVES_MAX) void similarity_lg_regs_kernel(LG_PARAMS) {
+    similarity_lg_body<STAMP, false>(LG_ARGS);
+}
+#undef LG_PARAMS
+#undef LG_ARGS
+
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
 // row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
                                                          uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vrow,
-                                                         uint8_t *__restrict__ vcode, int32_t *__restrict__ nvalid) {
+                                                         uint8_t *__restrict__ vcode, uint16_t *__restrict__ vtrow, int skiprow,
+                                                         int32_t *__restrict__ nvalid) {
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= ncols_pad) return;
@@ -886,6 +1092,7 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
     uint32_t *po = voff + (size_t)col * ldk;
     uint16_t *pr = vrow + (size_t)col * ldk;
     uint8_t *pc = vcode + (size_t)col * ldk;
+    uint16_t *pt = vtrow + (size_t)col * ldk;  // byte offset of the residue's row in a [row][64 lanes] float table
     int count = 0;
     for (int kb = 0; kb < m; kb += 64) {
         const int k = kb + lane;
@@ -896,6 +1103,7 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
             po[pos] = (uint32_t)k * ldw4;
             pr[pos] = (uint16_t)k;
             pc[pos] = (uint8_t)code;
+            pt[pos] = (uint16_t)((code >> 3) * 256u);
         }
         count += __builtin_popcountll(mask);
     }
@@ -903,6 +1111,7 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
         po[t] = (uint32_t)m * ldw4;  // row m of W: zeros
         pr[t] = (uint16_t)m;         // column m of W: zeros
         pc[t] = (uint8_t)BX_SKIP;
+        pt[t] = (uint16_t)(skiprow * 256);  // the table's zero row
     }
     if (lane == 0) nvalid[col] = count;
 }
@@ -949,7 +1158,7 @@ __global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__res
 
 // leading dimension of the per-column lists: the valid rows, then >= 192 padding entries (a block of the ordered
 // path, two prefetched groups of the round loop)
-int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the round loop reads up to 55 entries past the last one)
+int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the ordered path reads up to 191 entries past the last valid one, the round loops up to 63)
 int bx_cols_pad(int n) { return (n + 1 + 63) / 64 * 64; }  // at least one all-skipped column behind the last one
 size_t bx_wlow_rows(int m) { return (size_t)m + 2; }         // row m: zeros (the padding entries of the lists point there)
 
@@ -961,10 +1170,10 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
     sim_encode_cm_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codeT, ldk, ncp, err_key);
 }
 
-void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, uint32_t *voff, uint16_t *vrow,
-                       uint8_t *vcode, int32_t *nvalid) {
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vrow,
+                       uint8_t *vcode, uint16_t *vtrow, int32_t *nvalid) {
     const int ncp = bx_cols_pad(n);
-    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, nvalid);
+    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, vtrow, npos, nvalid);
 }
 
 int bx_cols_per_wave() { return BX_Q; }
@@ -994,22 +1203,37 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     return 0;
 }
 
-// the same contract as launch_similarity_bx; the kernel with per-lane grids (the default)
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
-                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
-                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
+// the same contract as launch_similarity_bx plus the 16-bit table-row list; the kernel with per-lane grids (the default)
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
+                         int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
+                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
-    const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0;
-    const unsigned grid = (unsigned)((ncols + BX_WAVES - 1) / BX_WAVES);
+    // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 1 -> no W loads, stamped kernel only)
+    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16);
+    const bool ldst = tuning().lg_regs == 0;
+    const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
+    // eight waves per workgroup while their tables stay within the 64 KB M0 can address (static arrays: 10.5 KB)
+    const int waves = ldst ? ((size_t)8 * nr * 256 + 10752 <= 65536 && !(tuning().lg_dbg & 2) ? 8 : 4) : BX_WAVES;
+    const size_t dyn = ldst ? (size_t)waves * nr * 256 : 0;
+    const unsigned grid = (unsigned)((ncols + waves - 1) / waves);
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
     const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
-    if (tuning().sim_mode & 64)
-        similarity_lg_kernel<true><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
-                                                                  wup, ldw, r0, t, num_out, den_out);
-    else
-        similarity_lg_kernel<false><<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes,
-                                                                   wup, ldw, r0, t, num_out, den_out);
+    const bool stamp = (tuning().sim_mode & 64) != 0;
+#define LG_LAUNCH(KERNEL)                                                                                              \
+    KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup, ldw, r0, \
+                                         t, num_out, den_out)
+    if (ldst) {
+        const void *k = stamp ? (const void *)similarity_lg_kernel<true> : (const void *)similarity_lg_kernel<false>;
+        const int e = set_max_lds_once(k, (int)dyn);
+        if (e) return e;
+        if (stamp) LG_LAUNCH(similarity_lg_kernel<true>);
+        else LG_LAUNCH(similarity_lg_kernel<false>);
+    } else {
+        if (stamp) LG_LAUNCH(similarity_lg_regs_kernel<true>);
+        else LG_LAUNCH(similarity_lg_regs_kernel<false>);
+    }
+#undef LG_LAUNCH
     return 0;
 }
 

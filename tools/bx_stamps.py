@@ -41,7 +41,7 @@ for cols in COLS:
                           "max_rounds": buf[8], "shortened_per_wave": round(buf[9] / w, 2), "wave_ms_avg": round(buf[6] / w / 1e5, 3), "longest_wave_kcycles": round(buf[7] / 1e3, 1),
                           "clock_GHz": round((buf[0] + buf[1] + buf[2]) / max(buf[6], 1) / 10, 3), "kcycles_per_wave": {
                               "prologue": round(buf[0] / w / 1e3, 1), "loops": round(buf[1] / w / 1e3, 1),
-                              "stitch": round(buf[2] / w / 1e3, 1)}}), flush=True)
+                              "stitch": round(buf[2] / w / 1e3, 1), "of_which_ordered_rows": round(buf[11] / w / 1e3, 1)}}), flush=True)
         if os.environ.get("BX_RECORDS"):
             nw = int(buf[3])
             rec = (ctypes.c_uint * (8 * nw))()
