@@ -101,6 +101,9 @@ struct msa_ctx {
     DevBuf<uint16_t> bx_row;   //     row index,
     DevBuf<uint8_t> bx_code;   //     code,
     DevBuf<uint16_t> bx_trow;  //     byte offset of the residue's row in a [row][64 lanes] float table
+    DevBuf<uint32_t> u_off, u_tt;  // union lists of the column pairs (two columns per wave): W row offset, two table-row offsets,
+    DevBuf<float> u_ee;            //     the two 1/0 flags,
+    DevBuf<int32_t> u_n;           //     entries per pair
     DevBuf<int32_t> bx_nvalid;
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
     PinBuf<int32_t> h_simcols;
@@ -423,7 +426,8 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     };
     int rc = run_pairs(c, false, true, false);
     if (rc) return rc;
-    rc = ensure_gaps(c, c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 3);  // (the binade-exact kernel's column list is built on the host)
+    const bool bx_family = c->tuning.sim_kernel == 0 || c->tuning.sim_kernel >= 3;
+    rc = ensure_gaps(c, bx_family);  // (the binade-exact kernel's column list is built on the host)
     if (rc) return rc;
     const int m = c->m, n = c->n;
     // tables
@@ -453,7 +457,12 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // kernel.  All three are bit-exact and parity-tested against each other and the oracle.
     // (its compacted lists hold 16-bit row indices and 32-bit W offsets: larger alignments take the chain kernels)
     const bool bx_fits = m < 32000;
-    if ((c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 3) && bx_fits) {
+    if (bx_family && bx_fits) {
+        // 0: by size -- two columns per wave from 5 pairs per workgroup and two workgroups per CU on (all its waves are
+        // resident from the start: fewer would leave the SIMDs short of waves) and alphabets up to 22 letters, else one
+        // column per wave; 4 "lg": one column per wave; 5 "q2": two columns per wave; 3 "bx": the one-grid-per-round
+        // predecessor
+        bool pairs2 = (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 5) && msak::lg2_fits(npos);
         const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
         HIPCHK(c, c->codeT.reserve(lsz));
         HIPCHK(c, c->bx_off.reserve(lsz));
@@ -478,8 +487,8 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
         // goes with the lightest, the second with the second to last, ...
         const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
-        const int q = msak::bx_cols_per_wave();
-        HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 16));
+        const int q = c->tuning.sim_kernel == 3 ? msak::bx_cols_per_wave() : 1;
+        HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 64 * (size_t)std::max(1, c->cus) + 64));
         // (counting sort by the number of rows that take no part, stable, in ordinary memory: the pinned staging
         // buffer is only written once, front to back)
         int32_t *list = c->h_simcols.p;
@@ -495,6 +504,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
                 order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
                 ++nact;
             }
+        if (c->tuning.sim_kernel == 0 && nact < 20 * std::max(1, c->cus)) pairs2 = false;
         int npad = 0;
         if (q == 2) {
             for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
@@ -503,16 +513,49 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             }
         } else {
             for (int i = 0; i < nact; ++i) list[npad++] = order[i];
-            while (npad % q) list[npad++] = n;
+            while (npad % (pairs2 ? 2 : q)) list[npad++] = n;  // (column n: all skipped)
+        }
+        int pair_waves = 0;
+        if (pairs2 && npad) {
+            // Two columns per wave, neighbours in the order above.  Every pair is resident from the start (no wave slot
+            // is ever refilled), so the time is set by the CU with the most work: two workgroups per CU, and the pairs
+            // dealt to the workgroups in serpentine order (heaviest with lightest) so that all carry the same load.
+            const int np = npad / 2;
+            int nwg = std::max(1, 2 * c->cus);
+            pair_waves = (np + nwg - 1) / nwg;
+            if (pair_waves > msak::lg2_max_waves()) {
+                pair_waves = msak::lg2_max_waves();
+                nwg = (np + pair_waves - 1) / pair_waves;
+            }
+            order.assign(list, list + npad);
+            npad = 0;
+            for (int g = 0; g < nwg; ++g)
+                for (int w = 0; w < pair_waves; ++w) {
+                    const int pi = w * nwg + ((w & 1) ? nwg - 1 - g : g);
+                    list[npad++] = pi < np ? order[2 * pi] : n;
+                    list[npad++] = pi < np ? order[2 * pi + 1] : n;
+                }
         }
         mark("columns sorted");
-        HIPCHK(c, c->simcols.reserve((size_t)n + 8));
+        HIPCHK(c, c->simcols.reserve((size_t)npad + 8));
         if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));
         HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
         {
             ProfScope ps(c, "sim");
-            const int e = c->tuning.sim_kernel == 3
+            int e;
+            if (pairs2) {
+                // neighbours in the order by valid rows share a wave and the W rows of the union of their valid rows
+                const size_t usz = (size_t)(npad / 2 + 1) * msak::bx_ldk(m) + 64;
+                HIPCHK(c, c->u_off.reserve(usz));
+                HIPCHK(c, c->u_tt.reserve(usz));
+                HIPCHK(c, c->u_ee.reserve(2 * usz));
+                HIPCHK(c, c->u_n.reserve((size_t)npad / 2 + 64));
+                e = msak::launch_similarity_lg2(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, npos, c->bx_nvalid.p, c->codeT.p, m, n,
+                                                c->simcols.p, npad, pair_waves, c->u_off.p, c->u_tt.p, c->u_ee.p, c->u_n.p, c->wlow.p,
+                                                c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
+            } else
+                e = c->tuning.sim_kernel == 3
                               ? msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p,
                                                            m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
                                                            c->simnum.p, c->simden.p)
@@ -891,7 +934,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->u_off.release(); c->u_tt.release(); c->u_ee.release(); c->u_n.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
     c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();

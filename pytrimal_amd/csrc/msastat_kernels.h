@@ -8,7 +8,8 @@ namespace msak {
 // Diagnostic switches (environment variables MSA_*), read ONCE when a context is created and handed to the
 // launch wrappers through a thread-local pointer for the duration of an API call (contexts are per thread).
 struct Tuning {
-    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact with per-lane grids (default), 3 "bx" its one-grid-per-round predecessor,
+    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact with per-lane grids, one or two columns per wave by size (default),
+                               // 4 "lg" one column per wave, 5 "q2" two columns per wave, 3 "bx" its one-grid-per-round predecessor,
                                // 1 "chain" numerator + denominator kernels, 2 "pc"
     int sim_tcols = 0;         // MSA_SIM_TCOLS: column-tile width of the chain kernels (0 = 64)
     int sim_mode = 0;          // MSA_SIM_MODE: in-kernel stamps / ablations of the chain kernels
@@ -59,6 +60,12 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
                          int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
+bool lg2_fits(int npos);
+int lg2_max_waves();
+int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, int npos,
+                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, int waves,
+                          uint32_t *uoff, uint32_t *utt, float *uee, int32_t *nunion, const float *wlow, const float *wup, int ldw,
+                          const void *tab, float *num_out, float *den_out);
 bool sim_num_transposed(int tcols);
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,
                         const int32_t *gaps_w, void *codes8, unsigned long long *err_key, int tcols);

@@ -2061,7 +2061,7 @@ Tuning tuning_from_env() {
         const char *e = getenv(name);
         return e ? atoi(e) : dflt;
     };
-    if (const char *k = getenv("MSA_SIM_KERNEL")) t.sim_kernel = k[0] == 'c' ? 1 : (k[0] == 'p' ? 2 : (k[0] == 'b' ? 3 : 0));
+    if (const char *k = getenv("MSA_SIM_KERNEL")) t.sim_kernel = k[0] == 'c' ? 1 : (k[0] == 'p' ? 2 : (k[0] == 'b' ? 3 : (k[0] == 'l' ? 4 : (k[0] == 'q' ? 5 : 0))));
     t.sim_tcols = num("MSA_SIM_TCOLS", 0);
     t.sim_mode = num("MSA_SIM_MODE", 0);
     t.sim_tp = num("MSA_SIM_TP", 1);

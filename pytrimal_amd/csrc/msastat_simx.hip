@@ -126,6 +126,7 @@ struct ColView {
     int ldw;
     int compact;  // lanes of a round are consecutive entries of the compacted list (else consecutive rows)
     int lastpad;  // the last entry of the lists (padding)
+    int nr;       // 0: `tab` is the {distance, valid} table [32][32]; > 0: the replicated float table [nr][nr][32 copies]
 };
 
 // Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
@@ -174,11 +175,20 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
             c[i] = cv.code[e];
         }
     };
+    // (replicated table: entry (a, b) has 32 copies, lane l reads copy l % 32 -- no bank conflict whatever the codes)
+    const uint32_t rrow = cv.nr ? (((cj == BX_SKIP ? (uint32_t)cv.nr - 1u : cj >> 3) * (uint32_t)cv.nr) << 7) + ((uint32_t)(lane & 31) << 2) : 0u;
     auto values = [&](const uint32_t(&k)[4], const uint32_t(&c)[4], float(&w)[4], f2(&de)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             w[i] = wr[k[i]];  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
-            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
+            if (cv.nr) {
+                const bool skip = c[i] == BX_SKIP;
+                const uint32_t b = skip ? (uint32_t)cv.nr - 1u : c[i] >> 3;
+                de[i].x = *reinterpret_cast<const __attribute__((address_space(3))) float *>(tab + (rrow + (b << 7)));
+                de[i].y = skip ? 0.0f : 1.0f;
+            } else {
+                de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
+            }
         }
     };
     uint32_t k[4], c[4];
@@ -481,6 +491,7 @@ __device__ __forceinline__ void similarity_bx_body(const uint32_t *__restrict__ 
         cv[q].ldw = ldw_;
         cv[q].compact = compact_;
         cv[q].lastpad = (int)ldk - 1;
+        cv[q].nr = 0;
         // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles
         // its lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes
         // are consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
@@ -907,6 +918,7 @@ __device__ __forceinline__ void similarity_lg_body(
     cv.ldw = ldw_;
     cv.compact = 0;
     cv.lastpad = (int)ldk - 1;
+    cv.nr = 0;
     const __attribute__((address_space(1))) uint16_t *vtrow =
         uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
     const int nv = cv.nvalid;
@@ -1079,6 +1091,324 @@ __global__ __launch_bounds__(64 * LG_WAVES_MAX) void similarity_lg_regs_kernel(L
 #undef LG_PARAMS
 #undef LG_ARGS
 
+// ---- two columns per wave ------------------------------------------------------------------------------------
+// The kernel above is bound by the vector-memory pipeline: one 256-byte buffer load of a W row per 64 terms costs
+// the CU ~8.5 cycles whatever the occupancy (tools/ubench_wstream.hip: 18 TB/s chip-wide for this pattern, all
+// L2 hits), and 2.2e8 of them are 3.6 of its 4.0 ms at 2000 x 10000.  Here a wave owns TWO columns (neighbours in
+// the order by valid rows) and walks the UNION of their valid rows once: every W row loaded serves both columns.
+//   * the lane's table lookup D[a_k][a_j] comes from ONE table per workgroup instead of one per wave and round:
+//     every entry replicated 32 times ([a_k][a_j][copy], lane l reads copy l % 32: no bank conflict), address =
+//     (a_k * nr * 128, from the list, SGPR) + (a_j * 128 + 4 (l % 32), per lane and round): one v_add + ds_read_b32;
+//   * a row that takes part in only one of the two columns: the other column reads the table's zero row
+//     (numerator term 0) and adds W * 0 to its denominator -- v_pk_fma_f32 with the 1/0 flag of the list as the
+//     scalar operand; W * 1 is exact, so fl(W * 1 + s) is the reference's fl(s + W);
+//   * no per-wave LDS, 5 waves per SIMD, all the waves of 10 000 columns resident at once.
+struct PairView {  // the union of two columns' valid rows, in row order (lg2_union_kernel)
+    const __attribute__((address_space(1))) uint32_t *off;  // W row offset; padding: the zero row
+    const __attribute__((address_space(1))) uint32_t *tt;   // table-row offsets a_k * nr * 128 of the two columns, 16 bits each; padding: zero rows
+    const __attribute__((address_space(1))) float *ee;      // {takes part in column 1, in column 2} as 1.0 / 0.0
+    int n;
+};
+
+__device__ __forceinline__ void round_loop_q2(__amdgpu_buffer_rsrc_t wrsrc, PairView pv, int tstart, int tend, uint32_t joff,
+                                              ldsp rtab, uint32_t vb1, uint32_t vb2, f2 &an1, f2 &ad1, f2 &an2, f2 &ad2) {
+    typedef const __attribute__((address_space(4))) uint32_t *c32;
+    typedef const __attribute__((address_space(4))) float *cf32;
+    auto lo = [&](uint32_t(&o)[8], int t) {
+        c32 p = (c32)(uint64_t)(pv.off + t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = p[i];
+    };
+    auto lt = [&](uint32_t(&x)[8], int t) {
+        c32 p = (c32)(uint64_t)(pv.tt + t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = p[i];
+    };
+    auto le = [&](float(&e)[16], int t) {
+        cf32 p = (cf32)(uint64_t)(pv.ee + 2 * t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = p[i];
+    };
+    auto bload = [&](float(&w)[8], const uint32_t(&o)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, o[i], 0));
+    };
+    auto dissue = [&](float(&d1)[8], float(&d2)[8], const uint32_t(&x)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            d1[i] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(rtab + (vb1 + (x[i] & 0xFFFFu)));
+            d2[i] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(rtab + (vb2 + (x[i] >> 16)));
+        }
+    };
+    auto consume_reload = [&](float(&w)[8], const float(&d1)[8], const float(&d2)[8], const float(&e)[16], const uint32_t(&next)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float wi = w[i];
+            const float x1 = wi * d1[i], x2 = wi * d2[i];
+            w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next[i], 0));
+            an1 += f2{x1, x1};
+            an2 += f2{x2, x2};
+            ad1 = __builtin_elementwise_fma(f2{wi, wi}, f2{e[2 * i], e[2 * i]}, ad1);
+            ad2 = __builtin_elementwise_fma(f2{wi, wi}, f2{e[2 * i + 1], e[2 * i + 1]}, ad2);
+        }
+    };
+    // Groups of 8 union entries, A and B in turn.  In front of a group: its table values and flags and the W row
+    // offsets of the group after next have arrived (one lgkmcnt(0), everything outstanding is a group old); then
+    // the table reads of the next group and the scalar loads of later groups are issued, then 8 steps of VALU work
+    // whose W rows were requested two groups ago.
+    uint32_t oA[8], oB[8], tA[8], tB[8];
+    float eA[16], eB[16], wA[8], wB[8], d1A[8], d2A[8], d1B[8], d2B[8];
+    lo(oA, tstart);
+    lo(oB, tstart + 8);
+    lt(tA, tstart);
+    le(eA, tstart);
+    bload(wA, oA);
+    bload(wB, oB);
+    dissue(d1A, d2A, tA);
+    lt(tB, tstart + 8);
+    lo(oA, tstart + 16);
+#pragma unroll 1
+    for (int t = tstart; t < tend; t += 16) {  // (the lists are padded: zero row of W, zero rows of the table, flags 0)
+        dissue(d1B, d2B, tB);
+        lt(tA, t + 16);
+        le(eB, t + 8);
+        lo(oB, t + 24);
+        __builtin_amdgcn_sched_barrier(0);  // (the scalar loads must not sink towards their use: the next wait would stall on them)
+        consume_reload(wA, d1A, d2A, eA, oA);
+        dissue(d1A, d2A, tA);
+        lt(tB, t + 24);
+        le(eA, t + 16);
+        lo(oA, t + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_reload(wB, d1B, d2B, eB, oB);
+    }
+}
+
+constexpr int LG2_WAVES = 12;  // waves per workgroup (a multiple of 4: a workgroup fills the SIMDs evenly): two workgroups share a CU (the 56 KB table each), 6 waves per SIMD
+
+template <bool STAMP>
+__global__ __launch_bounds__(64 * LG2_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void similarity_lg2_kernel(
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
+    const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m, int n,
+    const int32_t *__restrict__ cols, int npairs, const uint32_t *__restrict__ uoff_, const uint32_t *__restrict__ utt_,
+    const float *__restrict__ uee_, const int32_t *__restrict__ nunion, int nr, const float *__restrict__ wlow_,
+    uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
+    float *__restrict__ num_out, float *__restrict__ den_out) {
+    const gf32p wup = (gf32p)(uint64_t)wup_;
+    __shared__ uint32_t hist[LG2_WAVES][2][32];  // residue counts of the wave's columns
+    __shared__ float gtab[LG2_WAVES][2][32];     // G[a] = mean over the column's valid rows of D[.][a]
+    extern __shared__ float rtab_[];             // [nr][nr][32]: D[a][b] (zero where a or b is the row behind the alphabet), 32 copies
+    for (int i = threadIdx.x; i < nr * nr * 32; i += blockDim.x) {
+        const int a = (i >> 5) / nr, b = (i >> 5) % nr;
+        rtab_[i] = (a < nr - 1 && b < nr - 1) ? tab_g[(a * 32 + b) * 2] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < LG2_WAVES * 2 * 32; i += blockDim.x) (&hist[0][0][0])[i] = 0u;
+    __syncthreads();
+    const ldsp rtab = (ldsp)(const __attribute__((address_space(3))) void *)rtab_;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    const int pi = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (pi >= npairs) return;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
+    PairView pv;
+    pv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)uoff_ + (size_t)pi * ldk);
+    pv.tt = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)utt_ + (size_t)pi * ldk);
+    pv.ee = uniform_ptr((const __attribute__((address_space(1))) float *)(uint64_t)uee_ + (size_t)pi * ldk * 2);
+    pv.n = uni(nunion[pi]);
+    ColView cv[2];
+    int col[2], nv[2], jstart[2], tb[2];
+    float sn[2], sd[2], cn[2], cd[2];
+    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0;
+    if (STAMP) {
+        t0c = __builtin_readcyclecounter();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        col[q] = uni(cols[2 * pi + q]);  // (the list is padded with column n: an all-skipped column)
+        const int c = col[q];
+        cv[q].off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)c * ldk);
+        cv[q].row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)c * ldk);
+        cv[q].code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)c * ldk);
+        cv[q].nvalid = uni(nvalid[c]);
+        cv[q].colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)c * ldk);
+        cv[q].ldw = ldw_;
+        cv[q].compact = 0;
+        cv[q].lastpad = (int)ldk - 1;
+        cv[q].nr = nr;
+        nv[q] = cv[q].nvalid;
+        // the column's residue frequencies -> G
+        for (int t = lane; t < nv[q]; t += 64) atomicAdd(&hist[wave][q][cv[q].code[t] >> 3], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (lane < 32) {
+            float g = 0.0f;
+            if (lane < nr - 1)
+                for (int b = 0; b < nr - 1; ++b) g += (float)hist[wave][q][b] * rtab_[(b * nr + lane) * 32];
+            gtab[wave][q][lane] = nv[q] > 0 ? g / (float)nv[q] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // the first rows in the reference's order: at least up to the first row that takes part
+        f2 s2 = {0.0f, 0.0f};
+        float qn0 = 0.0f, qd0 = 0.0f;
+        jstart[q] = 0;
+        tb[q] = 0;
+        bool seen = false;
+        while (jstart[q] < m - 1 && tb[q] < nv[q] && (jstart[q] < (r0_ & 0xFFFF) || !seen)) {
+            const uint32_t cj = (uint32_t)uni((int)cv[q].colcode[jstart[q]]);
+            if (cj != BX_SKIP) {
+                ++tb[q];
+                seen = true;
+                const float rem = (float)(nv[q] - tb[q]);
+                qd0 += rem;
+                qn0 += rem * gtab[wave][q][cj >> 3];
+                s2 = exact_row(cv[q], wup, rtab, jstart[q], tb[q], 3, s2);
+            }
+            ++jstart[q];
+        }
+        if (tb[q] >= nv[q]) jstart[q] = m;  // nothing behind the ordered rows: the column is done
+        sn[q] = unif(s2.x);
+        sd[q] = unif(s2.y);
+        qn0 = unif(qn0);
+        qd0 = unif(qd0);
+        cn[q] = unif((sn[q] > 0.0f && qn0 > 0.0f) ? sn[q] / qn0 : 0.8f);
+        cd[q] = unif((sd[q] > 0.0f && qd0 > 0.0f) ? sd[q] / qd0 : 0.8f);
+    }
+    if (STAMP) {
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        t_pro = t1 - t0c;
+        t0c = t1;
+    }
+    int j0 = min(jstart[0], jstart[1]) & ~63;
+    // valid rows of either column / of their union before j0
+    int tbase[2] = {0, 0}, tbaseU = 0;
+    for (int r = lane; r < j0; r += 64) {  // (j0 > 0 only when both columns begin with 64 or more rows that take no part)
+        const bool v0 = cv[0].colcode[r] != BX_SKIP, v1 = cv[1].colcode[r] != BX_SKIP;
+        tbase[0] += __builtin_popcountll(__ballot(v0));
+        tbase[1] += __builtin_popcountll(__ballot(v1));
+        tbaseU += __builtin_popcountll(__ballot(v0 || v1));
+    }
+    tbase[0] = uni(tbase[0]);
+    tbase[1] = uni(tbase[1]);
+    tbaseU = uni(tbaseU);
+    for (; j0 < m - 1 && (tbase[0] < nv[0] || tbase[1] < nv[1]); j0 += 64) {
+        const int nrows = min(64, m - 1 - j0);
+        unsigned long long vall[2], vmask[2];
+        uint32_t vb[2];
+        float Bn[2], Bd[2], Qn[2], Qd[2];
+        bool takes[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t craw = lane < nrows ? (uint32_t)cv[q].colcode[j0 + lane] : BX_SKIP;
+            vall[q] = __ballot(craw != BX_SKIP);
+            const uint32_t cj8 = j0 + lane >= jstart[q] ? craw : BX_SKIP;  // (rows before jstart were evaluated in order)
+            vmask[q] = __ballot(cj8 != BX_SKIP);
+            takes[q] = cj8 != BX_SKIP;
+            const uint32_t aj = takes[q] ? cj8 >> 3 : (uint32_t)nr - 1u;
+            vb[q] = (aj << 7) + ((uint32_t)(lane & 31) << 2);
+            // predicted sum in front of every row -> the lane's grid
+            const int behind = nv[q] - (tbase[q] + __builtin_popcountll(vall[q] & ((2ull << lane) - 1ull)));
+            const float qd = takes[q] ? (float)behind : 0.0f;
+            const float qn = takes[q] ? (float)behind * gtab[wave][q][cj8 >> 3] : 0.0f;
+            const float Pd = wave_prefix(qd), Pn = wave_prefix(qn);
+            float un, ud;
+            grid_of(sn[q] + cn[q] * (Pn - qn), Bn[q], un);
+            grid_of(sd[q] + cd[q] * (Pd - qd), Bd[q], ud);
+            Qn[q] = rl(Pn, 63);
+            Qd[q] = rl(Pd, 63);
+        }
+        // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
+        f2 an0 = {Bn[0], Bn[0] + Bn[0] * 0x1p-23f}, ad0 = {Bd[0], Bd[0] + Bd[0] * 0x1p-23f};
+        f2 an1 = {Bn[1], Bn[1] + Bn[1] * 0x1p-23f}, ad1 = {Bd[1], Bd[1] + Bd[1] * 0x1p-23f};
+        round_loop_q2(wrsrc, pv, tbaseU & ~7, pv.n, 4u * (uint32_t)(j0 + lane), rtab, vb[0], vb[1], an0, ad0, an1, ad1);
+        if (STAMP) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            t_loop += t1 - t0c;
+            t0c = t1;
+            ++n_rounds;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f2 an = q ? an1 : an0, ad = q ? ad1 : ad0;
+            // (a lane whose row takes no part added W x flag to its denominator accumulators: ignored)
+            const ResolvedLg rn = resolve_lg<STAMP>(cv[q], wup, rtab, j0, tbase[q], vall[q], vmask[q], 0, sn[q], Bn[q], an.x - Bn[q],
+                                                    an.y - (Bn[q] + Bn[q] * 0x1p-23f));
+            const ResolvedLg rd = resolve_lg<STAMP>(cv[q], wup, rtab, j0, tbase[q], vall[q], vmask[q], 1, sd[q], Bd[q],
+                                                    takes[q] ? ad.x - Bd[q] : 0.0f, takes[q] ? ad.y - (Bd[q] + Bd[q] * 0x1p-23f) : 0.0f);
+            const float sn1 = unif(rn.s), sd1 = unif(rd.s);
+            if (sn1 > sn[q] && Qn[q] > 0.0f) cn[q] = unif((sn1 - sn[q]) / Qn[q]);
+            if (sd1 > sd[q] && Qd[q] > 0.0f) cd[q] = unif((sd1 - sd[q]) / Qd[q]);
+            sn[q] = sn1;
+            sd[q] = sd1;
+            tbase[q] += __builtin_popcountll(vall[q]);
+            if (STAMP) {
+                n_ordered += (unsigned)(rn.ordered + rd.ordered);
+                t_ord += rn.t_ordered + rd.t_ordered;
+            }
+        }
+        tbaseU += __builtin_popcountll(vall[0] | vall[1]);
+        if (STAMP) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            t_res += t1 - t0c;
+            t0c = t1;
+        }
+    }
+    if (STAMP && lane == 0) {
+        atomicAdd(&g_bx_stamps[0], t_pro);
+        atomicAdd(&g_bx_stamps[1], t_loop);
+        atomicAdd(&g_bx_stamps[2], t_res);
+        atomicAdd(&g_bx_stamps[3], 1ull);
+        atomicAdd(&g_bx_stamps[4], n_rounds);
+        atomicAdd(&g_bx_stamps[6], __builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
+        atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
+        atomicMax(&g_bx_stamps[8], n_rounds);
+        atomicAdd(&g_bx_stamps[10], n_ordered);
+        atomicAdd(&g_bx_stamps[11], t_ord);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (col[q] < n) {
+                num_out[col[q]] = sn[q];
+                den_out[col[q]] = sd[q];
+            }
+    }
+}
+
+// The union lists of the column pairs (one wave per pair): for every row that takes part in either column, in row
+// order: W row offset, the two table-row offsets (row behind the alphabet = zero row where the row takes no part),
+// the two 1/0 flags; padded behind the last entry like the single-column lists.
+__global__ __launch_bounds__(256) void lg2_union_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, const int32_t *__restrict__ cols,
+                                                        int npairs, uint32_t ldw4, int nr, uint32_t *__restrict__ uoff,
+                                                        uint32_t *__restrict__ utt, float *__restrict__ uee, int32_t *__restrict__ nunion) {
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= npairs) return;
+    const uint8_t *s0 = codeT + (size_t)cols[2 * pi] * ldk, *s1 = codeT + (size_t)cols[2 * pi + 1] * ldk;
+    uint32_t *po = uoff + (size_t)pi * ldk, *pt = utt + (size_t)pi * ldk;
+    float2 *pe = reinterpret_cast<float2 *>(uee) + (size_t)pi * ldk;
+    const uint32_t stride = (uint32_t)nr * 128u, zrow = (uint32_t)(nr - 1) * stride;
+    int count = 0;
+    for (int kb = 0; kb < m; kb += 64) {
+        const int k = kb + lane;
+        const uint32_t c0 = k < m ? s0[k] : BX_SKIP, c1 = k < m ? s1[k] : BX_SKIP;
+        const bool v0 = c0 != BX_SKIP, v1 = c1 != BX_SKIP;
+        const unsigned long long mask = __ballot(v0 || v1);
+        if (v0 || v1) {
+            const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            po[pos] = (uint32_t)k * ldw4;
+            pt[pos] = (v0 ? (c0 >> 3) * stride : zrow) | ((v1 ? (c1 >> 3) * stride : zrow) << 16);
+            pe[pos] = make_float2(v0 ? 1.0f : 0.0f, v1 ? 1.0f : 0.0f);
+        }
+        count += __builtin_popcountll(mask);
+    }
+    for (int64_t t = count + lane; t < ldk; t += 64) {
+        po[t] = (uint32_t)m * ldw4;  // row m of W: zeros
+        pt[t] = zrow | (zrow << 16);
+        pe[t] = make_float2(0.0f, 0.0f);
+    }
+    if (lane == 0) nunion[pi] = count;
+}
+
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
 // row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
@@ -1234,6 +1564,39 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
         else LG_LAUNCH(similarity_lg_regs_kernel<false>);
     }
 #undef LG_LAUNCH
+    return 0;
+}
+
+// Two columns per wave (consecutive entries of `cols`, ncols even, padded with the all-skipped column n; `waves`
+// consecutive pairs share a workgroup): the union lists are built here from the column order.  npos + 1 <= 23
+// (16-bit table-row offsets).
+bool lg2_fits(int npos) { return npos + 1 <= 23; }
+int lg2_max_waves() { return LG2_WAVES; }
+int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, int npos,
+                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, int waves,
+                          uint32_t *uoff, uint32_t *utt, float *uee, int32_t *nunion, const float *wlow, const float *wup, int ldw,
+                          const void *tab, float *num_out, float *den_out) {
+    const int64_t ldk = bx_ldk(m);
+    const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0;
+    const int npairs = ncols / 2;
+    if (npairs == 0) return 0;
+    const int nr = npos + 1;
+    lg2_union_kernel<<<(npairs + 3) / 4, 256, 0, s>>>(codeT, ldk, m, cols, npairs, (uint32_t)ldw * 4u, nr, uoff, utt, uee, nunion);
+    const size_t dyn = (size_t)nr * nr * 128;
+    if (waves < 1 || waves > LG2_WAVES) return (int)hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((npairs + waves - 1) / waves);
+    const float *t = static_cast<const float *>(tab);
+    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
+    const bool stamp = (tuning().sim_mode & 64) != 0;
+    const void *k = stamp ? (const void *)similarity_lg2_kernel<true> : (const void *)similarity_lg2_kernel<false>;
+    const int e = set_max_lds_once(k, (int)dyn);
+    if (e) return e;
+    if (stamp)
+        similarity_lg2_kernel<true><<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, npairs, uoff, utt, uee,
+                                                                     nunion, nr, wlow, wbytes, wup, ldw, r0, t, num_out, den_out);
+    else
+        similarity_lg2_kernel<false><<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, npairs, uoff, utt, uee,
+                                                                      nunion, nr, wlow, wbytes, wup, ldw, r0, t, num_out, den_out);
     return 0;
 }
 

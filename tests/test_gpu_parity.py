@@ -31,7 +31,8 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM"):
+        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
+                     "MSA_LG_REGS", "MSA_LG_DBG"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -281,9 +282,9 @@ def _sim_parity(ctx, a, indet=ord("X")):
     assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
 
 
-# binade-exact with per-lane grids (default), its one-grid-per-round predecessor, numerator + denominator chain
-# kernels, single chain
-KERNELS = ["", "bx", "chain", "pc"]
+# binade-exact with per-lane grids: by size (default) / one column per wave / two columns per wave; its
+# one-grid-per-round predecessor; numerator + denominator chain kernels; single chain
+KERNELS = ["", "lg", "q2", "bx", "chain", "pc"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -304,15 +305,44 @@ def test_binade_kernel_shapes(ctx_with, compact, r0):
     _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT=compact, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
 
 
+@pytest.mark.parametrize("kernel", ["lg", "q2"])
 @pytest.mark.parametrize("r0", ["0", "1", "3", "8", "40", "64", "70", "200"])
-def test_lane_grid_kernel_ordered_prefix(ctx_with, r0):
+def test_lane_grid_kernel_ordered_prefix(ctx_with, kernel, r0):
     """Per-lane grids: the number of rows evaluated in order before the first round (which then starts in the middle
     of a 64-row block, or several blocks in) must not matter."""
-    _sim_parity(ctx_with(MSA_BX_R0=r0), synth_msa(300, 150, 31))
-    _sim_parity(ctx_with(MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_BX_R0=r0), synth_msa(300, 150, 31))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
 
 
-def test_lane_grid_kernel_adversarial_predictions(ctx):
+@pytest.mark.parametrize("regs", ["0", "1"])
+def test_lane_grid_kernel_table_in_registers(ctx_with, regs):
+    """One column per wave: the lane's table column in LDS (default) or in 32 registers."""
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="lg", MSA_LG_REGS=regs), synth_msa(640, 257, 4882))
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="lg", MSA_LG_REGS=regs), _conserved_case(200, 70, 5))
+
+
+def test_column_pairs_with_disjoint_rows(ctx_with):
+    """Two columns per wave: neighbours whose valid rows barely overlap (the union list is twice as long as either
+    column's), columns that begin with more than 64 rows that take no part, an odd number of columns."""
+    r = np.random.default_rng(11)
+    a = synth_msa(330, 41, 77)
+    a[::2, 0:10] = ord("-")    # even rows only
+    a[1::2, 10:20] = ord("-")  # odd rows only
+    a[:150, 20:24] = ord("-")  # start late
+    a[:70, 24:27] = ord("-")
+    a[100:, 27:30] = ord("-")  # end early
+    a[r.random(a.shape) < 0.01] = ord("X")
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="q2"), np.ascontiguousarray(a))
+
+
+def test_column_pairs_chosen_by_size(ctx):
+    """The default picks two columns per wave from 5120 evaluated columns on (20 per CU): 6000 columns of 130 rows."""
+    _sim_parity(ctx, synth_msa(130, 6000, 99))
+
+
+@pytest.mark.parametrize("kernel", ["lg", "q2"])
+def test_lane_grid_kernel_adversarial_predictions(ctx_with, kernel):
+    ctx = ctx_with(MSA_SIM_KERNEL=kernel)
     """Columns whose sums the per-lane predictor cannot foresee: the top half of the rows identical sequences (all
     their mutual weights zero, then a jump), a block of gaps in the middle of every column, residues sorted by row."""
     r = np.random.default_rng(5)
@@ -354,13 +384,13 @@ def test_similarity_above_resident_limit(ctx_with, kernel):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2100, 72, 77))
 
 
-@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
+@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
 def test_similarity_36_round_resident_kernel(ctx_with, kernel):
     """2016 < m <= 4032: the 36-round instantiation of the resident numerator kernel."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2017, 33, 79))
 
 
-@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
+@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
 def test_similarity_streaming_numerator(ctx_with, kernel):
     """m > 4032: the chain numerator kernel streams its codes two rounds ahead."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(4040, 20, 80))
@@ -377,13 +407,13 @@ def test_similarity_fallback_kernels(ctx_with, switch, shape):
     _sim_parity(ctx_with(MSA_SIM_KERNEL="chain", **{name: value}), synth_msa(m, n, 515 + m))
 
 
-@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
+@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
 def test_similarity_many_rows_few_columns(ctx_with, kernel):
     """m = 9000, a single partial column tile."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(9000, 8, 81))
 
 
-@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
+@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
 def test_similarity_at_resident_limit(ctx_with, kernel):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2016, 40, 78))
 
@@ -454,7 +484,7 @@ def test_nucleotide_statistics(ctx, degenerate):
     assert err is None
 
 
-@pytest.mark.parametrize("kernel", ["", "bx", "chain"])
+@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
 def test_wide_alignment_many_workgroups(ctx_with, kernel):
     """Many more column tiles than CUs (the chain workgroups take a CU each): several waves of workgroups."""
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(60, 40000, 4321))
