@@ -458,11 +458,10 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     // (its compacted lists hold 16-bit row indices and 32-bit W offsets: larger alignments take the chain kernels)
     const bool bx_fits = m < 32000;
     if (bx_family && bx_fits) {
-        // 0: by size -- two columns per wave from 5 pairs per workgroup and two workgroups per CU on (all its waves are
-        // resident from the start: fewer would leave the SIMDs short of waves) and alphabets up to 22 letters, else one
-        // column per wave; 4 "lg": one column per wave; 5 "q2": two columns per wave; 3 "bx": the one-grid-per-round
-        // predecessor
-        bool pairs2 = (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 5) && msak::lg2_fits(npos);
+        // 0 / 4 "lg": one column per wave (measured at least as fast as two columns per wave at every shape tried:
+        // tools/lg_sweep.py); 5 "q2": two columns per wave sharing the W loads (alphabets up to 22 letters);
+        // 3 "bx": the one-grid-per-round predecessor
+        const bool pairs2 = c->tuning.sim_kernel == 5 && msak::lg2_fits(npos);
         const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
         HIPCHK(c, c->codeT.reserve(lsz));
         HIPCHK(c, c->bx_off.reserve(lsz));
@@ -504,7 +503,6 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
                 order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
                 ++nact;
             }
-        if (c->tuning.sim_kernel == 0 && nact < 20 * std::max(1, c->cus)) pairs2 = false;
         int npad = 0;
         if (q == 2) {
             for (int i = 0, k = nact - 1; i <= k; ++i, --k) {

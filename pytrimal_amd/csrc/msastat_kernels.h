@@ -8,8 +8,8 @@ namespace msak {
 // Diagnostic switches (environment variables MSA_*), read ONCE when a context is created and handed to the
 // launch wrappers through a thread-local pointer for the duration of an API call (contexts are per thread).
 struct Tuning {
-    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 binade-exact with per-lane grids, one or two columns per wave by size (default),
-                               // 4 "lg" one column per wave, 5 "q2" two columns per wave, 3 "bx" its one-grid-per-round predecessor,
+    int sim_kernel = 0;        // MSA_SIM_KERNEL: 0 / 4 "lg" binade-exact with per-lane grids, one column per wave (default),
+                               // 5 "q2" two columns per wave, 3 "bx" its one-grid-per-round predecessor,
                                // 1 "chain" numerator + denominator kernels, 2 "pc"
     int sim_tcols = 0;         // MSA_SIM_TCOLS: column-tile width of the chain kernels (0 = 64)
     int sim_mode = 0;          // MSA_SIM_MODE: in-kernel stamps / ablations of the chain kernels
@@ -25,7 +25,7 @@ struct Tuning {
     int bx_compact = 0;        // MSA_BX_COMPACT=1: the rows of a round are consecutive valid rows (gather loads of W)
     int bx_asm = 0;            // MSA_BX_ASM=1: the round loop with the table read folded into the multiply (inline asm; experimental)
     int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
-    int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, with MSA_SIM_MODE=64 only; 2: four waves per workgroup)
+    int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, with MSA_SIM_MODE=64 only; 2: eight waves per workgroup; 16: two columns per wave without wave priorities)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
 };
 Tuning tuning_from_env();

@@ -1209,6 +1209,15 @@ __global__ __launch_bounds__(64 * LG2_WAVES) __attribute__((amdgpu_waves_per_eu(
     const int wave = uni(threadIdx.x >> 6);
     const int pi = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (pi >= npairs) return;
+    // Every wave is resident from the start and the kernel ends with the heaviest pair: the host deals the pairs so
+    // that wave 0 of a workgroup holds the heaviest and the last wave the lightest -- the heavy ones issue first.
+    if (!(r0_ & 0x20000)) {
+        const int nw = (int)(blockDim.x >> 6);
+        const int band = nw > 1 ? (wave * 4) / nw : 0;  // 0 (heaviest quarter) .. 3
+        if (band == 0) __builtin_amdgcn_s_setprio(3);
+        else if (band == 1) __builtin_amdgcn_s_setprio(2);
+        else if (band == 2) __builtin_amdgcn_s_setprio(1);
+    }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
     PairView pv;
     pv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)uoff_ + (size_t)pi * ldk);
@@ -1543,7 +1552,9 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     const bool ldst = tuning().lg_regs == 0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
     // eight waves per workgroup while their tables stay within the 64 KB M0 can address (static arrays: 10.5 KB)
-    const int waves = ldst ? ((size_t)8 * nr * 256 + 10752 <= 65536 && !(tuning().lg_dbg & 2) ? 8 : 4) : BX_WAVES;
+    // four waves per workgroup: five workgroups (20 waves) per CU for a 20-letter alphabet, and a workgroup's slots
+    // are refilled as soon as its four columns are done (eight per workgroup, MSA_LG_DBG & 2: 4.0 instead of 3.8 ms at C3)
+    const int waves = ldst ? ((tuning().lg_dbg & 2) && (size_t)8 * nr * 256 + 10752 <= 65536 ? 8 : 4) : BX_WAVES;
     const size_t dyn = ldst ? (size_t)waves * nr * 256 : 0;
     const unsigned grid = (unsigned)((ncols + waves - 1) / waves);
     if (grid == 0) return 0;
@@ -1577,7 +1588,8 @@ int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *v
                           uint32_t *uoff, uint32_t *utt, float *uee, int32_t *nunion, const float *wlow, const float *wup, int ldw,
                           const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
-    const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0;
+    // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 16 -> no wave priorities)
+    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 16) ? 0x20000 : 0);
     const int npairs = ncols / 2;
     if (npairs == 0) return 0;
     const int nr = npos + 1;

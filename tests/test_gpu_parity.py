@@ -282,7 +282,7 @@ def _sim_parity(ctx, a, indet=ord("X")):
     assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
 
 
-# binade-exact with per-lane grids: by size (default) / one column per wave / two columns per wave; its
+# binade-exact with per-lane grids: one column per wave (default = "lg") / two columns per wave; its
 # one-grid-per-round predecessor; numerator + denominator chain kernels; single chain
 KERNELS = ["", "lg", "q2", "bx", "chain", "pc"]
 
@@ -335,9 +335,9 @@ def test_column_pairs_with_disjoint_rows(ctx_with):
     _sim_parity(ctx_with(MSA_SIM_KERNEL="q2"), np.ascontiguousarray(a))
 
 
-def test_column_pairs_chosen_by_size(ctx):
-    """The default picks two columns per wave from 5120 evaluated columns on (20 per CU): 6000 columns of 130 rows."""
-    _sim_parity(ctx, synth_msa(130, 6000, 99))
+def test_column_pairs_many_workgroups(ctx_with):
+    """Two columns per wave with more pairs than two workgroups per CU hold at one wave each: 6000 columns of 130 rows."""
+    _sim_parity(ctx_with(MSA_SIM_KERNEL="q2"), synth_msa(130, 6000, 99))
 
 
 @pytest.mark.parametrize("kernel", ["lg", "q2"])
