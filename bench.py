@@ -34,6 +34,29 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
+# the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane buffer loads of L2-resident rows, measured
+# with tools/ubench_wstream.hip on an MI355X (profiles/r02_ubench_wstream.txt): 18.0 - 18.7 TB/s chip-wide at 4 - 8
+# waves per SIMD, i.e. ~8.5 CU-cycles per wave-load whatever the occupancy
+W_STREAM_PEAK_GBS = 18500.0
+
+
+def similarity_w_stream_bytes(a, indet=ord("X")):
+    """Bytes of W the similarity kernel moves through the vector-memory pipeline in one launch (one 256-byte row per
+    partner step), computed from the alignment: per evaluated column and 64-row round, the valid rows at or behind
+    the round's first row, rounded to the 32-step granularity of the round loop."""
+    m, n = a.shape
+    valid = (a != ord("-")) & (a != indet)
+    nvalid = valid.sum(axis=0)
+    active = (a == ord("-")).sum(axis=0) / np.float32(m) < np.float32(0.8)
+    steps = 0
+    before = np.zeros(n, dtype=np.int64)
+    for j0 in range(0, m - 1, 64):
+        todo = nvalid - before
+        live = active & (todo > 0)
+        steps += int((((todo[live] + (before[live] & 15) + 31) // 32) * 32).sum())
+        before = before + valid[j0:j0 + 64].sum(axis=0)
+    return steps * 256, steps
+
 
 WORKLOADS = {
     # name: (m, n, base seed)
@@ -354,6 +377,16 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": alg, "ms_avg": round(kernels[dom]["ms_avg"], 4),
             }
+            if dom == "sim" and args.workload != "C5":
+                # what bounds it: the stream of W rows through the L1 / texture-addresser pipeline (all L2 hits), not HBM
+                wbytes, wsteps = similarity_w_stream_bytes(a)
+                rate = wbytes / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
+                roofline["w_stream"] = {
+                    "bound": "vector-memory pipeline (L1/TA), 256-byte dword loads of L2-resident W rows",
+                    "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
+                    "peak_source": "tools/ubench_wstream.hip on one MI355X (profiles/r02_ubench_wstream.txt), not measured in this run",
+                }
             if dom in ("sim", "pairs"):
                 # the pairwise passes are VALU-issue work, not bandwidth: one "pair-column" = one (j, k, column) term
                 pcs = pairs * n / (kernels[dom]["ms_avg"] * 1e-3)
@@ -361,9 +394,10 @@ def main():
                     "pair_columns_per_s": round(pcs, 1),
                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS,
                     "pair_columns_per_lane_op_peak": round(pcs / VALU_PEAK_LANEOPS, 4),
-                    "note": ("order-preserving fp32 accumulation evaluated in parallel (binade-exact kernel, DESIGN.md section "
-                             "5b): about 5.6 VALU instructions per 64 (row, partner) terms, of which two are the sums themselves; "
-                             "bound by VALU issue, HBM is irrelevant (the path moves tens of MB)") if dom == "sim" else
+                    "note": ("order-preserving fp32 accumulation evaluated in parallel (binade-exact kernel with per-lane "
+                             "grids, DESIGN.md section 5): three VALU instructions, one LDS row and one 256-byte W row per 64 "
+                             "(row, partner) terms; bound by the W stream through the vector-memory pipeline (roofline.w_stream), "
+                             "HBM is irrelevant (the path moves tens of MB)") if dom == "sim" else
                             "bit-sliced XOR / popcount over 32 columns per word: VALU issue + load latency, not bandwidth",
                 }
         roofline_all = {}

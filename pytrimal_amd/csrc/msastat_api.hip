@@ -138,6 +138,8 @@ struct msa_ctx {
     bool planes_pending = false;
     PinBuf<int32_t> h_gapstage;    // gap / indetermination counts on their way to h_gaps / h_indets
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
+    PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
+    int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete
 
     // host copies valid for the current alignment
     std::vector<int32_t> h_gaps, h_indets;
@@ -170,6 +172,7 @@ static int sync_stream(msa_ctx *c) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
     if (c->gaps_staged == 1) c->gaps_staged = 2;
+    if (c->rowtot_staged == 1) c->rowtot_staged = 2;
     if (c->planes_pending) {
         c->planes_pending = false;
         if (c->h_planeflag.p[0]) {
@@ -233,6 +236,7 @@ void invalidate(msa_ctx *c) {
     c->pairflag_pending = false;
     c->h_gaps.clear();
     c->gaps_staged = 0;
+    c->rowtot_staged = 0;
     c->planes_pending = false;
     c->h_indets.clear();
 }
@@ -652,8 +656,40 @@ int overlap(msa_ctx *c, float residue_overlap, float *out) {
 
 // Cleaner::removeAllGapsSeqsAndCols: first sequences (over kept columns), then columns (over
 // the updated sequences).
+// Residues per sequence over ALL columns, enqueued without waiting (the next synchronisation completes the copy):
+// remove_all_gaps can then tell from the host that no sequence can have lost all its residues.
+int stage_row_totals(msa_ctx *c) {
+    if (c->rowtot_staged || c->m <= 0 || c->n <= 0) return MSA_OK;
+    const int m = c->m, n = c->n;
+    HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
+    HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
+    HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
+    HIPCHK(c, hipMemsetAsync(c->keep_res_d.p, 1, (size_t)n + 64, c->stream));
+    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    c->rowtot_staged = 1;
+    return MSA_OK;
+}
+
 int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     const int m = c->m, n = c->n;
+    if (c->rowtot_staged == 2 && (int)c->h_gaps.size() == n) {
+        // A kept sequence with more residues than there are removed columns keeps at least one of them: when that
+        // holds for every kept sequence, none is left with gaps only, and (all sequences kept) a column is all-gap
+        // exactly when its gap count is m -- no pass over the alignment, no synchronisation.
+        const int removed = n - (int)std::count(keep_res, keep_res + n, 1);
+        bool safe = true, all_rows = true;
+        for (int i = 0; i < m && safe; ++i) {
+            if (keep_seq[i]) safe = c->h_rowtot.p[i] > removed;
+            else all_rows = false;
+        }
+        if (safe && all_rows) {
+            for (int j = 0; j < n; ++j)
+                if (keep_res[j] && c->h_gaps[j] == m) keep_res[j] = 0;
+            return MSA_OK;
+        }
+    }
     HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
     HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
@@ -938,7 +974,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
-    c->h_planeflag.release(); c->h_gapstage.release();
+    c->h_planeflag.release(); c->h_gapstage.release(); c->h_rowtot.release();
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);
@@ -1203,6 +1239,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             trace.mark("gaps");
             info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
             trace.mark("gap cut");
+            if ((rc = stage_row_totals(c))) return rc;  // (rides on the similarity fetch's wait)
             if ((rc = need_sim())) return rc;
             trace.mark("similarity");
             info->sim_cut = msah::comb_similarity_cut(gaps_w.data(), mdk_w.data(), n, info->gap_cut);

@@ -243,19 +243,29 @@ float comb_similarity_cut(const int32_t *gw, const float *mdkw, int n, int gap_c
     // p20 / p80: the value of the LAST descending rank whose percentage (float division, as upstream) is
     // <= 20 / <= 80; 0 when no rank qualifies.  The percentage grows with the rank, so the two ranks
     // come from a scan over ranks alone and the values from two selections instead of a full sort.
-    int r20 = 0, r80 = 0;
-    for (int rank = 1; rank <= size; ++rank) {
-        const double pct = (static_cast<float>(rank) / size) * 100.0;
-        if (pct <= 20.0) r20 = rank;
-        if (pct <= 80.0) r80 = rank;
-    }
-    auto by_rank = [&](int rank) -> float {  // rank 1 = largest value
-        if (rank == 0) return 0.0f;
-        auto nth = pool.begin() + (size - rank);
-        std::nth_element(pool.begin(), nth, pool.end());
-        return *nth;
+    // (the percentage is monotone in the rank: start from the arithmetic guess and settle on the exact comparison)
+    auto last_rank = [&](double limit) {
+        auto pct = [&](int rank) { return (static_cast<float>(rank) / size) * 100.0; };
+        int r = std::min(size, std::max(0, static_cast<int>(limit / 100.0 * size)));
+        while (r < size && pct(r + 1) <= limit) ++r;
+        while (r > 0 && pct(r) > limit) --r;
+        return r;
     };
-    const float p20 = by_rank(r20), p80 = by_rank(r80);
+    const int r20 = size > 0 ? last_rank(20.0) : 0, r80 = size > 0 ? last_rank(80.0) : 0;
+    // rank 1 = largest value; the lower rank first, the higher one (r20 <= r80) then lies in the part above it
+    float p20 = 0.0f, p80 = 0.0f;
+    auto from = pool.begin();
+    if (r80 > 0) {
+        auto nth = pool.begin() + (size - r80);
+        std::nth_element(pool.begin(), nth, pool.end());
+        p80 = *nth;
+        from = nth;
+    }
+    if (r20 > 0) {
+        auto nth = pool.begin() + (size - r20);
+        std::nth_element(from, nth, pool.end());
+        p20 = *nth;
+    }
     const double hi = std::log10(static_cast<double>(p20)), lo = std::log10(static_cast<double>(p80));
     return static_cast<float>(std::pow(10, ((hi - lo) / 10) + lo));
 }
