@@ -19,7 +19,12 @@ for w in C3 C2 C4 C5; do
 done
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/sq1_C3 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq1_C3.log 2>&1
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAVES SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/sq2_C3 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq2_C3.log 2>&1
+timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/sq3_C3 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/sq3_C3.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1_C4 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload C4 > $OUT/sq1_C4.log 2>&1
+cd $ROOT
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wstream tools/ubench_wstream.hip && timeout 120 /tmp/ubench_wstream > $OUT/ubench_wstream.txt 2>&1
+timeout 300 python tools/lg_sweep.py 2>/dev/null | grep "^{" > $OUT/lg_sweep.jsonl
+for k in "" q2 bx; do MSA_SIM_KERNEL=$k timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms | sed "s/^{/{\"kernel\": \"${k:-lg}\", /"; done > $OUT/bx_stamps.jsonl
 ls $OUT | head -40
 # keep only the small csv files (the merge back is limited to 64 MiB)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete

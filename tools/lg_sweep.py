@@ -1,5 +1,6 @@
-"""Similarity kernel time by shape and kernel variant (MSA_SIM_KERNEL = lg / q2, MSA_LG_DBG): where does two columns
-per wave start to pay?"""
+"""Similarity kernel time (ms) by shape and kernel variant: one column per wave (default: table in LDS, four waves per
+workgroup; eight waves per workgroup; table in registers), two columns per wave (q2), the one-grid-per-round
+predecessor (bx)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,9 +17,10 @@ shapes = [(2000, 3000), (2000, 5000), (2000, 7000), (2000, 10000), (1000, 4000),
 for m, n in shapes:
     a = synth_msa(m, n, 5000 + m + n)
     row = {"m": m, "n": n}
-    for label, env in (("lg", {"MSA_SIM_KERNEL": "lg"}), ("lg_wg4", {"MSA_SIM_KERNEL": "lg", "MSA_LG_DBG": "2"}),
-                       ("q2", {"MSA_SIM_KERNEL": "q2"})):
-        for k in ("MSA_SIM_KERNEL", "MSA_LG_DBG"):
+    for label, env in (("lg", {"MSA_SIM_KERNEL": "lg"}), ("lg_8_waves_per_workgroup", {"MSA_SIM_KERNEL": "lg", "MSA_LG_DBG": "2"}),
+                       ("lg_table_in_registers", {"MSA_SIM_KERNEL": "lg", "MSA_LG_REGS": "1"}), ("q2", {"MSA_SIM_KERNEL": "q2"}),
+                       ("bx", {"MSA_SIM_KERNEL": "bx"})):
+        for k in ("MSA_SIM_KERNEL", "MSA_LG_DBG", "MSA_LG_REGS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx = _lib.Context(0)

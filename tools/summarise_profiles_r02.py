@@ -24,7 +24,8 @@ def counters(d):
 
 
 family = {  # kernel -> the name bench.py's roofline uses
-    "msak::similarity_bx_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::gap_counts_kernel": "gaps",
+    "msak::similarity_bx_kernel": "sim", "msak::similarity_lg_kernel": "sim", "msak::similarity_lg_regs_kernel": "sim",
+    "msak::similarity_lg2_kernel": "sim", "msak::lg2_union_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::gap_counts_kernel": "gaps",
     "msak::prep_planes_kernel": "prep", "msak::identity_rows_kernel": "idstats", "msak::sim_encode_cm_kernel": "encode",
     "msak::bx_compact_kernel": "encode", "msak::cluster_mis_kernel": "cluster", "msak::cluster_adjacency_kernel": "cluster",
 }
@@ -66,7 +67,7 @@ for w in ("C3", "C2", "C4", "C5"):
 out = ["# rocprofv3 --pmc <SQ / GRBM counters> --kernel-trace over python3 bench.py --steps 3 --warmup 1; averages per dispatch.",
        "# SQ_* cycle counters count quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs:",
        "# kernel cycles = GRBM_GUI_ACTIVE / 8.  VALU busy = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles)."]
-for tag, dirs in (("C3", ("sq1_C3", "sq2_C3")), ("C4", ("sq1_C4",))):
+for tag, dirs in (("C3", ("sq1_C3", "sq2_C3", "sq3_C3")), ("C4", ("sq1_C4",))):
     acc = {}
     for d in dirs:
         acc.update(counters(d))
@@ -81,10 +82,20 @@ for tag, dirs in (("C3", ("sq1_C3", "sq2_C3")), ("C4", ("sq1_C4",))):
         if "GRBM_GUI_ACTIVE" in vals and "SQ_INSTS_VALU" in vals:
             cyc = vals["GRBM_GUI_ACTIVE"] / 8
             out.append(f"    -> kernel cycles {cyc:.3g}, VALU busy {vals['SQ_INSTS_VALU'] * 4 / (1024 * cyc):.2f}")
-        if "SQ_INSTS_VMEM_RD" in vals and "SQ_INSTS_VALU" in vals and "similarity_bx" in k:
-            out.append(f"    -> partner steps {vals['SQ_INSTS_VMEM_RD']:.3g} (one buffer load each), VALU / step "
-                       f"{vals['SQ_INSTS_VALU'] / vals['SQ_INSTS_VMEM_RD']:.2f}, SALU / step "
+        if "SQ_INSTS_VMEM_RD" in vals and "SQ_INSTS_VALU" in vals and "similarity_" in k:
+            out.append(f"    -> vector loads {vals['SQ_INSTS_VMEM_RD']:.3g} (one per partner step + the ordered rows), VALU / load "
+                       f"{vals['SQ_INSTS_VALU'] / vals['SQ_INSTS_VMEM_RD']:.2f}, SALU / load "
                        f"{vals.get('SQ_INSTS_SALU', 0) / vals['SQ_INSTS_VMEM_RD']:.2f}")
+        if "TA_TA_BUSY_sum" in vals and "GRBM_GUI_ACTIVE" in vals:
+            cyc = vals["GRBM_GUI_ACTIVE"] / 8
+            out.append(f"    -> texture addresser busy {vals['TA_TA_BUSY_sum'] / 256 / cyc:.2f} of the kernel (sum over 256 CUs), "
+                       f"texture data {vals.get('TD_TD_BUSY_sum', 0) / 256 / cyc:.2f}, LDS {vals.get('SQ_LDS_IDX_ACTIVE', 0) / 256 / cyc:.2f}")
 open(os.path.join(DST, "r02_pmc_sq.txt"), "w").write("\n".join(out) + "\n")
+ub = os.path.join(SRC, "ubench_wstream.txt")
+if os.path.exists(ub):
+    shutil.copy(ub, os.path.join(DST, "r02_ubench_wstream.txt"))
+for name in ("lg_sweep.jsonl", "bx_stamps.jsonl"):
+    if os.path.exists(os.path.join(SRC, name)):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r02_" + name))
 print("\n".join(lines[-40:]))
 print("\n".join(out))
