@@ -252,19 +252,53 @@ float comb_similarity_cut(const int32_t *gw, const float *mdkw, int n, int gap_c
         return r;
     };
     const int r20 = size > 0 ? last_rank(20.0) : 0, r80 = size > 0 ? last_rank(80.0) : 0;
-    // rank 1 = largest value; the lower rank first, the higher one (r20 <= r80) then lies in the part above it
+    // rank 1 = largest value.  Selection by a histogram over the leading bits of the (non-negative) floats -- their
+    // bit patterns order like the values -- and a selection inside the one bucket that holds the rank: two linear
+    // passes instead of two nth_element runs over the whole pool (negative or NaN values: plain nth_element).
     float p20 = 0.0f, p80 = 0.0f;
-    auto from = pool.begin();
-    if (r80 > 0) {
-        auto nth = pool.begin() + (size - r80);
-        std::nth_element(pool.begin(), nth, pool.end());
-        p80 = *nth;
-        from = nth;
+    bool plain = size < 2048;
+    if (!plain) {
+        constexpr int SHIFT = 18, NB = 1 << (31 - SHIFT);
+        std::vector<uint32_t> hist(NB + 1, 0u);
+        for (int i = 0; i < size && !plain; ++i) {
+            uint32_t b;
+            std::memcpy(&b, &pool[i], 4);
+            if (b >> 31 || b > 0x7F800000u) plain = true;
+            else ++hist[(b >> SHIFT) + 1];
+        }
+        if (!plain) {
+            for (int i = 0; i < NB; ++i) hist[i + 1] += hist[i];  // hist[k] = elements in buckets below k
+            std::vector<float> bucket;
+            auto select = [&](int rank) -> float {  // the element at ascending position size - rank
+                const uint32_t pos = static_cast<uint32_t>(size - rank);
+                const int k = static_cast<int>(std::upper_bound(hist.begin(), hist.end(), pos) - hist.begin()) - 1;
+                bucket.clear();
+                for (int i = 0; i < size; ++i) {
+                    uint32_t b;
+                    std::memcpy(&b, &pool[i], 4);
+                    if (static_cast<int>(b >> SHIFT) == k) bucket.push_back(pool[i]);
+                }
+                auto nth = bucket.begin() + (pos - hist[k]);
+                std::nth_element(bucket.begin(), nth, bucket.end());
+                return *nth;
+            };
+            if (r80 > 0) p80 = select(r80);
+            if (r20 > 0) p20 = select(r20);
+        }
     }
-    if (r20 > 0) {
-        auto nth = pool.begin() + (size - r20);
-        std::nth_element(from, nth, pool.end());
-        p20 = *nth;
+    if (plain) {  // the lower rank first, the higher one (r20 <= r80) then lies in the part above it
+        auto from = pool.begin();
+        if (r80 > 0) {
+            auto nth = pool.begin() + (size - r80);
+            std::nth_element(pool.begin(), nth, pool.end());
+            p80 = *nth;
+            from = nth;
+        }
+        if (r20 > 0) {
+            auto nth = pool.begin() + (size - r20);
+            std::nth_element(from, nth, pool.end());
+            p20 = *nth;
+        }
     }
     const double hi = std::log10(static_cast<double>(p20)), lo = std::log10(static_cast<double>(p80));
     return static_cast<float>(std::pow(10, ((hi - lo) / 10) + lo));
@@ -272,16 +306,21 @@ float comb_similarity_cut(const int32_t *gw, const float *mdkw, int n, int gap_c
 
 void clean_strict(const int32_t *gw, const float *mdkw, int n, int gap_cut, float sim_cut, bool variable,
                   uint8_t *keep) {
-    std::vector<uint8_t> rejected(n);
-    for (int c = 0; c < n; ++c) rejected[c] = gw[c] > gap_cut || mdkw[c] < sim_cut;
-    for (int c = 0; c < n; ++c) keep[c] = !rejected[c];
+    // (two guard entries on either side, branch-free passes: the compiler vectorises them)
+    std::vector<uint8_t> rej_store(static_cast<size_t>(n) + 4, 0);
+    uint8_t *rejected = rej_store.data() + 2;
+    for (int c = 0; c < n; ++c) rejected[c] = static_cast<uint8_t>((gw[c] > gap_cut) | (mdkw[c] < sim_cut));
     // rescue a rejected column when enough of its neighbours were accepted BEFORE any rescue
+    for (int c = 2; c < n - 2; ++c) {
+        const int around = rejected[c - 2] + rejected[c - 1] + rejected[c + 1] + rejected[c + 2];
+        keep[c] = static_cast<uint8_t>(!rejected[c] | (around <= 1));
+    }
     auto rej = [&](int c) { return static_cast<int>(rejected[c]); };
+    for (int c : {0, 1, n - 2, n - 1})
+        if (c >= 0 && c < n && (c < 2 || c >= n - 2)) keep[c] = !rejected[c];
     if (n > 2 && rejected[0]) keep[0] = (rej(1) + rej(2)) == 0;
     if (n > 3 && rejected[1]) keep[1] = (rej(0) + rej(2) + rej(3)) == 0;
     if (n >= 5) {
-        for (int c = 2; c < n - 2; ++c)
-            if (rejected[c]) keep[c] = (rej(c - 2) + rej(c - 1) + rej(c + 1) + rej(c + 2)) <= 1;
         if (rejected[n - 2]) keep[n - 2] = (rej(n - 4) + rej(n - 3) + rej(n - 1)) == 0;
         if (rejected[n - 1]) keep[n - 1] = (rej(n - 3) + rej(n - 2)) == 0;
     }

@@ -108,6 +108,28 @@ def test_similarity_side_cleaning(lib, name, make):
             assert np.array_equal(keep.astype(bool), oracle.clean_strict(g, mw, ogc, osc, variable))
 
 
+@pytest.mark.parametrize("n,seed", [(2047, 1), (2048, 2), (5000, 3), (10000, 4), (20011, 5)])
+def test_strict_cleaning_on_long_vectors(lib, n, seed):
+    """Synthetic statistic vectors at the lengths where the product's similarity cut selects by histogram instead
+    of nth_element (pool >= 2048), with ties, zeros and runs shorter than the minimum block."""
+    r = np.random.default_rng(seed)
+    m = 400
+    g = np.minimum(r.integers(0, m, n) * (r.random(n) < 0.6), m).astype(np.int32)
+    hist = np.bincount(g, minlength=m + 1).astype(np.int32)
+    mw = np.round(r.random(n) ** 2, 3).astype(np.float32)  # many equal values
+    mw[r.random(n) < 0.05] = 0.0
+    mx = int(g.max())
+    for variable in (0, 1):
+        keep = np.zeros(n, dtype=np.uint8)
+        gc, sc = ctypes.c_int32(0), ctypes.c_float(0)
+        assert lib.msa_clean_strict(p(g), p(g), p(mw), m, n, variable, p(keep), ctypes.byref(gc), ctypes.byref(sc)) == 0
+        ogc = oracle.cutpoint_2nd_slope(hist, m, n, mx)
+        osc = oracle.comb_simcut(g, mw, ogc)
+        assert gc.value == ogc
+        assert np.float32(sc.value).view(np.uint32) == osc.view(np.uint32)
+        assert np.array_equal(keep.astype(bool), oracle.clean_strict(g, mw, ogc, osc, variable))
+
+
 def test_window_too_big(lib):
     v = np.zeros(5, dtype=np.int32)
     out = np.zeros(5, dtype=np.int32)
