@@ -226,125 +226,8 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// identity_stats: the per-row max / mean of Cleaner::selectMethod, then the two means over
-// rows, every sum in the reference's order (ascending index, float32).  Lane = row i; the
-// symmetric matrix is read column-wise so that loads coalesce.
-// ------------------------------------------------------------------------------------------
-// The sums are short sequential float32 chains (m adds per row); what costs time is feeding
-// them.  Eight waves stage [128 rows j][64 columns i] tiles of the symmetric matrix through LDS,
-// each with its 16 loads of a tile in flight at once (the kernel is bound by memory latency: only
-// m/64 workgroups exist), wave 0 walks each tile in ascending j.
-constexpr int IDS_TJ = 128;
-constexpr int IDS_WAVES = 8;
-
-__global__ __launch_bounds__(64 * IDS_WAVES) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
-                                                                       float *__restrict__ row_avg,
-                                                                       float *__restrict__ row_max,
-                                                                       float *__restrict__ row_min) {
-    __shared__ float tile[2][IDS_TJ][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * 64;
-    const int i = i0 + lane;           // < ldw (ldw % 64 == 0; padding columns are zero)
-    const int ntiles = (m + IDS_TJ - 1) / IDS_TJ;
-    auto load_tile = [&](int t, int buf) {
-        const int jb = t * IDS_TJ;
-        float v[IDS_TJ / IDS_WAVES];
-#pragma unroll
-        for (int u = 0; u < IDS_TJ / IDS_WAVES; ++u) {
-            const int j = jb + wave + u * IDS_WAVES;
-            v[u] = (j < m) ? ident[(size_t)j * ldw + i] : 0.0f;  // ident[j][i] == ident[i][j]
-        }
-#pragma unroll
-        for (int u = 0; u < IDS_TJ / IDS_WAVES; ++u) tile[buf][wave + u * IDS_WAVES][lane] = v[u];
-    };
-    float mx = 0.0f, avg = 0.0f, mn = 1.0f;  // (getCutPointClusters starts its minimum at 1)
-    load_tile(0, 0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) load_tile(t + 1, (t + 1) & 1);
-        if (wave == 0) {
-            const int jb = t * IDS_TJ;
-            const int cnt = min(IDS_TJ, m - jb);
-            if (cnt == IDS_TJ && (jb + IDS_TJ <= i0 || jb >= i0 + 64)) {
-                // a full tile away from this block's diagonal: 16 LDS reads in flight per batch (one read per
-                // iteration exposes the LDS latency 2000 times: 150 us at m = 2000)
-#pragma unroll 1
-                for (int r0 = 0; r0 < IDS_TJ; r0 += 16) {
-                    float v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = tile[t & 1][r0 + u][lane];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        mx = mx < v[u] ? v[u] : mx;
-                        mn = mn > v[u] ? v[u] : mn;
-                        avg += v[u];
-                    }
-                }
-            } else {
-                for (int r = 0; r < cnt; ++r) {
-                    const float v = tile[t & 1][r][lane];
-                    if (jb + r != i) {
-                        mx = mx < v ? v : mx;
-                        mn = mn > v ? v : mn;
-                        avg += v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (wave == 0 && i < m) {
-        row_avg[i] = avg / (float)(m - 1);
-        row_max[i] = mx;
-        if (row_min) row_min[i] = mn;
-    }
-}
-
-__global__ __launch_bounds__(256) void identity_final_kernel(const float *__restrict__ row_avg,
-                                                             const float *__restrict__ row_max, int m,
-                                                             float *__restrict__ out2) {
-    extern __shared__ float stage[];  // [2][m]
-    for (int t = threadIdx.x; t < m; t += 256) {
-        stage[t] = row_avg[t];
-        stage[m + t] = row_max[t];
-    }
-    __syncthreads();
-    if (threadIdx.x) return;
-    float a = 0.0f, x = 0.0f;
-    int i = 0;
-    for (; i + 16 <= m; i += 16) {  // 32 LDS reads in flight, then the two sequential sums
-        float va[16], vx[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            va[u] = stage[i + u];
-            vx[u] = stage[m + i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            a += va[u];
-            x += vx[u];
-        }
-    }
-    for (; i < m; ++i) {
-        a += stage[i];
-        x += stage[m + i];
-    }
-    out2[0] = a / (float)m;
-    out2[1] = x / (float)m;
-}
-
-__global__ void identity_final_big_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max, int m,
-                                          float *__restrict__ out2) {
-    if (threadIdx.x || blockIdx.x) return;
-    float a = 0.0f, x = 0.0f;
-    for (int i = 0; i < m; ++i) {
-        a += row_avg[i];
-        x += row_max[i];
-    }
-    out2[0] = a / (float)m;
-    out2[1] = x / (float)m;
-}
+// (the identity row statistics -- selectMethod's sequential float32 sums -- live in msastat_simx.hip: they are
+// evaluated with the same binade-exact block test as the ordered rows of the similarity kernel)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -2129,16 +2012,6 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
         else PAIR_LAUNCH(8, 1);
     }
 #undef PAIR_LAUNCH
-}
-
-void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
-                           float *out2, float *row_min) {
-    identity_rows_kernel<<<(m + 63) / 64, 64 * IDS_WAVES, 0, s>>>(ident, m, ldw, row_avg, row_max, row_min);
-    if ((size_t)m * 8 <= 64 * 1024) {
-        identity_final_kernel<<<1, 256, (size_t)m * 8, s>>>(row_avg, row_max, m, out2);
-    } else {
-        identity_final_big_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
-    }
 }
 
 void launch_sim_encode8(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, int npos,

@@ -1418,6 +1418,69 @@ __global__ __launch_bounds__(256) void lg2_union_kernel(const uint8_t *__restric
     if (lane == 0) nunion[pi] = count;
 }
 
+// ---- identity row statistics (Cleaner::calculateSeqIdentity's consumers: selectMethod, getCutPointClusters) --------
+// Per sequence: the float32 sum of its identities with every other sequence IN INDEX ORDER (/ (m - 1)), their
+// maximum and minimum; then the sums of the row averages and of the row maxima in index order (/ m).  The terms are
+// >= 0, so the sequential sums are evaluated a chunk of 256 terms at a time with the binade test of the similarity
+// kernel's ordered rows (chunk_step): one wave per sequence instead of one dependent add chain per lane (83 + 24 us
+// -> a few us at m = 2000), bit-identical.
+__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+                                                            float *__restrict__ row_avg, float *__restrict__ row_max,
+                                                            float *__restrict__ row_min) {
+    const int lane = threadIdx.x & 63;
+    const int i = uni((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (i >= m) return;
+    const float *r = ident + (size_t)i * ldw;  // ident[i][j] == ident[j][i]
+    float s = 0.0f, mx = 0.0f, mn = 1.0f;      // (getCutPointClusters starts its minimum at 1)
+    for (int base = 0; base < m; base += 256) {
+        float x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = base + 64 * c + lane;
+            const bool in = t < m && t != i;
+            const float v = in ? r[t] : 0.0f;
+            x[c] = v;
+            if (in) {
+                mx = mx < v ? v : mx;
+                mn = mn > v ? v : mn;
+            }
+        }
+        s = chunk_step(s, x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_xor(mx, off, 64), b = __shfl_xor(mn, off, 64);
+        mx = mx < a ? a : mx;
+        mn = mn > b ? b : mn;
+    }
+    if (lane == 0) {
+        row_avg[i] = s / (float)(m - 1);
+        row_max[i] = mx;
+        if (row_min) row_min[i] = mn;
+    }
+}
+
+__global__ __launch_bounds__(64) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                            int m, float *__restrict__ out2) {
+    const int lane = threadIdx.x;
+    float a = 0.0f, b = 0.0f;
+    for (int base = 0; base < m; base += 256) {
+        float xa[4], xb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = base + 64 * c + lane;
+            xa[c] = t < m ? row_avg[t] : 0.0f;
+            xb[c] = t < m ? row_max[t] : 0.0f;
+        }
+        a = chunk_step(a, xa);
+        b = chunk_step(b, xb);
+    }
+    if (lane == 0) {
+        out2[0] = a / (float)m;
+        out2[1] = b / (float)m;
+    }
+}
+
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
 // row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
@@ -1610,6 +1673,12 @@ int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *v
         similarity_lg2_kernel<false><<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, npairs, uoff, utt, uee,
                                                                       nunion, nr, wlow, wbytes, wup, ldw, r0, t, num_out, den_out);
     return 0;
+}
+
+void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max, float *out2,
+                           float *row_min) {
+    identity_rows_kernel<<<(m + 3) / 4, 256, 0, s>>>(ident, m, ldw, row_avg, row_max, row_min);
+    identity_final_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
 }
 
 extern "C" int msa_debug_bx_stamps(unsigned long long *out16, int reset) {
