@@ -164,9 +164,7 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
     if (uni((int)cj) == (int)BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
-    // Chunks of four blocks: one latency of the W gather and of the table gather per 256 terms (the LDS is busy with
-    // the round loops of the other waves), list entries a chunk ahead.  Entries behind the lists' padding are
-    // clamped onto its last entry.
+    // Chunks of four blocks (256 terms).  Entries behind the lists' padding are clamped onto its last entry.
     auto entries = [&](int t, uint32_t(&k)[4], uint32_t(&c)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -191,14 +189,21 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
             }
         }
     };
+    // software pipeline: list entries two chunks ahead, W values and table entries one chunk ahead -- the vector-memory
+    // pipeline is saturated by the round loops of the other waves (a load waits ~3000 cycles in its queue), so no
+    // load may sit on this dependent path
     uint32_t k[4], c[4];
+    float w[4];
+    f2 de[4];
     int tb = tfirst;
     entries(tb, k, c);
+    values(k, c, w, de);
+    entries(tb + 256, k, c);
     for (; tb < cv.nvalid; tb += 256) {
-        float w[4];
-        f2 de[4];
-        values(k, c, w, de);          // four W gathers and four table gathers in flight together
-        entries(tb + 256, k, c);      // the next chunk's entries meanwhile
+        float wn[4];
+        f2 den[4];
+        values(k, c, wn, den);
+        entries(tb + 512, k, c);
         if (which & 1) {
             const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
             s0 = chunk_step(s0, x);
@@ -206,6 +211,11 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
         if (which & 2) {
             const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
             s1 = chunk_step(s1, x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w[i] = wn[i];
+            de[i] = den[i];
         }
     }
     return f2{s0, s1};
@@ -927,6 +937,7 @@ __device__ __forceinline__ void similarity_lg_body(
         t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
+    __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
     // the column's residue frequencies -> G
     for (int t = lane; t < nv; t += 64) atomicAdd(&hist[wave][cv.code[t] >> 3], 1u);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -967,6 +978,7 @@ __device__ __forceinline__ void similarity_lg_body(
         t_pro = t1 - t0c;
         t0c = t1;
     }
+    __builtin_amdgcn_s_setprio(0);
     int j0 = jstart & ~63;
     int first = jstart - j0;  // the round's lanes before it were evaluated above
     int tbase;                // valid rows before j0
@@ -1024,6 +1036,9 @@ __device__ __forceinline__ void similarity_lg_body(
             t0c = t1;
             ++n_rounds;
         }
+        // The stitching is a latency-bound instruction stream that competes for issue slots with the round loops of
+        // the SIMD's other waves (which are bound by the W stream, not by issue): it runs at the highest wave priority.
+        __builtin_amdgcn_s_setprio(3);
         // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
         const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
         const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
@@ -1034,6 +1049,7 @@ __device__ __forceinline__ void similarity_lg_body(
         sn = sn1;
         sd = sd1;
         tbase += __builtin_popcountll(vall);
+        __builtin_amdgcn_s_setprio(0);
         if (STAMP) {
             const unsigned long long t1 = __builtin_readcyclecounter();
             t_res += t1 - t0c;
