@@ -1216,6 +1216,8 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     }
 
     if (!seq_mode) {
+        // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
+        if ((rc = stage_row_totals(c))) return rc;
         if (method == MSA_METHOD_AUTOMATED1) {
             // one pair pass produces both float matrices when strict is likely to follow
             rc = run_pairs(c, true, true, false);
@@ -1239,7 +1241,6 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             trace.mark("gaps");
             info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
             trace.mark("gap cut");
-            if ((rc = stage_row_totals(c))) return rc;  // (rides on the similarity fetch's wait)
             if ((rc = need_sim())) return rc;
             trace.mark("similarity");
             info->sim_cut = msah::comb_similarity_cut(gaps_w.data(), mdk_w.data(), n, info->gap_cut);
