@@ -189,21 +189,17 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
             }
         }
     };
-    // software pipeline: list entries two chunks ahead, W values and table entries one chunk ahead -- the vector-memory
-    // pipeline is saturated by the round loops of the other waves (a load waits ~3000 cycles in its queue), so no
-    // load may sit on this dependent path
+    // (list entries a chunk ahead; the W gather and the table gather of a chunk are issued together.  A deeper
+    // pipeline -- values a chunk ahead as well -- measured no faster: what an ordered row waits for is its turn to
+    // issue, which is why the callers raise the wave priority, and it costs 32 registers)
     uint32_t k[4], c[4];
-    float w[4];
-    f2 de[4];
     int tb = tfirst;
     entries(tb, k, c);
-    values(k, c, w, de);
-    entries(tb + 256, k, c);
     for (; tb < cv.nvalid; tb += 256) {
-        float wn[4];
-        f2 den[4];
-        values(k, c, wn, den);
-        entries(tb + 512, k, c);
+        float w[4];
+        f2 de[4];
+        values(k, c, w, de);
+        entries(tb + 256, k, c);
         if (which & 1) {
             const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
             s0 = chunk_step(s0, x);
@@ -211,11 +207,6 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
         if (which & 2) {
             const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
             s1 = chunk_step(s1, x);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            w[i] = wn[i];
-            de[i] = den[i];
         }
     }
     return f2{s0, s1};
