@@ -444,6 +444,31 @@ def test_similarity_zero_and_late_sums(ctx_with, kernel, shape):
     _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), _conserved_case(m, n, 700 + m))
 
 
+@pytest.mark.parametrize("kernel", ["lg", "q2", "bx"])
+@pytest.mark.parametrize("letters", ["ACGT", "ABCDEFGHIKLMNOPQRSTUVWYZ", "ABCDEFGHIJKLMNOPQRSTUVWYZ"])
+def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
+    """Custom matrices over 4, 24 and 25 letters (indetermination X): the per-wave LDS tables hold alphabet + 1 rows;
+    two columns per wave serve up to 22 letters and hand larger alphabets to the one-column kernel."""
+    r = np.random.default_rng(len(letters))
+    npos = len(letters)
+    sim = r.integers(-4, 9, (npos, npos)).astype(np.float32)
+    sim = (sim + sim.T) / 2
+    matrix = oracle.make_matrix(sim, letters)
+    alpha = np.frombuffer(letters.encode(), dtype=np.uint8)
+    a = alpha[r.integers(0, npos, (190, 150))].copy()
+    a[r.random(a.shape) < 0.2] = ord("-")
+    a[r.random(a.shape) < 0.02] = ord("X")
+    a = np.ascontiguousarray(a)
+    ctx = ctx_with(MSA_SIM_KERNEL=kernel)
+    ctx.upload(a, ord("X"))
+    og, _, _, _ = oracle.gaps(a)
+    ohit, odst = oracle.pair_counts(a, ord("X"))
+    omdk, oq = oracle.similarity(a, oracle.weights(ohit, odst), og, *matrix, ord("X"))
+    mdk, q = ctx.similarity(*matrix)
+    assert np.array_equal(bits(q), bits(oq))
+    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
+
+
 def _random_case(seed):
     """Small random alignments with extreme compositions: very gappy / fully gapped rows and columns,
     identical rows, indeterminations, lower case."""
