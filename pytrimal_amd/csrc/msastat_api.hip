@@ -73,12 +73,17 @@ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 }  // namespace
 
+struct SimOrder {  // the similarity kernel's column list: entries (padded), waves per workgroup of the two-column variant
+    int npad = 0, pair_waves = 0;
+};
+
 struct msa_ctx {
     int device = 0;
     int cus = 256;  // compute units of the device
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // the similarity denominators run beside the numerator kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_gaps = nullptr;  // behind the staged copy of the gap counts: waiting for it does not wait for later work
     char hip_err[256] = {0};
 
     // alignment
@@ -108,6 +113,8 @@ struct msa_ctx {
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
     PinBuf<int32_t> h_simcols;
     std::vector<int32_t> sort_order, sort_bins;  // scratch of the column ordering
+    SimOrder order;                 // the column list in h_simcols when order_ready (built ahead of similarity() by msa_trim)
+    bool order_ready = false, order_pairs2 = false;
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
@@ -117,7 +124,7 @@ struct msa_ctx {
     DevBuf<uint8_t> lut;
     DevBuf<float> tab;
     DevBuf<int32_t> gaps_w;
-    DevBuf<float> q, mdk, simnum, simden;
+    DevBuf<float> mdk, simnum, simden;  // mdk: MDK [n] followed by Q [n]
     DevBuf<unsigned long long> errkey;
     DevBuf<int> errflag;
     DevBuf<int> pairflag;          // set by the pair pass when some pair has dst = 0 (undefined identity)
@@ -237,6 +244,7 @@ void invalidate(msa_ctx *c) {
     c->h_gaps.clear();
     c->gaps_staged = 0;
     c->rowtot_staged = 0;
+    c->order_ready = false;
     c->planes_pending = false;
     c->h_indets.clear();
 }
@@ -294,8 +302,13 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
             HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost,
                                      c->stream));
             c->gaps_staged = 1;
+            SYNC(c);
         }
-        if (c->gaps_staged == 1) SYNC(c);  // (2: a synchronisation has already covered the copies)
+        if (c->gaps_staged == 1) {  // (2: a synchronisation has already covered the copies)
+            // staged earlier: wait for the copies alone, not for what was enqueued behind them
+            if (c->ev_gaps) HIPCHK(c, hipEventSynchronize(c->ev_gaps));
+            else SYNC(c);
+        }
         c->h_gaps.assign(c->h_gapstage.p, c->h_gapstage.p + c->n);
         c->h_indets.assign(c->h_gapstage.p + c->n, c->h_gapstage.p + 2 * c->n);
         c->gaps_staged = 0;
@@ -311,6 +324,8 @@ int stage_gaps(msa_ctx *c) {
     HIPCHK(c, c->h_gapstage.reserve((size_t)2 * c->n));
     HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (!c->ev_gaps) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gaps, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_gaps, c->stream));
     c->gaps_staged = 1;
     return MSA_OK;
 }
@@ -402,8 +417,8 @@ int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_de
     HIPCHK(c, c->h_u64.reserve(1));
     HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32, (size_t)2 * n + 64)));
     HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_f32.p + n, c->q.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    // (MDK and Q are the two halves of one buffer: one copy)
+    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
     SYNC(c);
     const unsigned long long key = c->h_u64.p[0];
     if (key != ~0ull) {
@@ -416,6 +431,68 @@ int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_de
     }
     std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
     if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
+    return MSA_OK;
+}
+
+// The columns the binade-exact kernels evaluate (not zeroed by the ">= 80 % gaps" rule), the ones with the most valid
+// rows first (their waves run longest), into the pinned staging list.  Host work only: msa_trim calls it while the pair
+// pass runs, similarity() otherwise.
+int build_sim_order(msa_ctx *c, const int32_t *gaps_windowed, bool pairs2, SimOrder *out) {
+    const int m = c->m, n = c->n;
+    // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first (their
+    // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
+    // goes with the lightest, the second with the second to last, ...
+    const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
+    const int q = c->tuning.sim_kernel == 3 ? msak::bx_cols_per_wave() : 1;
+    HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 64 * (size_t)std::max(1, c->cus) + 64));
+    // (counting sort by the number of rows that take no part, stable, in ordinary memory: the pinned staging
+    // buffer is only written once, front to back)
+    int32_t *list = c->h_simcols.p;
+    std::vector<int32_t> &order = c->sort_order, &bins = c->sort_bins;
+    order.resize((size_t)n + 1);
+    bins.assign((size_t)m + 2, 0);
+    int nact = 0;
+    for (int j = 0; j < n; ++j)
+        if (!(((float)gw_host[j] / (float)m) >= 0.8f)) ++bins[std::min(c->h_gaps[j] + c->h_indets[j], m) + 1];
+    for (int g = 0; g <= m; ++g) bins[g + 1] += bins[g];
+    for (int j = 0; j < n; ++j)
+        if (!(((float)gw_host[j] / (float)m) >= 0.8f)) {
+            order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
+            ++nact;
+        }
+    int npad = 0;
+    if (q == 2) {
+        for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
+            list[npad++] = order[i];
+            list[npad++] = i < k ? order[k] : n;  // (an odd count leaves the middle column alone: column n is all skipped)
+        }
+    } else {
+        for (int i = 0; i < nact; ++i) list[npad++] = order[i];
+        while (npad % (pairs2 ? 2 : q)) list[npad++] = n;  // (column n: all skipped)
+    }
+    int pair_waves = 0;
+    if (pairs2 && npad) {
+        // Two columns per wave, neighbours in the order above.  Every pair is resident from the start (no wave slot
+        // is ever refilled), so the time is set by the CU with the most work: two workgroups per CU, and the pairs
+        // dealt to the workgroups in serpentine order (heaviest with lightest) so that all carry the same load.
+        const int np = npad / 2;
+        int nwg = std::max(1, 2 * c->cus);
+        pair_waves = (np + nwg - 1) / nwg;
+        if (pair_waves > msak::lg2_max_waves()) {
+            pair_waves = msak::lg2_max_waves();
+            nwg = (np + pair_waves - 1) / pair_waves;
+        }
+        order.assign(list, list + npad);
+        npad = 0;
+        for (int g = 0; g < nwg; ++g)
+            for (int w = 0; w < pair_waves; ++w) {
+                const int pi = w * nwg + ((w & 1) ? nwg - 1 - g : g);
+                list[npad++] = pi < np ? order[2 * pi] : n;
+                list[npad++] = pi < np ? order[2 * pi + 1] : n;
+            }
+    }
+    out->npad = npad;
+    out->pair_waves = pair_waves;
     return MSA_OK;
 }
 
@@ -475,8 +552,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
         HIPCHK(c, c->errkey.reserve(1));
         HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
-        HIPCHK(c, c->q.reserve((size_t)n + 64));
-        HIPCHK(c, c->mdk.reserve((size_t)n + 64));
+        HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
         HIPCHK(c, c->simnum.reserve((size_t)n + 64));
         HIPCHK(c, c->simden.reserve((size_t)n + 64));
         {
@@ -486,63 +562,21 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
                                     c->bx_nvalid.p);
         }
         mark("lists enqueued");
-        // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first (their
-        // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
-        // goes with the lightest, the second with the second to last, ...
-        const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
-        const int q = c->tuning.sim_kernel == 3 ? msak::bx_cols_per_wave() : 1;
-        HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 64 * (size_t)std::max(1, c->cus) + 64));
-        // (counting sort by the number of rows that take no part, stable, in ordinary memory: the pinned staging
-        // buffer is only written once, front to back)
-        int32_t *list = c->h_simcols.p;
-        std::vector<int32_t> &order = c->sort_order, &bins = c->sort_bins;
-        order.resize((size_t)n + 1);
-        bins.assign((size_t)m + 2, 0);
-        int nact = 0;
-        for (int j = 0; j < n; ++j)
-            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) ++bins[std::min(c->h_gaps[j] + c->h_indets[j], m) + 1];
-        for (int g = 0; g <= m; ++g) bins[g + 1] += bins[g];
-        for (int j = 0; j < n; ++j)
-            if (!(((float)gw_host[j] / (float)m) >= 0.8f)) {
-                order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
-                ++nact;
-            }
-        int npad = 0;
-        if (q == 2) {
-            for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
-                list[npad++] = order[i];
-                list[npad++] = i < k ? order[k] : n;  // (an odd count leaves the middle column alone: column n is all skipped)
-            }
+        SimOrder ord;
+        if (c->order_ready && c->order_pairs2 == pairs2) {
+            ord = c->order;  // built by msa_trim while the pair pass ran
         } else {
-            for (int i = 0; i < nact; ++i) list[npad++] = order[i];
-            while (npad % (pairs2 ? 2 : q)) list[npad++] = n;  // (column n: all skipped)
+            rc = build_sim_order(c, gaps_windowed, pairs2, &ord);
+            if (rc) return rc;
         }
-        int pair_waves = 0;
-        if (pairs2 && npad) {
-            // Two columns per wave, neighbours in the order above.  Every pair is resident from the start (no wave slot
-            // is ever refilled), so the time is set by the CU with the most work: two workgroups per CU, and the pairs
-            // dealt to the workgroups in serpentine order (heaviest with lightest) so that all carry the same load.
-            const int np = npad / 2;
-            int nwg = std::max(1, 2 * c->cus);
-            pair_waves = (np + nwg - 1) / nwg;
-            if (pair_waves > msak::lg2_max_waves()) {
-                pair_waves = msak::lg2_max_waves();
-                nwg = (np + pair_waves - 1) / pair_waves;
-            }
-            order.assign(list, list + npad);
-            npad = 0;
-            for (int g = 0; g < nwg; ++g)
-                for (int w = 0; w < pair_waves; ++w) {
-                    const int pi = w * nwg + ((w & 1) ? nwg - 1 - g : g);
-                    list[npad++] = pi < np ? order[2 * pi] : n;
-                    list[npad++] = pi < np ? order[2 * pi + 1] : n;
-                }
-        }
+        c->order_ready = false;
+        const int npad = ord.npad, pair_waves = ord.pair_waves;
+        const int32_t *list = c->h_simcols.p;
+        (void)list;
         mark("columns sorted");
         HIPCHK(c, c->simcols.reserve((size_t)npad + 8));
         if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->simnum.p, 0, sizeof(float) * n, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->simden.p, 0, sizeof(float) * n, c->stream));
+        // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
         {
             ProfScope ps(c, "sim");
             int e;
@@ -566,7 +600,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
                                                            c->ldw, c->tab.p, c->simnum.p, c->simden.p);
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
         }
-        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
+        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
         HIPCHK(c, hipGetLastError());
         mark("kernel enqueued");
         rc = fetch_similarity(c, n, mdk_out, q_out, detail);
@@ -579,8 +613,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
     HIPCHK(c, c->errkey.reserve(1));
     HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
-    HIPCHK(c, c->q.reserve((size_t)n + 64));
-    HIPCHK(c, c->mdk.reserve((size_t)n + 64));
+    HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
     if (split) {
         // numerators and denominators are independent sequential sums: two kernels, two streams
         rc = ensure_planes(c);
@@ -616,7 +649,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_num");
         }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->q.p, c->mdk.p);
+        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
     } else {
         {
             ProfScope ps(c, "encode");
@@ -626,7 +659,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipGetLastError());
         ProfScope ps(c, "sim");
         const int e = msak::launch_similarity_pc(c->stream, c->simcodes.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                                 gw_dev, c->q.p, c->mdk.p, tcols);
+                                                 gw_dev, c->mdk.p + n, c->mdk.p, tcols);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     HIPCHK(c, hipGetLastError());
@@ -970,7 +1003,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
     c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->u_off.release(); c->u_tt.release(); c->u_ee.release(); c->u_n.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
-    c->q.release(); c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
+    c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
@@ -978,6 +1011,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
         (void)hipEventDestroy(c->ev_join);
         (void)hipStreamDestroy(c->stream2);
     }
@@ -1107,6 +1141,7 @@ int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t 
     if (!c || !c->raw || !vhash || !dist || !mdk_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    c->order_ready = false;  // (only msa_trim builds the column order ahead, for its own call)
     return similarity(c, vhash, dist, npos, gaps_windowed, mdk_out, q_out, detail);
 }
 
@@ -1139,6 +1174,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     HIPCHK(c, hipSetDevice(c->device));
     TrimTrace trace(c->tuning.trace != 0);
     TuneScope tune(c);
+    c->order_ready = false;
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
@@ -1179,7 +1215,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     };
 
     int method = p->method;
-    bool seq_mode = false;
+    bool seq_mode = false, have_gap_cut = false;
     if (method == MSA_METHOD_NODUPLICATESEQS) {
         rc = remove_duplicates(c, keep_seq);
         if (rc) return rc;
@@ -1219,12 +1255,25 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
         if ((rc = stage_row_totals(c))) return rc;
         if (method == MSA_METHOD_AUTOMATED1) {
-            // one pair pass produces both float matrices when strict is likely to follow
+            // The gap counts first (both methods need them), then one pair pass that produces both float matrices
+            // (strict is likely to follow).  While the pair pass runs, the host does everything that depends on the
+            // gap counts alone: their window, the gap cut, the similarity kernel's column order.
+            rc = stage_gaps(c);
+            if (rc) return rc;
             rc = run_pairs(c, true, true, false);
             if (rc) return rc;
-            rc = stage_gaps(c);  // both methods need the gap counts: they ride on the identity statistics' wait
-            if (rc) return rc;
             trace.mark("pairs enqueued");
+            if ((rc = need_gaps())) return rc;  // (waits for the staged copy only)
+            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            have_gap_cut = true;
+            if (p->vhash && p->dist && (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel >= 3) && m < 32000) {
+                const bool pairs2 = c->tuning.sim_kernel == 5 && msak::lg2_fits(p->npos);
+                rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, pairs2, &c->order);
+                if (rc) return rc;
+                c->order_ready = true;
+                c->order_pairs2 = pairs2;
+            }
+            trace.mark("gap cut + column order");
             rc = identity_stats(c, &info->avg_seq, &info->max_seq);
             if (rc) return rc;
             trace.mark("identity stats");
@@ -1234,12 +1283,12 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         if (method == MSA_METHOD_AUTOMATED2) return MSA_E_NOT_IMPLEMENTED;
         if (method == MSA_METHOD_GAPPYOUT) {
             if ((rc = need_gaps())) return rc;
-            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            if (!have_gap_cut) info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
             msah::clean_gaps(gaps_w.data(), n, info->gap_cut, 0, keep_res);
         } else if (method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS) {
             if ((rc = need_gaps())) return rc;
             trace.mark("gaps");
-            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            if (!have_gap_cut) info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
             trace.mark("gap cut");
             if ((rc = need_sim())) return rc;
             trace.mark("similarity");
