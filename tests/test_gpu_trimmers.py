@@ -295,6 +295,28 @@ def test_clusters_device_search(monkeypatch, clusters):
         _lib.reset_thread_context()
 
 
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.9])
+def test_representatives_device_kernels(monkeypatch, thr):
+    """identity_threshold clustering on the device (forced below its 2000-sequence default as well) at several row
+    counts, masks against the oracle's greedy clustering."""
+    from pytrimal_amd.synth import synth_msa
+
+    from pytrimal_amd import _lib
+
+    monkeypatch.setenv("MSA_DEVICE_CLUSTERS", "1")
+    _lib.reset_thread_context()
+    try:
+        for m, n, seed in ((70, 90, 41), (2100, 60, 42), (4200, 40, 43)):
+            a = synth_msa(m, n, seed)
+            a[7] = a[3]
+            ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+            trimmed = RepresentativeTrimmer(identity_threshold=thr, platform=PLATFORM).trim(ali)
+            assert_matches_oracle(trimmed, a, identity_threshold=thr)
+    finally:
+        monkeypatch.delenv("MSA_DEVICE_CLUSTERS")
+        _lib.reset_thread_context()
+
+
 # --- randomized sweep: every trimmer family on small random alignments, masks against the oracle's trim ---------
 
 
