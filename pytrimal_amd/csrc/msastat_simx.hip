@@ -829,8 +829,12 @@ __device__ __forceinline__ void lg_wait_rows(LgD &D) {
                  : "memory");
 }
 
-template <bool NOLOAD>  // NOLOAD (diagnostics, MSA_LG_DBG=1): the W rows are not reloaded -- what the W stream costs
-__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const __attribute__((address_space(1))) uint32_t *off,
+// W rows by global_load_dword with a 64-bit per-lane address instead of buffer_load_dword (SGPR row offset + per-lane
+// offset, range-checked): tools/ubench_wstream.hip measures 5.3 instead of 8.6 CU-cycles per 256-byte wave-load for
+// the same rows (30 against 18 TB/s chip-wide) -- the buffer path costs the texture addresser more per instruction.
+// One more VALU instruction per step (the address).  BUFFER = true keeps the buffer loads (MSA_LG_DBG & 64).
+template <bool NOLOAD, bool BUFFER>  // NOLOAD (diagnostics, MSA_LG_DBG=1): the W rows are not reloaded -- what the W stream costs
+__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const float *wlow_g, const __attribute__((address_space(1))) uint32_t *off,
                                                const __attribute__((address_space(1))) uint16_t *trow, int tstart, int tend,
                                                uint32_t joff, uint32_t base, f2 &an, f2 &ad) {
     typedef const __attribute__((address_space(4))) uint32_t *c32;
@@ -842,9 +846,15 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
 #pragma unroll
         for (int i = 0; i < 8; ++i) en.c[i] = pc[i];
     };
+    // (every list offset + lane offset lies inside wlow: rows 0 .. m, columns below ldw)
+    const __attribute__((address_space(1))) char *wlane = (const __attribute__((address_space(1))) char *)(uint64_t)wlow_g + joff;
+    auto wrow = [&](uint32_t off) -> float {
+        if (BUFFER) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, off, 0));
+        return *reinterpret_cast<const __attribute__((address_space(1))) float *>(wlane + off);
+    };
     auto bload = [&](float(&w)[16], const LgEntries &en) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
+        for (int i = 0; i < 16; ++i) w[i] = wrow(en.o[i]);
     };
     // 16 steps; every W row is requested 16 steps before its use
     auto consume_reload = [&](float(&w)[16], const LgD &D, const LgEntries &next) {
@@ -852,7 +862,7 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
         for (int i = 0; i < 16; ++i) {
             const float x = w[i] * D.d[i];
             const f2 xn = {x, x}, xd = {w[i], w[i]};
-            if (!NOLOAD) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[i], 0));
+            if (!NOLOAD) w[i] = wrow(next.o[i]);
             an += xn;
             ad += xd;
         }
@@ -1008,10 +1018,13 @@ __device__ __forceinline__ void similarity_lg_body(
             for (int a = 0; a < nr; ++a)
                 lt[a * 64] = (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x;
             const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(ltab + (size_t)wave * nr * 64);
+            // (the diagnostic loop versions exist in the stamped kernel only)
             if (STAMP && (r0_ & 0x10000))
-                round_loop_lds<true>(wrsrc, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+                round_loop_lds<true, false>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+            else if (STAMP && (r0_ & 0x40000))
+                round_loop_lds<false, true>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
             else
-                round_loop_lds<false>(wrsrc, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+                round_loop_lds<false, false>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
         } else {
             const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
             v32f T;  // the lane's table column
@@ -1088,7 +1101,7 @@ __device__ __forceinline__ void similarity_lg_body(
         float *__restrict__ num_out, float *__restrict__ den_out
 #define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, tab_g, num_out, den_out
 template <bool STAMP>
-__global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(6, 6))) void similarity_lg_kernel(LG_PARAMS) {
+__global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
     similarity_lg_body<STAMP, true>(LG_ARGS);
 }
 template <bool STAMP>
@@ -1618,7 +1631,7 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
     // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 1 -> no W loads, stamped kernel only)
-    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16);
+    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16) | ((tuning().lg_dbg & 64) ? 0x40000 : 0);
     const bool ldst = tuning().lg_regs == 0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
     // eight waves per workgroup while their tables stay within the 64 KB M0 can address (static arrays: 10.5 KB)
