@@ -832,9 +832,17 @@ __device__ __forceinline__ void lg_wait_rows(LgD &D) {
 // W rows by global_load_dword with a 64-bit per-lane address instead of buffer_load_dword (SGPR row offset + per-lane
 // offset, range-checked): tools/ubench_wstream.hip measures 5.3 instead of 8.6 CU-cycles per 256-byte wave-load for
 // the same rows (30 against 18 TB/s chip-wide) -- the buffer path costs the texture addresser more per instruction.
-// One more VALU instruction per step (the address).  BUFFER = true keeps the buffer loads (MSA_LG_DBG & 64).
-template <bool NOLOAD, bool BUFFER>  // NOLOAD (diagnostics, MSA_LG_DBG=1): the W rows are not reloaded -- what the W stream costs
-__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const float *wlow_g, const __attribute__((address_space(1))) uint32_t *off,
+// One more VALU instruction per step (the address).
+// MODE 3: (production) global loads with the row address in an SGPR pair and the lane offset in a VGPR (s_add_u32 /
+//         s_addc_u32: two SALU, no VALU); hand-issued, so the loop counts VMCNT itself: 16 loads are in flight at
+//         every step and nothing else of the loop is a vector-memory instruction
+//      0: global loads, 64-bit per-lane address left to the compiler (v_lshl_add_u64: one VALU + one SALU per step;
+//         diagnostics, MSA_LG_DBG & 128: 3.38 instead of 3.13 ms at C3)
+//      1: buffer loads (diagnostics, MSA_LG_DBG & 64: 4.03 ms)
+//      2: no W reloads at all (diagnostics, MSA_LG_DBG & 1: what the W stream costs; results are wrong)
+template <int MODE>
+__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const float *wlow_g,
+                                               const __attribute__((address_space(1))) uint32_t *off,
                                                const __attribute__((address_space(1))) uint16_t *trow, int tstart, int tend,
                                                uint32_t joff, uint32_t base, f2 &an, f2 &ad) {
     typedef const __attribute__((address_space(4))) uint32_t *c32;
@@ -848,21 +856,27 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
     };
     // (every list offset + lane offset lies inside wlow: rows 0 .. m, columns below ldw)
     const __attribute__((address_space(1))) char *wlane = (const __attribute__((address_space(1))) char *)(uint64_t)wlow_g + joff;
-    auto wrow = [&](uint32_t off) -> float {
-        if (BUFFER) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, off, 0));
-        return *reinterpret_cast<const __attribute__((address_space(1))) float *>(wlane + off);
+    const uint64_t wuni = (uint64_t)uniform_ptr((const __attribute__((address_space(1))) char *)(uint64_t)wlow_g);
+    auto wrow = [&](float &dst, uint32_t o) {
+        if (MODE == 1) dst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, o, 0));
+        else if (MODE == 3) {
+            const uint64_t row = wuni + o;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(joff), "s"(row) : "memory");
+        } else dst = *reinterpret_cast<const __attribute__((address_space(1))) float *>(wlane + o);
     };
     auto bload = [&](float(&w)[16], const LgEntries &en) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = wrow(en.o[i]);
+        for (int i = 0; i < 16; ++i) wrow(w[i], en.o[i]);
     };
     // 16 steps; every W row is requested 16 steps before its use
     auto consume_reload = [&](float(&w)[16], const LgD &D, const LgEntries &next) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float x = w[i] * D.d[i];
-            const f2 xn = {x, x}, xd = {w[i], w[i]};
-            if (!NOLOAD) w[i] = wrow(next.o[i]);
+            if (MODE == 3) asm volatile("s_waitcnt vmcnt(15)" : "+v"(w[i])::"memory");  // the oldest of the 16 loads in flight
+            const float wi = w[i];
+            const float x = wi * D.d[i];
+            const f2 xn = {x, x}, xd = {wi, wi};
+            if (MODE != 2) wrow(w[i], next.o[i]);
             an += xn;
             ad += xd;
         }
@@ -888,6 +902,7 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
         consume_reload(w, dB, eA);
     }
     lg_wait_rows(dA);  // (nothing may stay in flight into the caller's LDS traffic)
+    if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 constexpr int LG_WAVES_MAX = 8;  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
@@ -1020,11 +1035,13 @@ __device__ __forceinline__ void similarity_lg_body(
             const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(ltab + (size_t)wave * nr * 64);
             // (the diagnostic loop versions exist in the stamped kernel only)
             if (STAMP && (r0_ & 0x10000))
-                round_loop_lds<true, false>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+                round_loop_lds<2>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
             else if (STAMP && (r0_ & 0x40000))
-                round_loop_lds<false, true>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+                round_loop_lds<1>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+            else if (STAMP && (r0_ & 0x80000))
+                round_loop_lds<0>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
             else
-                round_loop_lds<false, false>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+                round_loop_lds<3>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
         } else {
             const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
             v32f T;  // the lane's table column
@@ -1631,7 +1648,8 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
     const int64_t ldk = bx_ldk(m);
     // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 1 -> no W loads, stamped kernel only)
-    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16) | ((tuning().lg_dbg & 64) ? 0x40000 : 0);
+    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16) | ((tuning().lg_dbg & 64) ? 0x40000 : 0) |
+                   ((tuning().lg_dbg & 128) ? 0x80000 : 0);
     const bool ldst = tuning().lg_regs == 0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
     // eight waves per workgroup while their tables stay within the 64 KB M0 can address (static arrays: 10.5 KB)
