@@ -34,10 +34,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
-# the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane buffer loads of L2-resident rows, measured
-# with tools/ubench_wstream.hip on an MI355X (profiles/r02_ubench_wstream.txt): 18.0 - 18.7 TB/s chip-wide at 4 - 8
-# waves per SIMD, i.e. ~8.5 CU-cycles per wave-load whatever the occupancy
-W_STREAM_PEAK_GBS = 18500.0
+# the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane loads of L2-resident rows, measured with
+# tools/ubench_wstream.hip on an MI355X (profiles/r02_ubench_wstream.txt): global_load_dword 29 - 30 TB/s chip-wide
+# (5.3 CU-cycles per wave-load at the nominal clock; buffer_load_dword with an SGPR row offset: 18.3 TB/s, 8.6 cycles)
+W_STREAM_PEAK_GBS = 29700.0
 
 
 def similarity_w_stream_bytes(a, indet=ord("X")):
@@ -382,7 +382,8 @@ def main():
                 wbytes, wsteps = similarity_w_stream_bytes(a)
                 rate = wbytes / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
                 roofline["w_stream"] = {
-                    "bound": "vector-memory pipeline (L1/TA), 256-byte dword loads of L2-resident W rows",
+                    "bound": "vector-memory pipeline (L1/TA), 256-byte global_load_dword wave-loads of L2-resident W rows "
+                             "(texture addresser 92 % busy at the clock the kernel runs at: profiles/r02_pmc_sq.txt)",
                     "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
                     "peak_source": "tools/ubench_wstream.hip on one MI355X (profiles/r02_ubench_wstream.txt), not measured in this run",
