@@ -32,7 +32,10 @@ __global__ __launch_bounds__(256) void k(const float *w, uint32_t wbytes, int ro
             asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(joff), "s"(sb) : "memory");
             return fv{d};
         } else if constexpr (VEC == 1) return fv{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, joff, so, POL))};
-        else if constexpr (VEC == 2) return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b64(rsrc, joff, so, 0));
+        else if constexpr (POL == 4) {  // global loads of 2 / 4 dwords per lane
+            const char *p = (const char *)w + so;
+            return *(const __attribute__((address_space(1))) fv *)(p + joff);
+        } else if constexpr (VEC == 2) return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b64(rsrc, joff, so, 0));
         else return __builtin_bit_cast(fv, __builtin_amdgcn_raw_buffer_load_b128(rsrc, joff, so, 0));
     };
 #pragma unroll
@@ -99,6 +102,8 @@ int main() {
         run<1, 4>(w, rowsmax * 8192, rows, 6, sink);
         run<1, 5>(w, rowsmax * 8192, rows, 6, sink);
         run<1, 5>(w, rowsmax * 8192, rows, 4, sink);
+        run<2, 4>(w, rowsmax * 8192, rows, 6, sink);
+        run<4, 4>(w, rowsmax * 8192, rows, 6, sink);
     }
     return 0;
 }
