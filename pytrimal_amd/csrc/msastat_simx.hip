@@ -1,8 +1,8 @@
-// msastat_simx.hip -- the binade-exact similarity kernel (statistics::Similarity::calculateVectors,
+// msastat_simx.hip -- the binade-exact similarity kernels (statistics::Similarity::calculateVectors,
 // reference include/trimal/statistics.pxd:55): both sequential float32 sums of every column, evaluated
 // in parallel and still bit-identical to the reference's one-add-after-the-other order.
 //
-// Why a sequential float32 sum can be evaluated out of order (DESIGN.md section 5b has the proof):
+// Why a sequential float32 sum can be evaluated out of order (DESIGN.md section 5.1 has the proof):
 //   s' = fl(s + x) with s in the binade [B, 2B), ulp u = B * 2^-23, and x >= 0 rounds x to the grid u:
 //   s' = s + r_u(x), where r_u(x) depends on s only through the PARITY of s/u, and only when x is an exact
 //   tie ((k + 1/2) u).  All terms of this statistic are >= 0, so s never leaves a binade downwards.  Hence,
@@ -13,23 +13,23 @@
 //   One lane owns one row j of the pair sequence (its terms k > j are contiguous in the reference's order), 64
 //   rows make a round, and a scan over the lanes stitches the rows together: prefix sums (exact), parity picks at
 //   the few tie rows, and the first row whose sum would reach 2B.  That row is evaluated in the reference's
-//   order (blocks of 64 terms with the same test, then term by term); the rows behind it use a second pair of
-//   accumulators kept on the next grid (2B, 2u).  Anything else ends the round early.  Every commit is checked
+//   order (chunks of 256 terms with the same test, then blocks of 64, then term by term).  Every commit is checked
 //   (sum < 2B, grids as assumed), so speculation can only cost time, never exactness.
 //
-// Work mapping: one wave = one column (the columns the ">= 80 % gaps" rule zeroes never get a wave).  Lane = one of
-// 64 CONSECUTIVE rows j of the round; the wave walks the column's VALID rows k behind the round's first row
-// (a compacted list: a row whose residue takes no part costs no step), one step per partner row:
-//   W[k][j]      lower-triangular copy of the weight matrix, one coalesced 256-byte buffer load per step whose
-//                row offset comes straight from the list (SGPR) -- no address arithmetic;
-//   D[a_k][a_j]  from the lane's own copy of its table column (32 VGPRs, refilled per round from LDS) indexed
-//                by the wave-uniform a_k through relative VGPR addressing -- no LDS access in the loop;
-//   one packed multiply {W, W} x {D, e} and two packed adds ({even, odd} of the numerator, of the denominator);
-//   chains that may leave their binade in this round (predicted from the last round's increment) add two more
-//   on the next grid: four instantiations of the loop.
-// No dependent chain is left: the kernel is bound by VALU issue (5.6 VALU instructions per step measured, 4 of
-// them in the loop), not by add latency.  Limits: m < 32000 (16-bit row indices, 32-bit W offsets); above that
-// the chain kernels of msastat_kernels.hip run.
+// What is in this file, in order:
+//   * helpers (scans, exact_row: one row in the reference's order) and `similarity_bx`, the first kernel of the
+//     family: ONE grid per chain and round, a second pair of accumulators for predicted crossings, rounds cut short
+//     for the others, the lane's table column in 32 VGPRs (MSA_SIM_KERNEL=bx; section 5.7 of DESIGN.md);
+//   * `similarity_lg` (the default): every lane on the grid of its own predicted sum, one loop version, the table
+//     column in a per-wave LDS table read by ds_read_addtid_b32, W rows by hand-issued global loads.  Work mapping:
+//     one wave = one column (the columns the ">= 80 % gaps" rule zeroes never get a wave), lane = one of 64
+//     consecutive rows j of the round, one step per VALID partner row k behind the round's first row (compacted
+//     list): 3 VALU + 1 LDS + 1 VMEM instruction per 64 terms.  Bound by the vector L1's bandwidth (the W stream:
+//     texture addresser 92 % busy), not by VALU issue or add latency;
+//   * `similarity_lg2` (MSA_SIM_KERNEL=q2): two columns per wave sharing the W loads -- measured, not faster;
+//   * the identity row statistics (sequential float32 sums through the same chunk test);
+//   * the layout kernels (column-major codes, compacted lists, union lists) and the launchers.
+// Limits: m < 32000 (16-bit row indices, 32-bit W offsets); above that the chain kernels of msastat_kernels.hip run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
