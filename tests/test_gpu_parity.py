@@ -4,6 +4,8 @@ Bit-exact for every integer output (gap counts, hit/dst, masks) and for the floa
 weight matrices and the similarity quotient Q (the reference's sequential accumulation order is
 reproduced); MDK = exp(-Q) is held to the 1e-6 absolute tolerance BASELINE.json states.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -467,6 +469,20 @@ def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
     mdk, q = ctx.similarity(*matrix)
     assert np.array_equal(bits(q), bits(oq))
     assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_similarity_kernels_agree_on_random_shapes(seed):
+    """tools/cross_check.py: per-lane grids (one and two columns per wave) and the one-grid-per-round kernel against
+    the dependent-add chain kernels on random shapes and compositions (conserved, sorted, gap blocks, m = 2 .. 3000):
+    independent implementations of one bit-exact statistic must agree bit for bit."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "cross_check.py"), "60", str(seed)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def _random_case(seed):
