@@ -1857,20 +1857,25 @@ __global__ __launch_bounds__(64) void rows_equal_kernel(const uint8_t *__restric
 // Each round reads a snapshot of the two bit sets and writes the next one (no torn reads).
 // adjacency bits: bit u of row t  <=>  ident[seq_at[t]][seq_at[u]] > thr, only u < t kept.
 // ------------------------------------------------------------------------------------------
+// adjacency words are stored WORD-major (adj[w * m + t]: word w of vertex t), so that the threads of the clustering
+// kernel -- one vertex each, all walking the words in step -- read consecutive addresses.
 __global__ __launch_bounds__(256) void cluster_adjacency_kernel(const float *__restrict__ ident, int ldw,
                                                                 const int32_t *__restrict__ seq_at, int m, float thr,
                                                                 uint32_t *__restrict__ adj, int words) {
-    const int t = blockIdx.y;                              // processing index of the row vertex
-    const int w = blockIdx.x * 256 + threadIdx.x;          // word of earlier vertices
-    if (w >= words) return;
-    const float *row = ident + (size_t)seq_at[t] * ldw;
+    const int t = blockIdx.x * 256 + threadIdx.x;  // processing index of the row vertex
+    const int w = blockIdx.y;                      // word of earlier vertices
+    if (t >= m) return;
     uint32_t bits = 0;
+    if (w * 32 < t) {  // (only earlier vertices u < t are kept)
+        const int col = seq_at[t];
 #pragma unroll 4
-    for (int b = 0; b < 32; ++b) {
-        const int u = w * 32 + b;
-        if (u < t) bits |= (row[seq_at[u]] > thr ? 1u : 0u) << b;
+        for (int b = 0; b < 32; ++b) {
+            const int u = w * 32 + b;
+            // ident is symmetric: row seq_at[u] is shared by the 256 threads of the block
+            if (u < t) bits |= (ident[(size_t)seq_at[u] * ldw + col] > thr ? 1u : 0u) << b;
+        }
     }
-    adj[(size_t)t * words + w] = bits;
+    adj[(size_t)w * m + t] = bits;
 }
 
 __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__restrict__ adj, int m, int words,
@@ -1900,10 +1905,9 @@ __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__res
         int mine = 0;
         for (int t = threadIdx.x; t < m; t += 1024) {
             if (!((uc[t >> 5] >> (t & 31)) & 1u)) continue;
-            const uint32_t *row = adj + (size_t)t * words;
             int verdict = 1;  // 1 = REP, 0 = NON-REP, -1 = blocked by an undecided earlier neighbour
             for (int w = 0; w <= (t >> 5); ++w) {
-                const uint32_t a = row[w];
+                const uint32_t a = adj[(size_t)w * m + t];
                 if (!a) continue;
                 if (a & rc[w]) { verdict = 0; break; }
                 if (a & uc[w]) verdict = -1;
@@ -2158,7 +2162,7 @@ int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *se
     const int words = (int)cluster_adj_words(m);
     const size_t lds = (size_t)4 * words * sizeof(uint32_t);
     if (lds > 60 * 1024) return -1;  // caller falls back to the host path
-    dim3 grid((words + 255) / 256, m);
+    dim3 grid((m + 255) / 256, words);
     cluster_adjacency_kernel<<<grid, 256, 0, s>>>(ident, ldw, seq_at, m, thr, adj, words);
     cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, m, words, seq_at, keep_seq, count);
     return 0;
