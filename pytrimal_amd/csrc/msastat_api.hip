@@ -83,6 +83,8 @@ struct msa_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // the similarity denominators run beside the numerator kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_digest = nullptr;  // behind the copies of row_digest_begin
+    PinBuf<int32_t> h_len;           // ungapped lengths on their way to the host
     hipEvent_t ev_gaps = nullptr;  // behind the staged copy of the gap counts: waiting for it does not wait for later work
     char hip_err[256] = {0};
 
@@ -707,21 +709,23 @@ int stage_row_totals(msa_ctx *c) {
 
 int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     const int m = c->m, n = c->n;
-    if (c->rowtot_staged == 2 && (int)c->h_gaps.size() == n) {
-        // A kept sequence with more residues than there are removed columns keeps at least one of them: when that
-        // holds for every kept sequence, none is left with gaps only, and (all sequences kept) a column is all-gap
-        // exactly when its gap count is m -- no pass over the alignment, no synchronisation.
+    // A kept sequence with more residues than there are removed columns keeps at least one of them: when that holds
+    // for every kept sequence (residues per sequence staged by stage_row_totals), none is left with gaps only and the
+    // pass over the rows is not needed.
+    bool rows_safe = false, every_row_kept = true;
+    if (c->rowtot_staged == 2) {
         const int removed = n - (int)std::count(keep_res, keep_res + n, 1);
-        bool safe = true, all_rows = true;
-        for (int i = 0; i < m && safe; ++i) {
-            if (keep_seq[i]) safe = c->h_rowtot.p[i] > removed;
-            else all_rows = false;
+        rows_safe = true;
+        for (int i = 0; i < m; ++i) {
+            if (keep_seq[i]) rows_safe = rows_safe && c->h_rowtot.p[i] > removed;
+            else every_row_kept = false;
         }
-        if (safe && all_rows) {
-            for (int j = 0; j < n; ++j)
-                if (keep_res[j] && c->h_gaps[j] == m) keep_res[j] = 0;
-            return MSA_OK;
-        }
+    }
+    if (rows_safe && every_row_kept && (int)c->h_gaps.size() == n) {
+        // all sequences kept: a column is all-gap exactly when its gap count is m -- no pass over the alignment at all
+        for (int j = 0; j < n; ++j)
+            if (keep_res[j] && c->h_gaps[j] == m) keep_res[j] = 0;
+        return MSA_OK;
     }
     HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
@@ -729,12 +733,16 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_i
     HIPCHK(c, c->col_cnt.reserve((size_t)n + 64));
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, n)));
     HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
-    std::memcpy(c->h_u8.p, keep_res, n);
-    HIPCHK(c, hipMemcpyAsync(c->keep_res_d.p, c->h_u8.p, n, hipMemcpyHostToDevice, c->stream));
-    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
-    SYNC(c);
+    if (rows_safe) {
+        for (int i = 0; i < m; ++i) c->h_i32.p[i] = 1;  // (no sequence can be empty: skip the pass over the rows)
+    } else {
+        std::memcpy(c->h_u8.p, keep_res, n);
+        HIPCHK(c, hipMemcpyAsync(c->keep_res_d.p, c->h_u8.p, n, hipMemcpyHostToDevice, c->stream));
+        msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+        SYNC(c);
+    }
     bool all_rows = true;
     for (int i = 0; i < m; ++i) {
         if (keep_seq[i] && c->h_i32.p[i] == 0) {
@@ -764,21 +772,33 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_i
     return MSA_OK;
 }
 
-int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned long long> *hashes) {
+// ungapped lengths and row hashes: enqueued without waiting (row_digest_begin), fetched behind their own event
+// (row_digest_end) so that work enqueued in between -- the pair pass -- does not sit in front of the host
+int row_digest_begin(msa_ctx *c) {
     const int m = c->m;
     HIPCHK(c, c->lengths.reserve((size_t)m + 64));
     HIPCHK(c, c->hashes.reserve((size_t)2 * m + 64));
     msak::launch_row_digest(c->stream, c->raw, m, c->n, c->ld, c->lengths.p, c->hashes.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    HIPCHK(c, c->h_len.reserve((size_t)m + 4));
     HIPCHK(c, c->h_u64.reserve((size_t)2 * m + 1));
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->lengths.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_len.p, c->lengths.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->hashes.p, sizeof(unsigned long long) * 2 * m, hipMemcpyDeviceToHost,
                              c->stream));
-    SYNC(c);
-    lengths.assign(c->h_i32.p, c->h_i32.p + m);
+    if (!c->ev_digest) HIPCHK(c, hipEventCreateWithFlags(&c->ev_digest, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_digest, c->stream));
+    return MSA_OK;
+}
+int row_digest_end(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned long long> *hashes) {
+    const int m = c->m;
+    HIPCHK(c, hipEventSynchronize(c->ev_digest));
+    lengths.assign(c->h_len.p, c->h_len.p + m);
     if (hashes) hashes->assign(c->h_u64.p, c->h_u64.p + 2 * m);
     return MSA_OK;
+}
+int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned long long> *hashes) {
+    const int rc = row_digest_begin(c);
+    return rc ? rc : row_digest_end(c, lengths, hashes);
 }
 
 // Cleaner::removeDuplicates (as patched by the reference): the earlier of two identical rows goes.
@@ -828,10 +848,13 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
 int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     const int m = c->m;
     if (m < 2) return MSA_E_FALLBACK;
-    int rc = run_pairs(c, true, false, false);
+    // the ungapped lengths first, then the pair pass: the processing order is sorted on the host while it runs
+    int rc = row_digest_begin(c);
+    if (rc) return rc;
+    rc = run_pairs(c, true, false, false);
     if (rc) return rc;
     std::vector<int32_t> lengths;
-    rc = row_digest(c, lengths, nullptr);
+    rc = row_digest_end(c, lengths, nullptr);
     if (rc) return rc;
     const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
     const size_t words = msak::cluster_adj_words(m);
@@ -1007,11 +1030,12 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
-    c->h_planeflag.release(); c->h_gapstage.release(); c->h_rowtot.release();
+    c->h_planeflag.release(); c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release();
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);
         if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
+        if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
         (void)hipEventDestroy(c->ev_join);
         (void)hipStreamDestroy(c->stream2);
     }
@@ -1214,6 +1238,8 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         return msah::window_f32(mdk.data(), n, sim_hw, mdk_w.data());
     };
 
+    // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
+    if ((rc = stage_row_totals(c))) return rc;
     int method = p->method;
     bool seq_mode = false, have_gap_cut = false;
     if (method == MSA_METHOD_NODUPLICATESEQS) {
@@ -1252,8 +1278,6 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     }
 
     if (!seq_mode) {
-        // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
-        if ((rc = stage_row_totals(c))) return rc;
         if (method == MSA_METHOD_AUTOMATED1) {
             // The gap counts first (both methods need them), then one pair pass that produces both float matrices
             // (strict is likely to follow).  While the pair pass runs, the host does everything that depends on the
