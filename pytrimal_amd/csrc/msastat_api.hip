@@ -27,11 +27,13 @@ template <typename T>
 struct DevBuf {  // grow-only device allocation, reused across uploads
     T *p = nullptr;
     size_t cap = 0;
+    uint64_t tag = 0;  // caller's note about the contents (e.g. "padding zeroed for this shape"); a reallocation clears it
     hipError_t reserve(size_t count) {
         if (count <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        tag = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
         if (e == hipSuccess) cap = count;
         return e;
@@ -41,6 +43,11 @@ struct DevBuf {  // grow-only device allocation, reused across uploads
         p = nullptr;
         cap = 0;
     }
+};
+
+template <typename T>
+struct DevView {  // a window of another device allocation (the state block, the table block)
+    T *p = nullptr;
 };
 
 template <typename T>
@@ -84,6 +91,7 @@ struct msa_ctx {
     hipStream_t stream2 = nullptr;  // the similarity denominators run beside the numerator kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_digest = nullptr;  // behind the copies of row_digest_begin
+    hipEvent_t ev_rowtot = nullptr;  // behind the copy of stage_row_totals
     PinBuf<int32_t> h_len;           // ungapped lengths on their way to the host
     hipEvent_t ev_gaps = nullptr;  // behind the staged copy of the gap counts: waiting for it does not wait for later work
     char hip_err[256] = {0};
@@ -99,7 +107,15 @@ struct msa_ctx {
     int nchunk = 0, m_pad = 0, ldw = 0;
     DevBuf<uint32_t> planes;
     bool have_planes = false;
-    DevBuf<int32_t> gaps, indets;
+    // The small per-alignment state lives in ONE allocation so that one memset prepares it and one copy fetches its
+    // flags: 16 words of flags (ST_*), then the gap counts and the indetermination counts (state_npad words each).
+    DevBuf<int32_t> state;
+    int state_npad = 0;
+    bool state_zeroed = false;   // for the current alignment
+    bool errkey_dirty = false;   // an encode kernel may have written the first-bad-residue key since the state was zeroed
+    bool flags_dirty = false;    // a kernel that may raise a flag was enqueued since the flags were last fetched
+    PinBuf<int32_t> h_flags;     // the 16 flag words on the host (valid after the synchronisation that follows a fetch)
+    DevView<int32_t> gaps, indets;
     bool have_gaps = false;
     DevBuf<float> ident, wmat;
     DevBuf<float> wlow;        // strictly lower triangular mirror of wmat (binade-exact similarity kernel)
@@ -120,17 +136,21 @@ struct msa_ctx {
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
-    DevBuf<float> row_avg, row_max, row_min, stats2;
+    DevBuf<float> row_avg, row_max, row_min;
+    DevView<float> stats2;  // {mean, max} of the identity rows (state block)
     DevBuf<unsigned long long> pairmasks;  // denominator kernel: bit-interleaved validity words of row pairs
     DevBuf<uint32_t> simcodes;  // similarity codes: [G8 + 1][ld] x 8 B (codes8) or [G8 + 1][2][ld] x 16 B (codes32)
-    DevBuf<uint8_t> lut;
-    DevBuf<float> tab;
+    DevBuf<float> tables;  // {distance, both-valid} table followed by the byte -> code LUT: one upload, cached by content
+    DevView<uint8_t> lut;
+    DevView<float> tab;
+    std::vector<int32_t> tab_vhash;  // what `tables` was built from
+    std::vector<float> tab_dist;
+    int tab_npos = -1, tab_indet = -1;
     DevBuf<int32_t> gaps_w;
     DevBuf<float> mdk, simnum, simden;  // mdk: MDK [n] followed by Q [n]
-    DevBuf<unsigned long long> errkey;
-    DevBuf<int> errflag;
-    DevBuf<int> pairflag;          // set by the pair pass when some pair has dst = 0 (undefined identity)
-    PinBuf<int> h_pairflag;
+    DevView<unsigned long long> errkey;  // first bad residue of the similarity pass, complemented (0 = none): state block
+    DevView<int> errflag;                // prep_planes' non-ASCII flag (state block)
+    DevView<int> pairflag;               // set by the pair pass when some pair has dst = 0 (undefined identity; state block)
     bool pairflag_pending = false;
     DevBuf<uint32_t> col_ok;
     DevBuf<int32_t> good, row_cnt, col_cnt, lengths, pairs, equal;
@@ -143,8 +163,7 @@ struct msa_ctx {
     PinBuf<unsigned long long> h_u64;
     PinBuf<uint8_t> h_u8, h_raw;
     // results that are fetched asynchronously and validated at the next synchronisation of the stream
-    PinBuf<int> h_planeflag;       // prep_planes' non-ASCII flag
-    bool planes_pending = false;
+    bool planes_pending = false;   // prep_planes' non-ASCII flag has not been looked at yet
     PinBuf<int32_t> h_gapstage;    // gap / indetermination counts on their way to h_gaps / h_indets
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
     PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
@@ -176,15 +195,26 @@ int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
         if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
     } while (0)
 
-// Every wait on the context's stream goes through here: it also settles the asynchronous fetches above.
+// flag words of the state block
+enum { ST_ERRFLAG = 0, ST_PAIRFLAG = 1, ST_ERRKEY = 2 /* 2 words */, ST_STATS = 4 /* 2 floats */, ST_GATE = 6, ST_WORDS = 16 };
+
+// Every wait on the context's stream goes through here: it fetches the flag words when a kernel that may have raised
+// one ran since the last fetch (one 64-byte copy in front of the wait) and settles the asynchronous fetches above.
 static int sync_stream(msa_ctx *c) {
+    if (c->flags_dirty && c->state.p) {
+        hipError_t e = c->h_flags.reserve(ST_WORDS);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->h_flags.p, c->state.p, ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return fail_hip(c, e, "flag fetch");
+        c->flags_dirty = false;
+    }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
     if (c->gaps_staged == 1) c->gaps_staged = 2;
     if (c->rowtot_staged == 1) c->rowtot_staged = 2;
     if (c->planes_pending) {
         c->planes_pending = false;
-        if (c->h_planeflag.p[0]) {
+        if (c->h_flags.p[ST_ERRFLAG]) {
             c->have_planes = false;
             return MSA_E_NON_ASCII;
         }
@@ -249,6 +279,26 @@ void invalidate(msa_ctx *c) {
     c->order_ready = false;
     c->planes_pending = false;
     c->h_indets.clear();
+    c->state_zeroed = false;
+    c->flags_dirty = false;
+}
+
+// the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)
+int ensure_state(msa_ctx *c) {
+    if (c->state_zeroed) return MSA_OK;
+    c->state_npad = round_up(std::max(c->n, 1) + 64, 64);
+    const size_t words = ST_WORDS + (size_t)2 * c->state_npad;
+    HIPCHK(c, c->state.reserve(words));
+    c->errflag.p = c->state.p + ST_ERRFLAG;
+    c->pairflag.p = c->state.p + ST_PAIRFLAG;
+    c->errkey.p = reinterpret_cast<unsigned long long *>(c->state.p + ST_ERRKEY);
+    c->stats2.p = reinterpret_cast<float *>(c->state.p + ST_STATS);
+    c->gaps.p = c->state.p + ST_WORDS;
+    c->indets.p = c->gaps.p + c->state_npad;
+    HIPCHK(c, hipMemsetAsync(c->state.p, 0, words * sizeof(int32_t), c->stream));
+    c->state_zeroed = true;
+    c->errkey_dirty = false;
+    return MSA_OK;
 }
 
 int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
@@ -267,8 +317,8 @@ int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
 int ensure_planes(msa_ctx *c) {
     if (c->have_planes) return MSA_OK;
     HIPCHK(c, c->planes.reserve((size_t)8 * c->nchunk * c->m_pad + 64));
-    HIPCHK(c, c->errflag.reserve(1));
-    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
+    int rc = ensure_state(c);
+    if (rc) return rc;
     {
         ProfScope ps(c, "prep");
         msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad,
@@ -277,19 +327,24 @@ int ensure_planes(msa_ctx *c) {
     HIPCHK(c, hipGetLastError());
     // the non-ASCII verdict comes back with the next synchronisation of the stream (sync_stream): every caller
     // synchronises before it hands anything derived from the planes to the host
-    HIPCHK(c, c->h_planeflag.reserve(1));
-    HIPCHK(c, hipMemcpyAsync(c->h_planeflag.p, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->flags_dirty = true;
     c->planes_pending = true;
     c->have_planes = true;
     return MSA_OK;
 }
 
+// both count vectors to the pinned staging area: neighbours in the state block, one copy
+int copy_gap_counts(msa_ctx *c) {
+    const size_t words = (size_t)c->state_npad + c->n;
+    HIPCHK(c, c->h_gapstage.reserve(words));
+    HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * words, hipMemcpyDeviceToHost, c->stream));
+    return MSA_OK;
+}
+
 int ensure_gaps(msa_ctx *c, bool to_host) {
     if (!c->have_gaps) {
-        HIPCHK(c, c->gaps.reserve((size_t)c->n + 64));
-        HIPCHK(c, c->indets.reserve((size_t)c->n + 64));
-        HIPCHK(c, hipMemsetAsync(c->gaps.p, 0, sizeof(int32_t) * c->n, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->indets.p, 0, sizeof(int32_t) * c->n, c->stream));
+        int rc = ensure_state(c);  // (zeroes both count vectors)
+        if (rc) return rc;
         {
             ProfScope ps(c, "gaps");
             msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p);
@@ -299,10 +354,8 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
     }
     if (to_host && c->h_gaps.empty() && c->n > 0) {
         if (c->gaps_staged == 0) {
-            HIPCHK(c, c->h_gapstage.reserve((size_t)2 * c->n));
-            HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost,
-                                     c->stream));
+            int rc = copy_gap_counts(c);
+            if (rc) return rc;
             c->gaps_staged = 1;
             SYNC(c);
         }
@@ -312,7 +365,7 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
             else SYNC(c);
         }
         c->h_gaps.assign(c->h_gapstage.p, c->h_gapstage.p + c->n);
-        c->h_indets.assign(c->h_gapstage.p + c->n, c->h_gapstage.p + 2 * c->n);
+        c->h_indets.assign(c->h_gapstage.p + c->state_npad, c->h_gapstage.p + c->state_npad + c->n);
         c->gaps_staged = 0;
     }
     return MSA_OK;
@@ -323,9 +376,8 @@ int stage_gaps(msa_ctx *c) {
     int rc = ensure_gaps(c, false);
     if (rc) return rc;
     if (!c->h_gaps.empty() || c->gaps_staged || c->n <= 0) return MSA_OK;
-    HIPCHK(c, c->h_gapstage.reserve((size_t)2 * c->n));
-    HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p, c->gaps.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_gapstage.p + c->n, c->indets.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    rc = copy_gap_counts(c);
+    if (rc) return rc;
     if (!c->ev_gaps) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gaps, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_gaps, c->stream));
     c->gaps_staged = 1;
@@ -339,16 +391,23 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
     const bool need_ident = want_ident && !c->have_ident, need_w = want_w && !c->have_w;
     if (!need_ident && !need_w && !want_counts) return MSA_OK;
     const size_t fsz = (size_t)c->m * c->ldw + 512;  // slack: the similarity kernels read W a round past a row end
-    if (need_ident) {
-        HIPCHK(c, c->ident.reserve(fsz));
-        HIPCHK(c, hipMemsetAsync(c->ident.p, 0, fsz * sizeof(float), c->stream));
-    }
+    // The pair pass writes every entry (i, j < m) of the float matrices and nothing else; the padding (columns m..ldw,
+    // the rows and the slack behind row m, the diagonal and the unused triangle of W) must read as zero.  It is zeroed
+    // when a buffer is new or the shape differs from the one it was last zeroed for -- not on every pass.
+    const uint64_t shape_tag = ((uint64_t)(uint32_t)c->m << 32) | (uint32_t)c->ldw | (1ull << 63);
+    auto zero_for_shape = [&](DevBuf<float> &buf, size_t count) -> int {
+        HIPCHK(c, buf.reserve(count));
+        if (buf.tag != shape_tag) {
+            HIPCHK(c, hipMemsetAsync(buf.p, 0, count * sizeof(float), c->stream));
+            buf.tag = shape_tag;
+        }
+        return MSA_OK;
+    };
+    if (need_ident && (rc = zero_for_shape(c->ident, fsz))) return rc;
     const size_t lsz = (msak::bx_wlow_rows(c->m) + 2) * (size_t)c->ldw;  // rows past m: zeros the kernel's prefetch may touch
     if (need_w) {
-        HIPCHK(c, c->wmat.reserve(fsz));
-        HIPCHK(c, hipMemsetAsync(c->wmat.p, 0, fsz * sizeof(float), c->stream));
-        HIPCHK(c, c->wlow.reserve(lsz));
-        HIPCHK(c, hipMemsetAsync(c->wlow.p, 0, lsz * sizeof(float), c->stream));
+        if ((rc = zero_for_shape(c->wmat, fsz))) return rc;
+        if ((rc = zero_for_shape(c->wlow, lsz))) return rc;
     }
     if (want_counts) {
         HIPCHK(c, c->hit.reserve((size_t)c->m * c->m + 1));
@@ -356,9 +415,6 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         HIPCHK(c, hipMemsetAsync(c->hit.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->dst.p, 0, (size_t)c->m * c->m * sizeof(uint32_t), c->stream));
     }
-    HIPCHK(c, c->pairflag.reserve(1));
-    HIPCHK(c, c->h_pairflag.reserve(1));
-    HIPCHK(c, hipMemsetAsync(c->pairflag.p, 0, sizeof(int), c->stream));
     {
         ProfScope ps(c, "pairs");
         msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
@@ -367,7 +423,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
                                  c->pairflag.p);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_pairflag.p, c->pairflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->flags_dirty = true;
     c->pairflag_pending = true;  // (read after the next synchronisation of the stream)
     if (need_ident) c->have_ident = true;
     if (need_w) c->have_w = true;
@@ -379,17 +435,15 @@ int identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
     if (rc) return rc;
     HIPCHK(c, c->row_avg.reserve(c->m + 64));
     HIPCHK(c, c->row_max.reserve(c->m + 64));
-    HIPCHK(c, c->stats2.reserve(2));
     {
         ProfScope ps(c, "idstats");
         msak::launch_identity_stats(c->stream, c->ident.p, c->m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, c->h_f32.reserve(2));
-    HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->stats2.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->flags_dirty = true;  // (the two statistics are flag words: they come back with the synchronisation)
     SYNC(c);
-    *avg_seq = c->h_f32.p[0];
-    *max_seq = c->h_f32.p[1];
+    std::memcpy(avg_seq, c->h_flags.p + ST_STATS, sizeof(float));
+    std::memcpy(max_seq, c->h_flags.p + ST_STATS + 1, sizeof(float));
     return MSA_OK;
 }
 
@@ -414,15 +468,50 @@ void build_tables(const int32_t *vhash, const float *dist, int npos, uint8_t ind
         }
 }
 
+// The two tables of the similarity pass in one device block, uploaded when their inputs differ from the ones the block
+// was built from (the same matrix serves call after call).
+int ensure_tables(msa_ctx *c, const int32_t *vhash, const float *dist, int npos) {
+    constexpr size_t TABF = 2 * 29 * 32;
+    const bool same = c->tables.p && c->tab_npos == npos && c->tab_indet == (int)c->indet && c->tab_vhash.size() == 26 &&
+                      std::memcmp(c->tab_vhash.data(), vhash, 26 * sizeof(int32_t)) == 0 &&
+                      c->tab_dist.size() == (size_t)npos * npos &&
+                      std::memcmp(c->tab_dist.data(), dist, sizeof(float) * npos * npos) == 0;
+    if (same) return MSA_OK;
+    HIPCHK(c, c->tables.reserve(TABF + 64));
+    c->tab.p = c->tables.p;
+    c->lut.p = reinterpret_cast<uint8_t *>(c->tables.p + TABF);
+    HIPCHK(c, c->h_f32.reserve(std::max<size_t>(TABF + 64, (size_t)2 * c->n + 64)));
+    // (the staging area may still be read by an earlier upload: wait for the stream before rewriting it)
+    SYNC(c);
+    build_tables(vhash, dist, npos, c->indet, reinterpret_cast<uint8_t *>(c->h_f32.p + TABF), c->h_f32.p);
+    HIPCHK(c, hipMemcpyAsync(c->tables.p, c->h_f32.p, (TABF + 64) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    SYNC(c);  // (h_f32 is reused for the results)
+    c->tab_vhash.assign(vhash, vhash + 26);
+    c->tab_dist.assign(dist, dist + (size_t)npos * npos);
+    c->tab_npos = npos;
+    c->tab_indet = c->indet;
+    return MSA_OK;
+}
+
+// the first-bad-residue key is zero after ensure_state; a second similarity pass over the same alignment resets it
+int reset_errkey(msa_ctx *c) {
+    int rc = ensure_state(c);
+    if (rc) return rc;
+    if (c->errkey_dirty) HIPCHK(c, hipMemsetAsync(c->errkey.p, 0, sizeof(unsigned long long), c->stream));
+    c->errkey_dirty = true;
+    return MSA_OK;
+}
+
 // MDK / Q and the first-bad-residue key back to the host (one synchronisation)
 int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
-    HIPCHK(c, c->h_u64.reserve(1));
     HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32, (size_t)2 * n + 64)));
-    HIPCHK(c, hipMemcpyAsync(c->h_u64.p, c->errkey.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    // (MDK and Q are the two halves of one buffer: one copy)
+    // (MDK and Q are the two halves of one buffer: one copy; the first-bad-residue key is a flag word)
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    c->flags_dirty = true;
     SYNC(c);
-    const unsigned long long key = c->h_u64.p[0];
+    unsigned long long key;
+    std::memcpy(&key, c->h_flags.p + ST_ERRKEY, sizeof(key));
+    key = ~key;  // (kept complemented on the device, where 0 = none and the largest complement = the first residue)
     if (key != ~0ull) {
         if (detail) {
             detail->col = static_cast<int32_t>(key >> 40);
@@ -513,18 +602,12 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     rc = ensure_gaps(c, bx_family);  // (the binade-exact kernel's column list is built on the host)
     if (rc) return rc;
     const int m = c->m, n = c->n;
-    // tables
-    uint8_t lut[256];
-    std::vector<float> tab(2 * 29 * 32);
-    build_tables(vhash, dist, npos, c->indet, lut, tab.data());
-    HIPCHK(c, c->lut.reserve(256));
-    HIPCHK(c, c->tab.reserve(tab.size()));
+    rc = ensure_tables(c, vhash, dist, npos);
+    if (rc) return rc;
+    rc = reset_errkey(c);
+    if (rc) return rc;
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, n)));
-    HIPCHK(c, c->h_f32.reserve(std::max<size_t>(tab.size(), (size_t)2 * n + 64)));
-    std::memcpy(c->h_u8.p, lut, 256);
-    std::memcpy(c->h_f32.p, tab.data(), tab.size() * sizeof(float));
-    HIPCHK(c, hipMemcpyAsync(c->lut.p, c->h_u8.p, 256, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tab.p, c->h_f32.p, tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32, (size_t)2 * n + 64)));
     // the vector used for the ">= 80 % gaps" cut
     const int32_t *gw_dev = c->gaps.p;
     if (gaps_windowed) {
@@ -552,8 +635,6 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, c->bx_code.reserve(lsz));
         HIPCHK(c, c->bx_trow.reserve(lsz));
         HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
-        HIPCHK(c, c->errkey.reserve(1));
-        HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
         HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
         HIPCHK(c, c->simnum.reserve((size_t)n + 64));
         HIPCHK(c, c->simden.reserve((size_t)n + 64));
@@ -613,8 +694,6 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
     const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
     HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
-    HIPCHK(c, c->errkey.reserve(1));
-    HIPCHK(c, hipMemsetAsync(c->errkey.p, 0xFF, sizeof(unsigned long long), c->stream));
     HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
     if (split) {
         // numerators and denominators are independent sequential sums: two kernels, two streams
@@ -696,13 +775,13 @@ int overlap(msa_ctx *c, float residue_overlap, float *out) {
 int stage_row_totals(msa_ctx *c) {
     if (c->rowtot_staged || c->m <= 0 || c->n <= 0) return MSA_OK;
     const int m = c->m, n = c->n;
-    HIPCHK(c, c->keep_res_d.reserve((size_t)n + 64));
     HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
     HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
-    HIPCHK(c, hipMemsetAsync(c->keep_res_d.p, 1, (size_t)n + 64, c->stream));
-    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, c->keep_res_d.p, c->row_cnt.p);
+    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, nullptr, c->row_cnt.p);  // (no mask: every column counts)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_rowtot, c->stream));
     c->rowtot_staged = 1;
     return MSA_OK;
 }
@@ -801,6 +880,19 @@ int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned l
     return rc ? rc : row_digest_end(c, lengths, hashes);
 }
 
+// Ungapped lengths = the residues per sequence over all columns that stage_row_totals fetches: waits for that copy
+// alone (its event), not for what was enqueued behind it.
+int ungapped_lengths(msa_ctx *c, std::vector<int32_t> &lengths) {
+    int rc = stage_row_totals(c);
+    if (rc) return rc;
+    if (c->rowtot_staged == 1) {
+        HIPCHK(c, hipEventSynchronize(c->ev_rowtot));
+        c->rowtot_staged = 2;
+    }
+    lengths.assign(c->h_rowtot.p, c->h_rowtot.p + c->m);
+    return MSA_OK;
+}
+
 // Cleaner::removeDuplicates (as patched by the reference): the earlier of two identical rows goes.
 int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
     const int m = c->m;
@@ -848,13 +940,14 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
 int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     const int m = c->m;
     if (m < 2) return MSA_E_FALLBACK;
-    // the ungapped lengths first, then the pair pass: the processing order is sorted on the host while it runs
-    int rc = row_digest_begin(c);
+    // the ungapped lengths first (msa_trim staged them), then the pair pass: the processing order is sorted on the
+    // host while it runs
+    int rc = stage_row_totals(c);
     if (rc) return rc;
     rc = run_pairs(c, true, false, false);
     if (rc) return rc;
     std::vector<int32_t> lengths;
-    rc = row_digest_end(c, lengths, nullptr);
+    rc = ungapped_lengths(c, lengths);
     if (rc) return rc;
     const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
     const size_t words = msak::cluster_adj_words(m);
@@ -895,7 +988,6 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     HIPCHK(c, c->row_avg.reserve(m + 64));
     HIPCHK(c, c->row_max.reserve(m + 64));
     HIPCHK(c, c->row_min.reserve(m + 64));
-    HIPCHK(c, c->stats2.reserve(2));
     {
         ProfScope ps(c, "idstats");
         msak::launch_identity_stats(c->stream, c->ident.p, m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p, c->row_min.p);
@@ -905,8 +997,9 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->stats2.p, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p + 2, c->row_max.p, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p + 2 + m, c->row_min.p, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+    SYNC(c);
     std::vector<int32_t> lengths;
-    rc = row_digest(c, lengths, nullptr);  // synchronises the stream
+    rc = ungapped_lengths(c, lengths);
     if (rc) return rc;
     float threshold = c->h_f32.p[0], hi = 0, lo = 1;
     for (int i = 0; i < m; ++i) {
@@ -1023,19 +1116,20 @@ void msa_ctx_destroy(msa_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    c->raw_own.release(); c->planes.release(); c->gaps.release(); c->indets.release(); c->ident.release();
+    c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
     c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->u_off.release(); c->u_tt.release(); c->u_ee.release(); c->u_n.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
-    c->stats2.release(); c->simcodes.release(); c->pairmasks.release(); c->lut.release(); c->tab.release(); c->gaps_w.release();
-    c->mdk.release(); c->simnum.release(); c->simden.release(); c->errkey.release(); c->errflag.release(); c->pairflag.release(); c->h_pairflag.release(); c->col_ok.release();
+    c->simcodes.release(); c->pairmasks.release(); c->gaps_w.release();
+    c->mdk.release(); c->simnum.release(); c->simden.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
-    c->h_planeflag.release(); c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release();
+    c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release();
+    if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
+    if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
+    if (c->ev_rowtot) (void)hipEventDestroy(c->ev_rowtot);
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);
-        if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
-        if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
         (void)hipEventDestroy(c->ev_join);
         (void)hipStreamDestroy(c->stream2);
     }
@@ -1262,7 +1356,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         rc = fetch_ident(c, ident);
         if (rc) return rc;
         std::vector<int32_t> lengths;
-        rc = row_digest(c, lengths, nullptr);
+        rc = ungapped_lengths(c, lengths);
         if (rc) return rc;
         float thr = p->max_identity;
         if (p->clusters != -1) thr = msah::cutpoint_clusters(ident.data(), m, lengths.data(), m, p->clusters);
@@ -1357,7 +1451,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     if (info->kept_residues == 0) info->warnings |= MSA_W_NO_COLUMNS_LEFT;
     if (c->pairflag_pending) {  // (remove_all_gaps synchronised the stream: the pair pass's flag has landed)
         c->pairflag_pending = false;
-        if (c->h_pairflag.p[0]) info->warnings |= MSA_W_UNDEFINED_IDENTITY;
+        if (c->h_flags.p && c->h_flags.p[ST_PAIRFLAG]) info->warnings |= MSA_W_UNDEFINED_IDENTITY;
     }
     return MSA_OK;
 }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void sim_encode8_kernel(const uint8_t *__restr
                 if (!skipcol) {
                     const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
                                                    ((unsigned long long)(code & 1u) << 8) | byte;
-                    atomicMin(err_key, key);
+                    atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
                 }
             } else if (code != 224u) {
                 idx = code >> 3;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void sim_encodeT_kernel(const uint8_t *__restr
                     if (!skipcol) {
                         const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
                                                        ((unsigned long long)(code & 1u) << 8) | byte;
-                        atomicMin(err_key, key);
+                        atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
                     }
                 } else if (code != 224u) {
                     idx = code >> 3;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void sim_encode32_kernel(const uint8_t *__rest
                 if (!skipcol) {
                     const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
                                                    ((unsigned long long)(code & 1u) << 8) | byte;
-                    atomicMin(err_key, key);
+                    atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
                 }
             } else if (code != 224u) {
                 idx = code >> 3;
@@ -1768,12 +1768,12 @@ __global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restri
     const int lane = threadIdx.x & 63;
     if (row >= m) return;
     // 16 bytes per lane and load (rows are 64-byte aligned, ld % 64 == 0; keep_res has 64 bytes of slack); bytes at
-    // or past n are masked off
+    // or past n are masked off.  keep_res == nullptr: every column counts.
     const uint4 *p = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld);
     const uint4 *k = reinterpret_cast<const uint4 *>(keep_res);
     int cnt = 0;
     for (int q = lane; q * 16 < n; q += 64) {
-        const uint4 x = p[q], kk = k[q];
+        const uint4 x = p[q], kk = k ? k[q] : make_uint4(~0u, ~0u, ~0u, ~0u);
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ks[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -1791,12 +1791,27 @@ __global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restri
 __global__ __launch_bounds__(256) void col_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
                                                          const uint8_t *__restrict__ keep_seq,
                                                          int32_t *__restrict__ col_nongap) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // as gap_counts: one thread = 4 adjacent columns (a dword per row), byte counters over a slab of 64 rows, one
+    // atomic per column and slab
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)c4 * 4 >= ld) return;
     const int r0 = blockIdx.y * 64, r1 = min(m, r0 + 64);
-    if (c >= n) return;
-    int cnt = 0;
-    for (int r = r0; r < r1; ++r) cnt += (keep_seq[r] && raw[(size_t)r * ld + c] != '-') ? 1 : 0;
-    if (cnt) atomicAdd(&col_nongap[c], cnt);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)r0 * ld) + c4;
+    const size_t stride = (size_t)(ld >> 2);
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+        const uint32_t x = *p;
+        p += stride;
+        const uint32_t nongap = (~zero_bytes(x ^ 0x2d2d2d2du) & 0x80808080u) >> 7;
+        acc += keep_seq[r] ? nongap : 0u;  // (wave-uniform)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        const uint32_t v = (acc >> (8 * k)) & 0xFFu;
+        if (c < n && v) atomicAdd(&col_nongap[c], (int)v);
+    }
 }
 
 // per-row ungapped length + 2x64-bit row hash (duplicate detection, representative ordering)
@@ -2146,7 +2161,7 @@ void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 
 void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,
                        int32_t *col_nongap) {
-    dim3 grid((n + 255) / 256, (m + 63) / 64);
+    dim3 grid((int)((ld / 4 + 255) / 256), (m + 63) / 64);
     col_nongap_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, keep_seq, col_nongap);
 }
 

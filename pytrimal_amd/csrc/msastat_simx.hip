@@ -1579,7 +1579,7 @@ __global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__res
             if (code >= 0xFEu) {
                 const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
                                                ((unsigned long long)(code & 1u) << 8) | byte;
-                atomicMin(err_key, key);
+                atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
                 code = BX_SKIP;
             }
         }
