@@ -167,7 +167,8 @@ struct msa_ctx {
     PinBuf<int32_t> h_gapstage;    // gap / indetermination counts on their way to h_gaps / h_indets
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
     PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
-    int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete
+    int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete, 3 enqueued on the side stream (not joined yet)
+    bool pipe_active = false, pipe_gated = false;  // msa_trim's similarity pipeline is in flight (see sim_pipeline_begin)
 
     // host copies valid for the current alignment
     std::vector<int32_t> h_gaps, h_indets;
@@ -503,12 +504,15 @@ int reset_errkey(msa_ctx *c) {
 }
 
 // MDK / Q and the first-bad-residue key back to the host (one synchronisation)
-int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
-    HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32, (size_t)2 * n + 64)));
+int fetch_similarity_enqueue(msa_ctx *c, int n) {
+    HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32 + 64, (size_t)2 * n + 64)));
     // (MDK and Q are the two halves of one buffer: one copy; the first-bad-residue key is a flag word)
     HIPCHK(c, hipMemcpyAsync(c->h_f32.p, c->mdk.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
     c->flags_dirty = true;
-    SYNC(c);
+    return MSA_OK;
+}
+// (after the synchronisation that followed fetch_similarity_enqueue)
+int fetch_similarity_finish(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
     unsigned long long key;
     std::memcpy(&key, c->h_flags.p + ST_ERRKEY, sizeof(key));
     key = ~key;  // (kept complemented on the device, where 0 = none and the largest complement = the first residue)
@@ -523,6 +527,12 @@ int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_de
     std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
     if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
     return MSA_OK;
+}
+int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
+    int rc = fetch_similarity_enqueue(c, n);
+    if (rc) return rc;
+    SYNC(c);
+    return fetch_similarity_finish(c, n, mdk_out, q_out, detail);
 }
 
 // The columns the binade-exact kernels evaluate (not zeroed by the ">= 80 % gaps" rule), the ones with the most valid
@@ -587,6 +597,69 @@ int build_sim_order(msa_ctx *c, const int32_t *gaps_windowed, bool pairs2, SimOr
     return MSA_OK;
 }
 
+// ---- the binade-exact similarity pass in three enqueue steps (similarity() runs them back to back on the context's
+// stream; msa_trim's pipeline puts the first two on the side stream, beside the pair pass) --------------------------
+// 1. column-major codes and the compacted lists of every column's valid rows
+int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t st) {
+    const int m = c->m, n = c->n;
+    const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
+    HIPCHK(c, c->codeT.reserve(lsz));
+    HIPCHK(c, c->bx_off.reserve(lsz));
+    HIPCHK(c, c->bx_row.reserve(lsz));
+    HIPCHK(c, c->bx_code.reserve(lsz));
+    HIPCHK(c, c->bx_trow.reserve(lsz));
+    HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
+    {
+        ProfScope pe(c, "encode", st);
+        msak::launch_sim_encode_cm(st, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
+        msak::launch_bx_compact(st, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, c->bx_nvalid.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    return MSA_OK;
+}
+// 2. the column list (built on the host into h_simcols)
+int sim_order_enqueue(msa_ctx *c, const SimOrder &ord, hipStream_t st) {
+    HIPCHK(c, c->simcols.reserve((size_t)ord.npad + 8));
+    if (ord.npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * ord.npad, hipMemcpyHostToDevice, st));
+    return MSA_OK;
+}
+// 3. the kernel and the MDK values (context's stream).  gate: device word that, when non-zero, turns the kernel into
+//    a no-op (automated1: raised by the identity statistics when they select gappyout); one-column kernel only.
+int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, bool pairs2, const int32_t *gw_dev, const int *gate) {
+    const int m = c->m, n = c->n;
+    const int npad = ord.npad, pair_waves = ord.pair_waves;
+    HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
+    HIPCHK(c, c->simnum.reserve((size_t)n + 64));
+    HIPCHK(c, c->simden.reserve((size_t)n + 64));
+    // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
+    {
+        ProfScope ps(c, "sim");
+        int e;
+        if (pairs2) {
+            // neighbours in the order by valid rows share a wave and the W rows of the union of their valid rows
+            const size_t usz = (size_t)(npad / 2 + 1) * msak::bx_ldk(m) + 64;
+            HIPCHK(c, c->u_off.reserve(usz));
+            HIPCHK(c, c->u_tt.reserve(usz));
+            HIPCHK(c, c->u_ee.reserve(2 * usz));
+            HIPCHK(c, c->u_n.reserve((size_t)npad / 2 + 64));
+            e = msak::launch_similarity_lg2(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, npos, c->bx_nvalid.p, c->codeT.p, m, n,
+                                            c->simcols.p, npad, pair_waves, c->u_off.p, c->u_tt.p, c->u_ee.p, c->u_n.p, c->wlow.p,
+                                            c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
+        } else
+            e = c->tuning.sim_kernel == 3
+                          ? msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p,
+                                                       m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
+                                                       c->simnum.p, c->simden.p)
+                          : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, npos,
+                                                       c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
+                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate);
+        if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
+    }
+    msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
+    HIPCHK(c, hipGetLastError());
+    return MSA_OK;
+}
+
 int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed,
                float *mdk_out, float *q_out, msa_err_detail *detail) {
     if (npos < 1 || npos > 28) return MSA_E_INVALID;
@@ -628,22 +701,8 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         // tools/lg_sweep.py); 5 "q2": two columns per wave sharing the W loads (alphabets up to 22 letters);
         // 3 "bx": the one-grid-per-round predecessor
         const bool pairs2 = c->tuning.sim_kernel == 5 && msak::lg2_fits(npos);
-        const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
-        HIPCHK(c, c->codeT.reserve(lsz));
-        HIPCHK(c, c->bx_off.reserve(lsz));
-        HIPCHK(c, c->bx_row.reserve(lsz));
-        HIPCHK(c, c->bx_code.reserve(lsz));
-        HIPCHK(c, c->bx_trow.reserve(lsz));
-        HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
-        HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
-        HIPCHK(c, c->simnum.reserve((size_t)n + 64));
-        HIPCHK(c, c->simden.reserve((size_t)n + 64));
-        {
-            ProfScope pe(c, "encode");
-            msak::launch_sim_encode_cm(c->stream, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
-            msak::launch_bx_compact(c->stream, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p,
-                                    c->bx_nvalid.p);
-        }
+        rc = sim_lists_enqueue(c, npos, gw_dev, c->stream);
+        if (rc) return rc;
         mark("lists enqueued");
         SimOrder ord;
         if (c->order_ready && c->order_pairs2 == pairs2) {
@@ -653,38 +712,11 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
             if (rc) return rc;
         }
         c->order_ready = false;
-        const int npad = ord.npad, pair_waves = ord.pair_waves;
-        const int32_t *list = c->h_simcols.p;
-        (void)list;
         mark("columns sorted");
-        HIPCHK(c, c->simcols.reserve((size_t)npad + 8));
-        if (npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * npad, hipMemcpyHostToDevice, c->stream));
-        // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
-        {
-            ProfScope ps(c, "sim");
-            int e;
-            if (pairs2) {
-                // neighbours in the order by valid rows share a wave and the W rows of the union of their valid rows
-                const size_t usz = (size_t)(npad / 2 + 1) * msak::bx_ldk(m) + 64;
-                HIPCHK(c, c->u_off.reserve(usz));
-                HIPCHK(c, c->u_tt.reserve(usz));
-                HIPCHK(c, c->u_ee.reserve(2 * usz));
-                HIPCHK(c, c->u_n.reserve((size_t)npad / 2 + 64));
-                e = msak::launch_similarity_lg2(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, npos, c->bx_nvalid.p, c->codeT.p, m, n,
-                                                c->simcols.p, npad, pair_waves, c->u_off.p, c->u_tt.p, c->u_ee.p, c->u_n.p, c->wlow.p,
-                                                c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
-            } else
-                e = c->tuning.sim_kernel == 3
-                              ? msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p,
-                                                           m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
-                                                           c->simnum.p, c->simden.p)
-                              : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, npos,
-                                                           c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
-                                                           c->ldw, c->tab.p, c->simnum.p, c->simden.p);
-            if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
-        }
-        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
-        HIPCHK(c, hipGetLastError());
+        rc = sim_order_enqueue(c, ord, c->stream);
+        if (rc) return rc;
+        rc = sim_kernel_enqueue(c, npos, ord, pairs2, gw_dev, nullptr);
+        if (rc) return rc;
         mark("kernel enqueued");
         rc = fetch_similarity(c, n, mdk_out, q_out, detail);
         mark("results fetched");
@@ -772,17 +804,20 @@ int overlap(msa_ctx *c, float residue_overlap, float *out) {
 // the updated sequences).
 // Residues per sequence over ALL columns, enqueued without waiting (the next synchronisation completes the copy):
 // remove_all_gaps can then tell from the host that no sequence can have lost all its residues.
-int stage_row_totals(msa_ctx *c) {
+int stage_row_totals(msa_ctx *c, hipStream_t st = nullptr) {
     if (c->rowtot_staged || c->m <= 0 || c->n <= 0) return MSA_OK;
+    const bool side = st && st != c->stream;
+    if (!st) st = c->stream;
     const int m = c->m, n = c->n;
     HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
     HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
-    msak::launch_row_nongap(c->stream, c->raw, m, n, c->ld, nullptr, c->row_cnt.p);  // (no mask: every column counts)
+    msak::launch_row_nongap(st, c->raw, m, n, c->ld, nullptr, c->row_cnt.p);  // (no mask: every column counts)
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
     if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_rowtot, c->stream));
-    c->rowtot_staged = 1;
+    HIPCHK(c, hipEventRecord(c->ev_rowtot, st));
+    // (3: on the side stream -- a wait on the context's stream does not cover it until the streams have joined)
+    c->rowtot_staged = side ? 3 : 1;
     return MSA_OK;
 }
 
@@ -885,7 +920,7 @@ int row_digest(msa_ctx *c, std::vector<int32_t> &lengths, std::vector<unsigned l
 int ungapped_lengths(msa_ctx *c, std::vector<int32_t> &lengths) {
     int rc = stage_row_totals(c);
     if (rc) return rc;
-    if (c->rowtot_staged == 1) {
+    if (c->rowtot_staged == 1 || c->rowtot_staged == 3) {
         HIPCHK(c, hipEventSynchronize(c->ev_rowtot));
         c->rowtot_staged = 2;
     }
@@ -1055,6 +1090,73 @@ int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of th
     HIPCHK(c, hipMemcpy2DAsync(host.data(), (size_t)c->m * sizeof(float), c->ident.p, (size_t)c->ldw * sizeof(float),
                                (size_t)c->m * sizeof(float), c->m, hipMemcpyDeviceToHost, c->stream));
     SYNC(c);
+    return MSA_OK;
+}
+
+// ---- msa_trim's similarity pipeline ----------------------------------------------------------------------------
+// A trim that needs (or, for automated1, may need) the similarity values enqueues everything before its first wait:
+//
+//   context's stream:  state memset, gap counts + copy (ev_gaps) | fork | planes, pair pass, [identity statistics ->
+//                      gate] | join | similarity kernel (skipped on the device when the gate is up), MDK, result copy
+//   side stream:       row totals + copy (ev_rowtot), column-major codes, compacted lists, column list
+//
+// and waits once, for everything.  The host work that depends on the gap counts alone (their window, the gap cut, the
+// column order) runs while the pair pass does.  gated: automated1 -- Cleaner::selectMethod's decision is also taken on
+// the device (identity_final_kernel), so that the similarity kernel can sit in the queue behind the statistics
+// without a round trip to the host; the host takes the same decision from the same two floats after the wait.
+bool sim_pipeline_applies(const msa_ctx *c, const msa_trim_params *p, int sim_hw) {
+    return p->vhash && p->dist && p->npos >= 1 && p->npos <= 28 && (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 4) &&
+           c->tuning.lg_regs == 0 && c->m < 32000 && c->m >= 2 && sim_hw <= c->n / 4 && c->tuning.pipeline != 0;
+}
+
+int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool gated, std::vector<int32_t> &gaps_w) {
+    const int n = c->n;
+    int rc = ensure_tables(c, p->vhash, p->dist, p->npos);
+    if (rc) return rc;
+    if ((rc = reset_errkey(c))) return rc;
+    if ((rc = stage_gaps(c))) return rc;
+    if (!c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if ((rc = stage_row_totals(c, c->stream2))) return rc;
+    const int32_t *gw_dev = c->gaps.p;
+    if (gap_hw == 0 && (rc = sim_lists_enqueue(c, p->npos, gw_dev, c->stream2))) return rc;  // (needs nothing from the host)
+    if ((rc = run_pairs(c, gated, true, false))) return rc;
+    // host: the gap counts arrive behind their own event while the pair pass runs
+    if ((rc = ensure_gaps(c, true))) return rc;
+    gaps_w.resize(n);
+    if ((rc = msah::window_i32(c->h_gaps.data(), n, gap_hw, gaps_w.data()))) return rc;
+    if (gap_hw > 0) {
+        HIPCHK(c, c->gaps_w.reserve((size_t)n + 64));
+        HIPCHK(c, c->h_i32.reserve((size_t)std::max(c->m, 2 * n) + 4));
+        std::memcpy(c->h_i32.p, gaps_w.data(), sizeof(int32_t) * n);
+        HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream2));
+        gw_dev = c->gaps_w.p;
+        if ((rc = sim_lists_enqueue(c, p->npos, gw_dev, c->stream2))) return rc;
+    }
+    SimOrder ord;
+    if ((rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, false, &ord))) return rc;
+    if ((rc = sim_order_enqueue(c, ord, c->stream2))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    int *gate = nullptr;
+    if (gated) {
+        HIPCHK(c, c->row_avg.reserve(c->m + 64));
+        HIPCHK(c, c->row_max.reserve(c->m + 64));
+        gate = c->state.p + ST_GATE;
+        ProfScope ps(c, "idstats");
+        msak::launch_identity_stats(c->stream, c->ident.p, c->m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p, nullptr, gate);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (c->rowtot_staged == 3) c->rowtot_staged = 1;  // (joined: a wait on the context's stream now covers the copy)
+    if ((rc = sim_kernel_enqueue(c, p->npos, ord, false, gw_dev, gate))) return rc;
+    if ((rc = fetch_similarity_enqueue(c, n))) return rc;
+    c->pipe_active = true;
+    c->pipe_gated = gated;
     return MSA_OK;
 }
 
@@ -1293,6 +1395,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     TrimTrace trace(c->tuning.trace != 0);
     TuneScope tune(c);
     c->order_ready = false;
+    c->pipe_active = false;
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
@@ -1318,6 +1421,20 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         gaps_w.resize(n);
         return msah::window_i32(c->h_gaps.data(), n, gap_hw, gaps_w.data());
     };
+    bool pipe_waited = false;
+    struct PipeGuard {  // an error exit must not leave the pipeline's copies in flight over the staging buffers
+        msa_ctx *c;
+        bool &waited;
+        ~PipeGuard() {
+            if (c->pipe_active && !waited) (void)hipStreamSynchronize(c->stream);
+            c->pipe_active = false;
+        }
+    } pipe_guard{c, pipe_waited};
+    auto pipe_wait = [&]() -> int {  // the one wait of a pipelined trim
+        if (pipe_waited) return MSA_OK;
+        pipe_waited = true;
+        return sync_stream(c);
+    };
     auto need_sim = [&]() -> int {
         if (!mdk.empty()) return MSA_OK;
         int r = need_gaps();
@@ -1325,16 +1442,35 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         if (sim_hw > n / 4) return MSA_E_WINDOW_TOO_BIG;
         if (!p->vhash || !p->dist) return MSA_E_INVALID;
         mdk.resize(n);
-        r = similarity(c, p->vhash, p->dist, p->npos, gap_hw > 0 ? gaps_w.data() : nullptr, mdk.data(), nullptr,
-                       &info->err);
+        if (c->pipe_active && !(c->pipe_gated && c->h_flags.p && pipe_waited && c->h_flags.p[ST_GATE])) {
+            // enqueued by sim_pipeline_begin: wait (once) and take the values
+            if ((r = pipe_wait())) return r;
+            r = fetch_similarity_finish(c, n, mdk.data(), nullptr, &info->err);
+        } else {
+            r = similarity(c, p->vhash, p->dist, p->npos, gap_hw > 0 ? gaps_w.data() : nullptr, mdk.data(), nullptr,
+                           &info->err);
+        }
         if (r) return r;
         mdk_w.resize(n);
         return msah::window_f32(mdk.data(), n, sim_hw, mdk_w.data());
     };
 
-    // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
-    if ((rc = stage_row_totals(c))) return rc;
     int method = p->method;
+    // Which trims enqueue the similarity pass up front (sim_pipeline_begin): the methods that always need its values,
+    // and automated1, which may (gated on the device by the identity statistics).
+    const bool column_mode = method != MSA_METHOD_NODUPLICATESEQS && p->clusters == -1 && p->max_identity == -1 &&
+                             !(p->residue_overlap != -1 && p->sequence_overlap != -1);
+    const bool sim_always = method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS ||
+                            (method == MSA_METHOD_NONE && p->similarity_threshold != -1);
+    const bool pipelined = column_mode && (sim_always || method == MSA_METHOD_AUTOMATED1) && sim_pipeline_applies(c, p, sim_hw);
+    if (pipelined) {
+        rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
+        if (rc) return rc;
+        trace.mark("pipeline enqueued");
+    } else {
+        // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
+        if ((rc = stage_row_totals(c))) return rc;
+    }
     bool seq_mode = false, have_gap_cut = false;
     if (method == MSA_METHOD_NODUPLICATESEQS) {
         rc = remove_duplicates(c, keep_seq);
@@ -1372,7 +1508,18 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     }
 
     if (!seq_mode) {
-        if (method == MSA_METHOD_AUTOMATED1) {
+        if (method == MSA_METHOD_AUTOMATED1 && pipelined) {
+            // everything is in the queue; the gap cut while it runs, then the one wait, then Cleaner::selectMethod
+            info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
+            have_gap_cut = true;
+            trace.mark("gap cut");
+            if ((rc = pipe_wait())) return rc;
+            trace.mark("waited");
+            std::memcpy(&info->avg_seq, c->h_flags.p + ST_STATS, sizeof(float));
+            std::memcpy(&info->max_seq, c->h_flags.p + ST_STATS + 1, sizeof(float));
+            info->selected_method = msah::select_method(info->avg_seq, info->max_seq, m);
+            method = info->selected_method == 1 ? MSA_METHOD_GAPPYOUT : MSA_METHOD_STRICT;
+        } else if (method == MSA_METHOD_AUTOMATED1) {
             // The gap counts first (both methods need them), then one pair pass that produces both float matrices
             // (strict is likely to follow).  While the pair pass runs, the host does everything that depends on the
             // gap counts alone: their window, the gap cut, the similarity kernel's column order.

@@ -19,6 +19,7 @@ struct Tuning {
     int sim_serial = 0;        // MSA_SIM_SERIAL: numerator and denominator kernel on one stream
     int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
     int trace = 0;             // MSA_TRACE
+    int pipeline = 1;          // MSA_PIPELINE=0: msa_trim waits for the gap counts / identity statistics before it enqueues the similarity pass
     int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)
     int bx_r0 = -1;            // MSA_BX_R0: rows evaluated in order before the first round (-1 = default)
     int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
@@ -56,10 +57,11 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
                          const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
-                           float *out2, float *row_min = nullptr);
+                           float *out2, float *row_min = nullptr, int *gate = nullptr);
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
                          int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
-                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out);
+                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
+                         const int *gate = nullptr);
 bool lg2_fits(int npos);
 int lg2_max_waves();
 int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, int npos,

@@ -1974,6 +1974,7 @@ Tuning tuning_from_env() {
     t.sim_serial = getenv("MSA_SIM_SERIAL") != nullptr;
     t.device_clusters = num("MSA_DEVICE_CLUSTERS", -1);
     t.trace = getenv("MSA_TRACE") != nullptr;
+    t.pipeline = num("MSA_PIPELINE", 1);
     t.bx_cols = num("MSA_BX_COLS", 0);
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);

@@ -1115,14 +1115,18 @@ __device__ __forceinline__ void similarity_lg_body(
         const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, \
         int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
         uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
-        float *__restrict__ num_out, float *__restrict__ den_out
+        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate
 #define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, tab_g, num_out, den_out
 template <bool STAMP>
 __global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
+    // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
+    // kernel that computes them raises the gate when the similarity values will not be used)
+    if (gate && *gate) return;
     similarity_lg_body<STAMP, true>(LG_ARGS);
 }
 template <bool STAMP>
 __global__ __launch_bounds__(64 * LG_WAVES_MAX) void similarity_lg_regs_kernel(LG_PARAMS) {
+    if (gate && *gate) return;
     similarity_lg_body<STAMP, false>(LG_ARGS);
 }
 #undef LG_PARAMS
@@ -1497,24 +1501,40 @@ __global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(64) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
-                                                            int m, float *__restrict__ out2) {
-    const int lane = threadIdx.x;
-    float a = 0.0f, b = 0.0f;
+// (two waves: one per sum.  gate != nullptr: Cleaner::selectMethod's decision is taken here as well -- *gate = 1 when it
+// selects gappyout, i.e. the similarity kernel enqueued behind this one has nothing to do; the host takes the same
+// decision from the same two numbers when they arrive)
+__global__ __launch_bounds__(128) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                             int m, float *__restrict__ out2, int *__restrict__ gate) {
+    __shared__ float res[2];
+    const int lane = threadIdx.x & 63;
+    const int which = uni((int)(threadIdx.x >> 6));
+    const float *src = which ? row_max : row_avg;
+    float a = 0.0f;
     for (int base = 0; base < m; base += 256) {
-        float xa[4], xb[4];
+        float xa[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int t = base + 64 * c + lane;
-            xa[c] = t < m ? row_avg[t] : 0.0f;
-            xb[c] = t < m ? row_max[t] : 0.0f;
+            xa[c] = t < m ? src[t] : 0.0f;
         }
         a = chunk_step(a, xa);
-        b = chunk_step(b, xb);
     }
     if (lane == 0) {
-        out2[0] = a / (float)m;
-        out2[1] = b / (float)m;
+        a = a / (float)m;
+        out2[which] = a;
+        res[which] = a;
+    }
+    __syncthreads();
+    if (gate && threadIdx.x == 0) {
+        const float avg = res[0], mx = res[1];
+        int sel;  // msah::select_method, literally
+        if (avg >= 0.55) sel = 1;
+        else if (avg <= 0.38) sel = 2;
+        else if (m <= 20) sel = 1;
+        else if (mx >= 0.5 && mx <= 0.65) sel = 1;
+        else sel = 2;
+        *gate = sel == 1 ? 1 : 0;
     }
 }
 
@@ -1645,7 +1665,8 @@ int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vr
 // the same contract as launch_similarity_bx plus the 16-bit table-row list; the kernel with per-lane grids (the default)
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
                          int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
-                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
+                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
+                         const int *gate) {
     const int64_t ldk = bx_ldk(m);
     // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 1 -> no W loads, stamped kernel only)
     const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16) | ((tuning().lg_dbg & 64) ? 0x40000 : 0) |
@@ -1664,7 +1685,7 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     const bool stamp = (tuning().sim_mode & 64) != 0;
 #define LG_LAUNCH(KERNEL)                                                                                              \
     KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup, ldw, r0, \
-                                         t, num_out, den_out)
+                                         t, num_out, den_out, gate)
     if (ldst) {
         const void *k = stamp ? (const void *)similarity_lg_kernel<true> : (const void *)similarity_lg_kernel<false>;
         const int e = set_max_lds_once(k, (int)dyn);
@@ -1714,9 +1735,9 @@ int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *v
 }
 
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max, float *out2,
-                           float *row_min) {
+                           float *row_min, int *gate) {
     identity_rows_kernel<<<(m + 3) / 4, 256, 0, s>>>(ident, m, ldw, row_avg, row_max, row_min);
-    identity_final_kernel<<<1, 64, 0, s>>>(row_avg, row_max, m, out2);
+    identity_final_kernel<<<1, 128, 0, s>>>(row_avg, row_max, m, out2, gate);
 }
 
 extern "C" int msa_debug_bx_stamps(unsigned long long *out16, int reset) {

@@ -34,7 +34,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
-                     "MSA_LG_REGS", "MSA_LG_DBG"):
+                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:

@@ -1,0 +1,166 @@
+"""msa_trim's similarity pipeline (everything enqueued before the first wait, automated1 gated on the device) against
+the oracle and against the same library with MSA_PIPELINE=0 (the serial flow: wait for the gap counts, wait for the
+identity statistics, then enqueue the similarity pass)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from pytrimal_amd import AutomaticTrimmer, ManualTrimmer, _lib
+from pytrimal_amd.matrix import SimilarityMatrix
+from pytrimal_amd.synth import synth_msa
+
+pytestmark = pytest.mark.gpu
+ALPHA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+
+
+@pytest.fixture
+def contexts(monkeypatch):
+    """(pipelined, serial) contexts: the switch is read when a context is created"""
+    made = []
+    for value in ("1", "0"):
+        monkeypatch.setenv("MSA_PIPELINE", value)
+        made.append(_lib.Context(0))
+    monkeypatch.delenv("MSA_PIPELINE")
+    yield made
+    for c in made:
+        c.close()
+
+
+def params_of(trimmer):
+    mx = SimilarityMatrix.aa()
+    vhash = np.ascontiguousarray(mx._vhash, dtype=np.int32)
+    dist = np.ascontiguousarray(mx._dist, dtype=np.float32)
+    p = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
+    trimmer._configure(p)
+    p.vhash = vhash.ctypes.data_as(ctypes.c_void_p)
+    p.dist = dist.ctypes.data_as(ctypes.c_void_p)
+    p.npos = len(mx)
+    return p, (vhash, dist)  # (the arrays must outlive the parameter block)
+
+
+def family(m, n, seed, keep):
+    """m copies of a random root, each residue kept with probability `keep` (else redrawn), 8 % gaps"""
+    r = np.random.default_rng(seed)
+    root = ALPHA[r.integers(0, 20, n)]
+    a = np.where(r.random((m, n)) < keep, root[None, :], ALPHA[r.integers(0, 20, (m, n))])
+    a[r.random((m, n)) < 0.08 * r.random(n)[None, :] * 4] = ord("-")
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def run_both(contexts, a, trimmer, **oracle_kw):
+    p, keepalive = params_of(trimmer)
+    res, seq, oinfo = oracle.trim(a, **oracle_kw)
+    infos = []
+    for ctx in contexts:
+        for _ in range(2):  # (twice: the second call runs over the buffers the first one left)
+            ctx.upload(a, ord("X"))
+            keep_res, keep_seq, info = ctx.trim(p)
+            assert np.array_equal(keep_res, res)
+            assert np.array_equal(keep_seq, seq)
+        infos.append(info)
+    del keepalive
+    return oinfo, infos
+
+
+CASES = {  # name: (m, n, seed, keep) -> what Cleaner::selectMethod makes of it
+    "conserved": (60, 300, 1, 0.92),   # mean identity >= 0.55: gappyout
+    "diverged": (60, 300, 2, 0.30),    # mean identity <= 0.38: strict
+    "few": (12, 200, 3, 0.70),         # in between, <= 20 sequences: gappyout
+    "middle": (80, 260, 4, 0.72),      # in between, mean of the row maxima below 0.5: strict
+    "middle_max": (80, 260, 7, 0.85),  # in between, mean of the row maxima in [0.5, 0.65]: gappyout
+    "large": (700, 900, 6, 0.45),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_automated1_gate(contexts, case):
+    m, n, seed, keep = CASES[case]
+    a = family(m, n, seed, keep)
+    oinfo, infos = run_both(contexts, a, AutomaticTrimmer("automated1", platform="hip"), method="automated1")
+    for info in infos:
+        assert info.selected_method == oinfo.selected
+        assert np.float32(info.avg_seq).view(np.uint32) == np.float32(oinfo.avg_seq).view(np.uint32)
+        assert np.float32(info.max_seq).view(np.uint32) == np.float32(oinfo.max_seq).view(np.uint32)
+        assert info.gap_cut == oinfo.gap_cut
+        if oinfo.selected == 2:
+            assert np.float32(info.sim_cut).view(np.uint32) == np.float32(oinfo.sim_cut).view(np.uint32)
+
+
+def test_automated1_cases_cover_both_methods():
+    picked = {name: oracle.trim(family(*CASES[name]), method="automated1")[2].selected for name in CASES}
+    assert set(picked.values()) == {1, 2}, picked
+    assert picked == {"conserved": 1, "diverged": 2, "few": 1, "middle": 2, "middle_max": 1, "large": 2}
+
+
+@pytest.mark.parametrize("kw", [dict(method="strict"), dict(method="strictplus"),
+                                dict(similarity_threshold=0.4), dict(gap_threshold=0.6, similarity_threshold=0.3),
+                                dict(gap_threshold=0.7, similarity_threshold=0.2, gap_window=2, similarity_window=3),
+                                dict(similarity_threshold=0.3, window=4, conservation_percentage=40)])
+@pytest.mark.parametrize("shape", [(9, 70, 0.5), (130, 333, 0.4), (513, 1100, 0.5)])
+def test_pipelined_methods(contexts, kw, shape):
+    m, n, keep = shape
+    a = family(m, n, 11 + m, keep)
+    trimmer = AutomaticTrimmer(kw["method"], platform="hip") if "method" in kw else ManualTrimmer(platform="hip", **kw)
+    run_both(contexts, a, trimmer, **kw)
+
+
+def test_shapes_alternate_on_one_context(contexts):
+    """the padding of the float matrices is zeroed per shape, not per pass: a context that sees a large alignment,
+    a small one and the large one again must not read what the other shape left behind"""
+    big, small, odd = synth_msa(300, 500, 71), synth_msa(70, 900, 72), synth_msa(257, 130, 73)
+    p, keepalive = params_of(AutomaticTrimmer("automated1", platform="hip"))
+    ps, keepalive2 = params_of(AutomaticTrimmer("strict", platform="hip"))
+    expected = {id(x): oracle.trim(x, method="automated1")[0] for x in (big, small, odd)}
+    expected_s = {id(x): oracle.trim(x, method="strict")[0] for x in (big, small, odd)}
+    for ctx in contexts:
+        for a in (big, small, big, odd, small, odd, big):
+            ctx.upload(a, ord("X"))
+            assert np.array_equal(ctx.trim(p)[0], expected[id(a)])
+            ctx.upload(a, ord("X"))
+            assert np.array_equal(ctx.trim(ps)[0], expected_s[id(a)])
+    del keepalive, keepalive2
+
+
+def test_bad_residue_only_matters_when_similarity_is_used(contexts):
+    """automated1 encodes the columns for the similarity pass before it knows whether strict will be selected: a
+    symbol outside the matrix must raise exactly when the reference would have reached the similarity statistic"""
+    for name in ("conserved", "diverged"):
+        a = family(*CASES[name]).copy()
+        a[5, 17] = ord("J")  # not in the default matrix
+        p, keepalive = params_of(AutomaticTrimmer("automated1", platform="hip"))
+        try:
+            res = oracle.trim(a, method="automated1")[0]
+        except oracle.OracleError:
+            res = None
+        for ctx in contexts:
+            ctx.upload(a, ord("X"))
+            if res is None:
+                with pytest.raises(ValueError):
+                    ctx.trim(p)
+            else:
+                assert np.array_equal(ctx.trim(p)[0], res)
+            # the context stays usable and clean after the error
+            b = family(*CASES["diverged"])
+            ctx.upload(b, ord("X"))
+            assert np.array_equal(ctx.trim(p)[0], oracle.trim(b, method="automated1")[0])
+        del keepalive
+
+
+def test_repeated_similarity_on_one_alignment(contexts):
+    """two similarity passes over one upload (the first-bad-residue key is reset in between)"""
+    a = family(90, 150, 5, 0.5)
+    vhash, dist = oracle.aa_matrix()
+    hit, dst = oracle.pair_counts(a, ord("X"))
+    mdk0, _ = oracle.similarity(a, oracle.weights(hit, dst), None, vhash, dist)
+    for ctx in contexts:
+        ctx.upload(a, ord("X"))
+        for k in range(3):
+            mdk, _ = ctx.similarity(vhash, dist)
+            assert np.array_equal(np.asarray(mdk, dtype=np.float32).view(np.uint32), np.asarray(mdk0, dtype=np.float32).view(np.uint32))
+            if k == 0:  # a pass that fails in between (a matrix without 'A') must not leave its key behind
+                holed = np.array(vhash, dtype=np.int32).copy()
+                holed[0] = -1
+                with pytest.raises(ValueError):
+                    ctx.similarity(holed, dist)
