@@ -1115,17 +1115,27 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
     if (rc) return rc;
     if ((rc = reset_errkey(c))) return rc;
     if ((rc = stage_gaps(c))) return rc;
-    if (!c->stream2) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    // A pair pass of a few hundred microseconds hides the side stream's work and what it costs the host to enqueue it
+    // (~80 us: events, a second queue); below that everything goes on the context's stream, the small kernels in
+    // front of the pair pass (the host sorts the column order while they run).
+    const bool forked = c->tuning.pipeline == 3 || ((double)c->m * c->m * n >= 2e9 && c->tuning.pipeline != 2);
+    hipStream_t side = c->stream;
+    if (forked) {
+        if (!c->stream2) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        side = c->stream2;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        // the context's stream first: the pair pass starts while the side stream is being filled
+        if ((rc = run_pairs(c, gated, true, false))) return rc;
+        HIPCHK(c, hipStreamWaitEvent(side, c->ev_fork, 0));
     }
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    if ((rc = stage_row_totals(c, c->stream2))) return rc;
+    if ((rc = stage_row_totals(c, side))) return rc;
     const int32_t *gw_dev = c->gaps.p;
-    if (gap_hw == 0 && (rc = sim_lists_enqueue(c, p->npos, gw_dev, c->stream2))) return rc;  // (needs nothing from the host)
-    if ((rc = run_pairs(c, gated, true, false))) return rc;
+    if (gap_hw == 0 && (rc = sim_lists_enqueue(c, p->npos, gw_dev, side))) return rc;  // (needs nothing from the host)
+    if (!forked && (rc = run_pairs(c, gated, true, false))) return rc;
     // host: the gap counts arrive behind their own event while the pair pass runs
     if ((rc = ensure_gaps(c, true))) return rc;
     gaps_w.resize(n);
@@ -1134,14 +1144,14 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
         HIPCHK(c, c->gaps_w.reserve((size_t)n + 64));
         HIPCHK(c, c->h_i32.reserve((size_t)std::max(c->m, 2 * n) + 4));
         std::memcpy(c->h_i32.p, gaps_w.data(), sizeof(int32_t) * n);
-        HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream2));
+        HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, side));
         gw_dev = c->gaps_w.p;
-        if ((rc = sim_lists_enqueue(c, p->npos, gw_dev, c->stream2))) return rc;
+        if ((rc = sim_lists_enqueue(c, p->npos, gw_dev, side))) return rc;
     }
     SimOrder ord;
     if ((rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, false, &ord))) return rc;
-    if ((rc = sim_order_enqueue(c, ord, c->stream2))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    if ((rc = sim_order_enqueue(c, ord, side))) return rc;
+    if (forked) HIPCHK(c, hipEventRecord(c->ev_join, side));
     int *gate = nullptr;
     if (gated) {
         HIPCHK(c, c->row_avg.reserve(c->m + 64));
@@ -1151,7 +1161,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
         msak::launch_identity_stats(c->stream, c->ident.p, c->m, c->ldw, c->row_avg.p, c->row_max.p, c->stats2.p, nullptr, gate);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (c->rowtot_staged == 3) c->rowtot_staged = 1;  // (joined: a wait on the context's stream now covers the copy)
     if ((rc = sim_kernel_enqueue(c, p->npos, ord, false, gw_dev, gate))) return rc;
     if ((rc = fetch_similarity_enqueue(c, n))) return rc;

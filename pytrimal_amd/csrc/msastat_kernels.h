@@ -19,7 +19,8 @@ struct Tuning {
     int sim_serial = 0;        // MSA_SIM_SERIAL: numerator and denominator kernel on one stream
     int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
     int trace = 0;             // MSA_TRACE
-    int pipeline = 1;          // MSA_PIPELINE=0: msa_trim waits for the gap counts / identity statistics before it enqueues the similarity pass
+    int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
+                               // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)
     int bx_r0 = -1;            // MSA_BX_R0: rows evaluated in order before the first round (-1 = default)
     int bx_waves = 0;          // MSA_BX_WAVES: waves per workgroup of that kernel (0 = default)
@@ -28,6 +29,8 @@ struct Tuning {
     int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
     int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, 64: W rows by buffer loads, 128: by compiler-addressed global loads -- all with MSA_SIM_MODE=64 only; 2: eight waves per workgroup; 16: two columns per wave without wave priorities)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
+    int pair_pipe = 1;         // MSA_PAIR_PIPE=0: the pair-count loop as the compiler schedules it instead of the software-pipelined one
+    int pair_xcd = 1;          // MSA_PAIR_XCD=0: two-dimensional grid (half of its tiles return at once) instead of the triangle's tiles only
 };
 Tuning tuning_from_env();
 void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults

@@ -136,15 +136,88 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { return a | b | c; }
 
+// tile of a block: (i-block, j-block).  n_iblocks > 0: one-dimensional grid over the tiles that hold pairs (j > i)
+// only, j-block by j-block -- a two-dimensional grid launches as many tiles that return at once, and the waves that
+// do the work end up unevenly spread over the SIMDs (every active wave is resident from the start: the fullest SIMD
+// sets the time).  j-block y holds min(n_iblocks, (y + 1) R) tiles, R = 64 TJ / TI.
+template <int TI, int TJ>
+__device__ __forceinline__ void pair_tile(int n_iblocks, int &ib, int &jb) {
+    ib = blockIdx.x;
+    jb = blockIdx.y;
+    if (n_iblocks > 0) {
+        constexpr int R = 64 * TJ / TI;
+        const int t = blockIdx.x;
+        const int jc = (n_iblocks + R - 1) / R - 1;  // first j-block whose row of tiles is cut off at n_iblocks
+        const int pc = R * jc * (jc + 1) / 2;
+        if (t < pc) {
+            jb = (int)((sqrtf(8.0f * (float)t / (float)R + 1.0f) - 1.0f) * 0.5f);
+            while (R * jb * (jb + 1) / 2 > t) --jb;
+            while (R * (jb + 1) * (jb + 2) / 2 <= t) ++jb;
+            ib = t - R * jb * (jb + 1) / 2;
+        } else {
+            jb = jc + (t - pc) / n_iblocks;
+            ib = (t - pc) % n_iblocks;
+        }
+    }
+}
+
+// epilogue of a tile: row-wise (coalesced along j) and mirrored (TI contiguous values per lane).  miss[][] counted the
+// misses of all 32 * nchunk columns (the columns behind n are gaps in every row).
+template <int TI, int TJ>
+__device__ __forceinline__ void pair_epilogue(const uint32_t (&miss)[TJ][TI], const uint32_t (&dst)[TJ][TI], int i0, int j0, int lane,
+                                              int nchunk, int m, int ldw, uint32_t *__restrict__ hit_out,
+                                              uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                              float *__restrict__ wmat, float *__restrict__ wlow, int *__restrict__ undef_flag) {
+#pragma unroll
+    for (int u = 0; u < TJ; ++u) {
+        const int j = j0 + 64 * u + lane;
+        if (j >= m) continue;
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const int i = i0 + t;
+            if (i >= m) break;
+            const bool diag = (i == j);
+            const uint32_t h = diag ? 0u : 32u * (uint32_t)nchunk - miss[u][t], d = diag ? 0u : dst[u][t];
+            if (hit_out) {
+                hit_out[(size_t)i * m + j] = h;
+                hit_out[(size_t)j * m + i] = h;
+            }
+            if (dst_out) {
+                dst_out[(size_t)i * m + j] = d;
+                dst_out[(size_t)j * m + i] = d;
+            }
+            if (!diag && d == 0u && undef_flag) atomicOr(undef_flag, 1);  // no column holds a residue of either row
+            if (ident || wmat) {
+                const float r = d ? (float)h / (float)d : 0.0f;
+                if (ident) {
+                    const float v = diag ? 0.0f : r;
+                    ident[(size_t)i * ldw + j] = v;
+                    ident[(size_t)j * ldw + i] = v;
+                }
+                if (wmat && i != j) {  // strictly upper triangular: the similarity pass reads W[j][k], k > j
+                    const float v = 1.0f - r;
+                    if (i < j) wmat[(size_t)i * ldw + j] = v;
+                    else wmat[(size_t)j * ldw + i] = v;
+                    // the mirror image (strictly lower triangular) for the kernel whose lanes are the rows j
+                    if (wlow) wlow[(size_t)(i < j ? j : i) * ldw + (i < j ? i : j)] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int TI, int TJ>
 __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
                                                          int m, int ldw, uint32_t *__restrict__ hit_out,
                                                          uint32_t *__restrict__ dst_out, float *__restrict__ ident,
                                                          float *__restrict__ wmat, float *__restrict__ wlow,
-                                                         int *__restrict__ undef_flag) {
+                                                         int *__restrict__ undef_flag, int n_iblocks) {
     const int lane = threadIdx.x;
-    const int i0 = blockIdx.x * TI;  // uniform
-    const int j0 = blockIdx.y * (64 * TJ);
+    int ib, jb;
+    pair_tile<TI, TJ>(n_iblocks, ib, jb);
+    const int i0 = ib * TI;  // uniform
+    const int j0 = jb * (64 * TJ);
+    if (j0 >= m_pad) return;
     if (j0 + 64 * TJ - 1 <= i0) return;  // tile holds no pair with j > i: its mirror tile writes both halves
     uint32_t hit[TJ][TI], dst[TJ][TI];
 #pragma unroll
@@ -186,44 +259,124 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
             }
         }
     }
-    // epilogue: row-wise (coalesced along j) and mirrored (TI contiguous values per lane)
+    pair_epilogue<TI, TJ>(hit, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
+}
+
+// The same tile with the loads software-pipelined (TI = 8).  The loop above leaves the schedule to the compiler: the
+// eight plane words of the rows i arrive through scalar loads in four batches per chunk, each followed by a full
+// wait (scalar loads return out of order: only lgkmcnt(0) is safe), and the j planes are requested at the top of the
+// chunk that uses them -- at three to four waves per SIMD (m = 2000) the SIMDs idle half of the time.  Here:
+//   * the j planes of chunk c + 1 are requested while chunk c is computed (two register sets, the loop unrolled by two);
+//   * the i planes come in two groups of four planes (32 SGPRs each, as many as the plain loop uses): the validity
+//     plane + planes 0..2, then planes 3..6; a chunk is computed in two phases of 5 VALU instructions per pair, and
+//     each group is requested at the start of the phase BEFORE the one that uses it, right behind the wait for the
+//     other group -- one phase of the wave (and of the SIMD's other waves) covers its latency.
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+template <int TJ>
+__global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                              int m, int ldw, uint32_t *__restrict__ hit_out,
+                                                              uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                              float *__restrict__ wmat, float *__restrict__ wlow,
+                                                              int *__restrict__ undef_flag, int n_iblocks) {
+    constexpr int TI = 8;
+    typedef const __attribute__((address_space(4))) u32x8 *c8;
+    const int lane = threadIdx.x;
+    int ib, jb;
+    pair_tile<TI, TJ>(n_iblocks, ib, jb);
+    const int i0 = ib * TI;  // uniform
+    const int j0 = jb * (64 * TJ);
+    if (j0 >= m_pad) return;
+    if (j0 + 64 * TJ - 1 <= i0) return;
+    uint32_t miss[TJ][TI], dst[TJ][TI], d[TJ][TI];
 #pragma unroll
-    for (int u = 0; u < TJ; ++u) {
-        const int j = j0 + 64 * u + lane;
-        if (j >= m) continue;
+    for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int t = 0; t < TI; ++t) miss[u][t] = dst[u][t] = 0;
+    const size_t ps = (size_t)nchunk * m_pad;
+    const uint32_t *pj = planes + j0 + lane;
+    const uint32_t *pi = planes + i0;  // 32-byte aligned (i0 % 8 == 0, m_pad % 128 == 0)
+    struct Group {
+        u32x8 p[4];
+    };
+    auto request_a = [&](Group &g, int c) {  // validity plane, planes 0..2
+        const uint32_t *q = pi + (size_t)c * m_pad;
+        g.p[0] = *(c8)(uint64_t)(q + 7 * ps);
+        g.p[1] = *(c8)(uint64_t)(q);
+        g.p[2] = *(c8)(uint64_t)(q + ps);
+        g.p[3] = *(c8)(uint64_t)(q + 2 * ps);
+    };
+    auto request_b = [&](Group &g, int c) {  // planes 3..6
+        const uint32_t *q = pi + (size_t)c * m_pad + 3 * ps;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) g.p[p] = *(c8)(uint64_t)(q + p * ps);
+    };
+    // everything requested so far has arrived (nothing younger is in flight here).  `pin`: the results of the phase in
+    // front of the wait pass through it, so that the optimiser cannot sink that phase behind the wait (which would
+    // then follow its request at once)
+    auto arrived = [&](Group &g, uint32_t (&pin)[TJ][TI]) {
+        if constexpr (TJ == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+s"(g.p[3]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]),
+                           "+v"(pin[0][3]), "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+s"(g.p[3]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]),
+                           "+v"(pin[0][3]), "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]), "+v"(pin[TJ - 1][0]),
+                           "+v"(pin[TJ - 1][1]), "+v"(pin[TJ - 1][2]), "+v"(pin[TJ - 1][3]), "+v"(pin[TJ - 1][4]), "+v"(pin[TJ - 1][5]),
+                           "+v"(pin[TJ - 1][6]), "+v"(pin[TJ - 1][7]));
+    };
+    auto request_j = [&](uint32_t (&b)[TJ][8], int c) {
+        const size_t off = (size_t)c * m_pad;
+#pragma unroll
+        for (int u = 0; u < TJ; ++u)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) b[u][p] = pj[off + p * ps + 64 * u];
+    };
+    Group ga, gb;
+    uint32_t b0[TJ][8], b1[TJ][8];
+    auto step = [&](int c, uint32_t (&b)[TJ][8], uint32_t (&bn)[TJ][8]) {
+        arrived(ga, miss);  // group A of chunk c
+        request_b(gb, c);
+        request_j(bn, c + 1 < nchunk ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TI; ++t) {
-            const int i = i0 + t;
-            if (i >= m) break;
-            const bool diag = (i == j);
-            // (hit[][] counted the misses of all 32 * nchunk columns; the columns behind n are gaps in every row)
-            const uint32_t h = diag ? 0u : 32u * (uint32_t)nchunk - hit[u][t], d = diag ? 0u : dst[u][t];
-            if (hit_out) {
-                hit_out[(size_t)i * m + j] = h;
-                hit_out[(size_t)j * m + i] = h;
-            }
-            if (dst_out) {
-                dst_out[(size_t)i * m + j] = d;
-                dst_out[(size_t)j * m + i] = d;
-            }
-            if (!diag && d == 0u && undef_flag) atomicOr(undef_flag, 1);  // no column holds a residue of either row
-            if (ident || wmat) {
-                const float r = d ? (float)h / (float)d : 0.0f;
-                if (ident) {
-                    const float v = diag ? 0.0f : r;
-                    ident[(size_t)i * ldw + j] = v;
-                    ident[(size_t)j * ldw + i] = v;
-                }
-                if (wmat && i != j) {  // strictly upper triangular: the similarity pass reads W[j][k], k > j
-                    const float v = 1.0f - r;
-                    if (i < j) wmat[(size_t)i * ldw + j] = v;
-                    else wmat[(size_t)j * ldw + i] = v;
-                    // the mirror image (strictly lower triangular) for the kernel whose lanes are the rows j
-                    if (wlow) wlow[(size_t)(i < j ? j : i) * ldw + (i < j ? i : j)] = v;
-                }
+            const uint32_t vi = ga.p[0][t], nvi = ~vi;  // columns in which row i holds no residue never count as hits
+#pragma unroll
+            for (int u = 0; u < TJ; ++u) {
+                uint32_t x = __builtin_amdgcn_bitop3_b32(nvi, ga.p[1][t], b[u][0], 0xF6);  // x | (y ^ z)
+                x = __builtin_amdgcn_bitop3_b32(x, ga.p[2][t], b[u][1], 0xF6);
+                d[u][t] = __builtin_amdgcn_bitop3_b32(x, ga.p[3][t], b[u][2], 0xF6);
+                dst[u][t] += __builtin_popcount(vi | b[u][7]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the first phase must not sink below the wait: the wait would then follow its request at once)
+        arrived(gb, d);  // group B of chunk c
+        request_a(ga, c + 1 < nchunk ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+#pragma unroll
+            for (int u = 0; u < TJ; ++u) {
+                uint32_t x = __builtin_amdgcn_bitop3_b32(d[u][t], gb.p[0][t], b[u][3], 0xF6);
+                x = __builtin_amdgcn_bitop3_b32(x, gb.p[1][t], b[u][4], 0xF6);
+                x = __builtin_amdgcn_bitop3_b32(x, gb.p[2][t], b[u][5], 0xF6);
+                x = __builtin_amdgcn_bitop3_b32(x, gb.p[3][t], b[u][6], 0xF6);
+                miss[u][t] += __builtin_popcount(x);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request_a(ga, 0);
+    request_j(b0, 0);
+    int c = 0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (; c + 1 < nchunk; c += 2) {  // (no branch inside the body: one basic block, the order above is the order issued)
+        step(c, b0, b1);
+        step(c + 1, b1, b0);
     }
+    if (c < nchunk) step(c, b0, b1);
+    arrived(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
+    pair_epilogue<TI, TJ>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
 }
 
 // (the identity row statistics -- selectMethod's sequential float32 sums -- live in msastat_simx.hip: they are
@@ -1979,6 +2132,8 @@ Tuning tuning_from_env() {
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);
     t.pair_ti = num("MSA_PAIR_TI", 0);
+    t.pair_xcd = num("MSA_PAIR_XCD", 1);
+    t.pair_pipe = num("MSA_PAIR_PIPE", 1);
     t.bx_compact = num("MSA_BX_COMPACT", 0);
     t.bx_asm = num("MSA_BX_ASM", 0);
     t.lg_regs = num("MSA_LG_REGS", 0);
@@ -2018,9 +2173,25 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     const int ti = tuning().pair_ti == 16 || tuning().pair_ti == 32 ? tuning().pair_ti : PAIR_TI;
     const long waves2 = (long)((m + ti - 1) / ti) * (m_pad / 128) / 2;
     const bool two = waves2 >= 8192;
-    dim3 grid((m + ti - 1) / ti, two ? m_pad / 128 : m_pad / 64);
+    const int nib = (m + ti - 1) / ti, njb = two ? m_pad / 128 : m_pad / 64;
+    const bool xcd = tuning().pair_xcd != 0;
+    dim3 grid(nib, njb);
+    // Below the two-rows-per-lane size the kernel is short of waves (three to four per SIMD at m = 2000): there the
+    // triangle-only grid and the software-pipelined loop pay (0.46 -> 0.37 ms at 2000 x 10000, 0.088 -> 0.074 ms at
+    // 1000 x 4000); with TJ = 2 the plain loop is 4 % faster (tools/pairs_time.py).
+    const bool lean = !two && ti == PAIR_TI;
+    if (xcd && lean) {
+        const int R = 64 * (two ? 2 : 1) / ti, jc = (nib + R - 1) / R - 1;
+        grid = dim3((unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib), 1);
+    }
+    const int nib_arg = xcd && lean ? nib : 0;
+    if ((lean && tuning().pair_pipe != 0) || (ti == PAIR_TI && tuning().pair_pipe == 2)) {  // (2: also with TJ = 2 -- diagnostics)
+        if (two) pair_counts_pipe_kernel<2><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib_arg);
+        else pair_counts_pipe_kernel<1><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib_arg);
+        return;
+    }
 #define PAIR_LAUNCH(TI_, TJ_) \
-    pair_counts_kernel<TI_, TJ_><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag)
+    pair_counts_kernel<TI_, TJ_><<<grid, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib_arg)
     if (ti == 32) {
         if (two) PAIR_LAUNCH(32, 2);
         else PAIR_LAUNCH(32, 1);

@@ -34,7 +34,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
-                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE"):
+                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -270,6 +270,38 @@ def test_c4_full_size_pair_counts(ctx):
     hits = np.where(is_gap, ng[None, :] - 1, np.where(is_x, nx[None, :] - 1, (m - ng - nx)[None, :] - 1))
     want = (hits >= need).sum(axis=1).astype(np.float32) / np.float32(n)
     assert np.array_equal(bits(ov), bits(want))
+
+
+@pytest.mark.parametrize("pipe,tri", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1"), ("2", "1")])
+@pytest.mark.parametrize("shape", [(2, 5), (9, 33), (65, 64), (130, 31), (513, 97), (700, 300), (1030, 70)])
+def test_pair_kernel_variants(ctx_with, pipe, tri, shape):
+    """the software-pipelined pair-count loop and the triangle-only grid against the plain ones and the oracle
+    (odd and even chunk counts, rows that end inside a tile)"""
+    m, n = shape
+    a = synth_msa(m, n, 300 + m)
+    ohit, odst = oracle.pair_counts(a, ord("X"))
+    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_XCD=tri)
+    ctx.upload(a, ord("X"))
+    hit, dst = ctx.pair_counts()
+    assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
+    ident, w = ctx.identities()
+    assert np.array_equal(bits(ident), bits(oracle.identities(ohit, odst)))
+    assert np.array_equal(bits(w), bits(oracle.weights(ohit, odst)))
+
+
+@pytest.mark.parametrize("pipe", ["0", "1", "2"])
+def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe):
+    """m large enough for two rows j per lane (TJ = 2): row slices against the oracle"""
+    m, n = 4300, 40
+    a = synth_msa(m, n, 77)
+    ctx = ctx_with(MSA_PAIR_PIPE=pipe)
+    ctx.upload(a, ord("X"))
+    hit, dst = ctx.pair_counts()
+    assert np.array_equal(hit, hit.T) and np.array_equal(dst, dst.T)
+    for rows in (np.r_[0:70], np.r_[2100:2200], np.r_[4200:4300], np.arange(5, m, 61)):
+        ohit, odst = oracle.pair_counts(a[rows], ord("X"))
+        assert np.array_equal(hit[np.ix_(rows, rows)], ohit)
+        assert np.array_equal(dst[np.ix_(rows, rows)], odst)
 
 
 def _sim_parity(ctx, a, indet=ord("X")):

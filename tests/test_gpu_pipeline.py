@@ -17,9 +17,10 @@ ALPHA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 
 @pytest.fixture
 def contexts(monkeypatch):
-    """(pipelined, serial) contexts: the switch is read when a context is created"""
+    """(pipelined, serial, pipelined with the side stream at any size) contexts: the switch is read when a context is
+    created"""
     made = []
-    for value in ("1", "0"):
+    for value in ("1", "0", "3"):
         monkeypatch.setenv("MSA_PIPELINE", value)
         made.append(_lib.Context(0))
     monkeypatch.delenv("MSA_PIPELINE")
