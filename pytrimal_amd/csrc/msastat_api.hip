@@ -197,15 +197,21 @@ int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
     } while (0)
 
 // flag words of the state block
-enum { ST_ERRFLAG = 0, ST_PAIRFLAG = 1, ST_ERRKEY = 2 /* 2 words */, ST_STATS = 4 /* 2 floats */, ST_GATE = 6, ST_WORDS = 16 };
+enum {
+    ST_ERRFLAG = 0, ST_PAIRFLAG = 1, ST_ERRKEY = 2 /* 2 words */, ST_STATS = 4 /* 2 floats */, ST_GATE = 6,
+    ST_USED = 8 /* 4 words: the byte values that occur in the alignment, for the pair pass's dense codes (prep_planes) */,
+    ST_FLAGS = 16 /* the words fetched with every wait */,
+    ST_USED_SLOTS = 16 /* 128 words: the copies of that set that gap_counts fills */,
+    ST_WORDS = 160
+};
 
 // Every wait on the context's stream goes through here: it fetches the flag words when a kernel that may have raised
 // one ran since the last fetch (one 64-byte copy in front of the wait) and settles the asynchronous fetches above.
 static int sync_stream(msa_ctx *c) {
     if (c->flags_dirty && c->state.p) {
-        hipError_t e = c->h_flags.reserve(ST_WORDS);
+        hipError_t e = c->h_flags.reserve(ST_FLAGS);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(c->h_flags.p, c->state.p, ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(c->h_flags.p, c->state.p, ST_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
         if (e != hipSuccess) return fail_hip(c, e, "flag fetch");
         c->flags_dirty = false;
     }
@@ -315,15 +321,20 @@ int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
     return MSA_OK;
 }
 
+int ensure_gaps(msa_ctx *c, bool to_host);
+
 int ensure_planes(msa_ctx *c) {
     if (c->have_planes) return MSA_OK;
-    HIPCHK(c, c->planes.reserve((size_t)8 * c->nchunk * c->m_pad + 64));
-    int rc = ensure_state(c);
+    HIPCHK(c, c->planes.reserve((size_t)msak::planes_total() * c->nchunk * c->m_pad + 64));
+    // (the dense codes of the planes are ranks in the set of byte values that gap_counts collects: that pass first)
+    const bool dense = msak::pair_dense(c->m);
+    int rc = dense ? ensure_gaps(c, false) : ensure_state(c);
     if (rc) return rc;
     {
         ProfScope ps(c, "prep");
-        msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad,
-                                 c->errflag.p);
+        msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad, c->errflag.p,
+                                 dense ? reinterpret_cast<const uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr,
+                                 reinterpret_cast<uint32_t *>(c->state.p + ST_USED));
     }
     HIPCHK(c, hipGetLastError());
     // the non-ASCII verdict comes back with the next synchronisation of the stream (sync_stream): every caller
@@ -348,7 +359,8 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
         if (rc) return rc;
         {
             ProfScope ps(c, "gaps");
-            msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p);
+            msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p,
+                                    msak::pair_dense(c->m) ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
         }
         HIPCHK(c, hipGetLastError());
         c->have_gaps = true;
@@ -421,7 +433,8 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
                                  want_counts ? c->hit.p : nullptr, want_counts ? c->dst.p : nullptr,
                                  need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr,
-                                 c->pairflag.p);
+                                 c->pairflag.p,
+                                 msak::pair_dense(c->m) ? reinterpret_cast<const uint32_t *>(c->state.p + ST_USED) : nullptr);
     }
     HIPCHK(c, hipGetLastError());
     c->flags_dirty = true;

@@ -29,6 +29,7 @@ struct Tuning {
     int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
     int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, 64: W rows by buffer loads, 128: by compiler-addressed global loads -- all with MSA_SIM_MODE=64 only; 2: eight waves per workgroup; 16: two columns per wave without wave priorities)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
+    int pair_dense = 1;        // MSA_PAIR_DENSE: 0 the pair pass always on the seven raw symbol planes, 1 dense codes from 1500 sequences on, 2 always
     int pair_pipe = 1;         // MSA_PAIR_PIPE=0: the pair-count loop as the compiler schedules it instead of the software-pipelined one
     int pair_xcd = 1;          // MSA_PAIR_XCD=0: two-dimensional grid (half of its tiles return at once) instead of the triangle's tiles only
 };
@@ -42,11 +43,15 @@ constexpr int PAIR_TI = 8;   // rows "i" per wave in pair_counts (wave-uniform, 
 constexpr int PAIR_TJ = 2;   // rows "j" per lane at most (1 below ~3000 rows: twice the waves, 0.77 -> 0.52 ms at 2000 x 10000); m_pad % 128 == 0
 
 void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
-                        int nchunk, int m_pad, int *err_flag);
+                        int nchunk, int m_pad, int *err_flag, const uint32_t *used_slots, uint32_t *used_out);
+int used_slot_words();  // words of the copies of the byte-value set that gap_counts fills and prep_planes folds into used_out[4]
+// used: the copies (used_slot_words() zeroed words), nullptr: not collected
 void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
-                       int32_t *indets);
+                       int32_t *indets, uint32_t *used);
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag);
+                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag, const uint32_t *used);
+bool pair_dense(int m);  // the pair pass of an m-sequence alignment runs on dense residue codes (MSA_PAIR_DENSE=0: never, 2: always)
+int planes_total();  // planes in the plane array (raw + validity + dense codes as "j" and as "i")
 // binade-exact similarity kernel (msastat_simx.hip)
 int64_t bx_ldk(int m);
 int bx_cols_pad(int n);

@@ -41,18 +41,69 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
     return ~(t | v | 0x7f7f7f7fu);
 }
 
+// Dense residue codes.  The pair pass compares symbols plane by plane; raw bytes have seven planes, but an alignment
+// uses a few dozen symbols at most.  gap_counts records which byte values occur (`used`: 128 bits); the rank of a
+// byte among the used values is its dense code, K = their number, and K itself is the code the rows "i" of the pair
+// pass carry wherever they hold no residue -- a code no row "j" has, so such a column is a mismatch without the
+// validity plane entering the comparison.  NP = 5 planes serve K <= 31 symbols (proteins with gaps, X, B, Z, ...),
+// 6 planes K <= 63; beyond that (NP = 0) the pair pass works on the raw planes.
+// Plane array: [0..6] raw symbol planes (written only when NP = 0), [7] validity, [8..13] dense codes of the rows as
+// "j", [14..19] dense codes of the rows as "i".
+constexpr int DENSE_J0 = 8, DENSE_I0 = 14, PLANES_TOTAL = 20;
+__device__ __forceinline__ void dense_set(const uint32_t *__restrict__ used, uint32_t (&w)[4], int &K, int &NP, int force_raw) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = used[i];
+    w[1] |= 1u << ('-' - 32);  // (the columns behind n are stored as gaps)
+    K = __builtin_popcount(w[0]) + __builtin_popcount(w[1]) + __builtin_popcount(w[2]) + __builtin_popcount(w[3]);
+    NP = force_raw ? 0 : (K + 1 <= 32 ? 5 : (K + 1 <= 64 ? 6 : 0));
+}
+
 __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restrict__ raw, int m, int n,
                                                           int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
-                                                          int nchunk, int m_pad, int *__restrict__ err_flag) {
+                                                          int nchunk, int m_pad, int *__restrict__ err_flag,
+                                                          const uint32_t *__restrict__ used_slots,
+                                                          uint32_t *__restrict__ used_out, int force_raw) {
+    __shared__ uint8_t lut[128];  // byte -> dense code
     const int row = blockIdx.x * 256 + threadIdx.x;  // < m_pad
     const int cpair = blockIdx.y;                    // 64-column group
-    if (row >= m_pad) return;
-    uint32_t out[2][8];
+    int K = 0, NP = 0;
+    if (used_slots) {
+        // fold gap_counts' copies of the set: word q of copy s sits at 4 s + q
+        __shared__ uint32_t folded[2][4];
+        if (threadIdx.x < 128) {
+            uint32_t v = used_slots[threadIdx.x];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+            for (int off = 4; off < 64; off <<= 1) v |= __shfl_xor(v, off, 64);
+            if ((threadIdx.x & 63) < 4) folded[threadIdx.x >> 6][threadIdx.x & 3] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            folded[0][threadIdx.x] |= folded[1][threadIdx.x];
+            if (blockIdx.x == 0 && blockIdx.y == 0) used_out[threadIdx.x] = folded[0][threadIdx.x];  // for the pair pass
+        }
+        __syncthreads();
+        const uint32_t *used = folded[0];
+        uint32_t w[4];
+        dense_set(used, w, K, NP, force_raw);
+        if (NP && threadIdx.x < 128) {
+            const int k = threadIdx.x, q = k >> 5;
+            int rank = __builtin_popcount(w[q] & ((1u << (k & 31)) - 1u));
+            for (int i = 0; i < q; ++i) rank += __builtin_popcount(w[i]);
+            lut[k] = (uint8_t)rank;
+        }
+        __syncthreads();
+    }
+    if (row >= m_pad) return;
+    uint32_t out[2][8], outj[2][6], outi[2][6];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) out[h][p] = 0;
-    if (row < m) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) outj[h][p] = outi[h][p] = 0;
+    }
+    const uint32_t k4 = (uint32_t)K * 0x01010101u;
+    if (row < m) {  // (the rows behind m stay zero in every plane: the pair pass computes them and writes nothing)
         const uint4 *src = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld + (size_t)cpair * 64);
         uint32_t bad = 0;
 #pragma unroll
@@ -72,8 +123,20 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
                 uint32_t inval = zero_bytes(x ^ 0x2d2d2d2du) | zero_bytes(x ^ indet4);  // 0x80 flags
                 uint32_t vbits = gather_bit4(~inval, 7);
                 const int h = q >> 1, sh = ((q & 1) * 4 + e) * 4;
+                if (NP) {
+                    const uint32_t cj = (uint32_t)lut[x & 127u] | ((uint32_t)lut[(x >> 8) & 127u] << 8) |
+                                        ((uint32_t)lut[(x >> 16) & 127u] << 16) | ((uint32_t)lut[(x >> 24) & 127u] << 24);
+                    const uint32_t im = (inval >> 7) * 0xFFu;  // 0xFF in the bytes that hold no residue
+                    const uint32_t ci = (cj & ~im) | (k4 & im);
 #pragma unroll
-                for (int p = 0; p < 7; ++p) out[h][p] |= gather_bit4(x, p) << sh;
+                    for (int p = 0; p < 6; ++p) {
+                        outj[h][p] |= gather_bit4(cj, p) << sh;
+                        outi[h][p] |= gather_bit4(ci, p) << sh;
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 7; ++p) out[h][p] |= gather_bit4(x, p) << sh;
+                }
                 out[h][7] |= vbits << sh;
             }
         }
@@ -84,8 +147,17 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
     for (int h = 0; h < 2; ++h) {
         const int chunk = cpair * 2 + h;
         if (chunk < nchunk) {
+            const size_t at = (size_t)chunk * m_pad + row;
+            if (NP) {
+                planes[7 * pstride + at] = out[h][7];
+                for (int p = 0; p < NP; ++p) {
+                    planes[(DENSE_J0 + p) * pstride + at] = outj[h][p];
+                    planes[(DENSE_I0 + p) * pstride + at] = outi[h][p];
+                }
+            } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) planes[p * pstride + (size_t)chunk * m_pad + row] = out[h][p];
+                for (int p = 0; p < 8; ++p) planes[p * pstride + at] = out[h][p];
+            }
         }
     }
 }
@@ -97,31 +169,88 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
 // HBM-bound: reads m*n bytes once.
 // ------------------------------------------------------------------------------------------
 constexpr int GAP_SLAB = 64;
+constexpr int USED_SLOTS = 32;  // copies of the 128-bit set of byte values that gap_counts fills (see there)
 
+// `used` != nullptr: the set of byte values that occur in columns < n is OR-ed into used[0..3] (bit b of the 128 = byte
+// value b & 127; bytes >= 0x80 are an error that prep_planes reports).  Every thread keeps the three set words of the
+// printable values in registers: per byte one shift (1 << (b & 31)), one sign-extending bit-field extract per word
+// (all ones when bits 6..5 of the byte name that word) and one three-input boolean; a byte below 0x20 marks all of
+// word 0 (a superset is as good as the set: codes stay distinct).  Measured alternatives: one LDS byte flag per
+// value (same-address stores serialise: 12 -> 42 us at 2000 x 10000), per-thread words in LDS updated with ds_or
+// (64 -> 72 us).
 __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
                                                          uint32_t indet4, int32_t *__restrict__ gaps,
-                                                         int32_t *__restrict__ indets) {
+                                                         int32_t *__restrict__ indets, uint32_t *__restrict__ used) {
+    uint32_t seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;
     const int c4 = blockIdx.x * 256 + threadIdx.x;  // dword column
-    if ((int64_t)c4 * 4 >= ld) return;
-    const int r0 = blockIdx.y * GAP_SLAB;
-    const int r1 = min(m, r0 + GAP_SLAB);
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)r0 * ld) + c4;
-    const size_t stride = (size_t)(ld >> 2);
-    uint32_t accg = 0, acci = 0;
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) {
-        uint32_t x = *p;
-        p += stride;
-        accg += zero_bytes(x ^ 0x2d2d2d2du) >> 7;
-        acci += zero_bytes(x ^ indet4) >> 7;
-    }
+    const bool active = (int64_t)c4 * 4 < ld;
+    if (active) {
+        const int r0 = blockIdx.y * GAP_SLAB;
+        const int r1 = min(m, r0 + GAP_SLAB);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)r0 * ld) + c4;
+        const size_t stride = (size_t)(ld >> 2);
+        const int inside = used ? max(0, min(4, n - c4 * 4)) : 0;  // bytes of this dword column in front of column n
+        uint32_t accg = 0, acci = 0;
+        // (0xFF in the bytes in front of column n: the others must not enter the set)
+        const uint32_t imask = inside >= 4 ? 0xFFFFFFFFu : (inside <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - inside))));
+        auto take = [&](uint32_t x) {
+            accg += zero_bytes(x ^ 0x2d2d2d2du) >> 7;
+            acci += zero_bytes(x ^ indet4) >> 7;
+            if (used) {  // (uniform)
+                const uint32_t h = x >> 1;
+                // bit 5 of a byte of y_s: bits 6..5 of that byte of x are s (binary 11 / 10 / 01)
+                const uint32_t y3 = x & h & imask, y2 = ~x & h & imask, y1 = x & ~h & imask;
+                seen0 |= zero_bytes(x & 0x60606060u) & imask;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c4 * 4 + k;
-        if (c < n) {
-            uint32_t g = (accg >> (8 * k)) & 0xFFu, x = (acci >> (8 * k)) & 0xFFu;
-            if (g) atomicAdd(&gaps[c], (int)g);
-            if (x) atomicAdd(&indets[c], (int)x);
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t bit = 1u << ((x >> (8 * k)) & 31u);
+                    // truth table 0xF8 = a | (b & c)
+                    seen1 = __builtin_amdgcn_bitop3_b32(seen1, bit, (uint32_t)__builtin_amdgcn_sbfe(y1, 8 * k + 5, 1), 0xF8);
+                    seen2 = __builtin_amdgcn_bitop3_b32(seen2, bit, (uint32_t)__builtin_amdgcn_sbfe(y2, 8 * k + 5, 1), 0xF8);
+                    seen3 = __builtin_amdgcn_bitop3_b32(seen3, bit, (uint32_t)__builtin_amdgcn_sbfe(y3, 8 * k + 5, 1), 0xF8);
+                }
+            }
+        };
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {  // eight rows requested before the first is looked at
+            uint32_t xs[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xs[i] = p[(size_t)i * stride];
+            p += 8 * stride;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) take(xs[i]);
+        }
+        for (; r < r1; ++r) {
+            take(*p);
+            p += stride;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 * 4 + k;
+            if (c < n) {
+                uint32_t g = (accg >> (8 * k)) & 0xFFu, x = (acci >> (8 * k)) & 0xFFu;
+                if (g) atomicAdd(&gaps[c], (int)g);
+                if (x) atomicAdd(&indets[c], (int)x);
+            }
+        }
+    }
+    if (used) {
+        // block union, then one atomic per word into one of USED_SLOTS copies of the set (all waves of the launch are
+        // resident at once: with a single copy their atomics queue up on one cache line for tens of microseconds);
+        // prep_planes folds the copies
+        __shared__ uint32_t red[4][4];
+        uint32_t v[4] = {seen0 ? 0xFFFFFFFFu : 0u, seen1, seen2, seen3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[q] |= __shfl_xor(v[q], off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const uint32_t u = red[0][threadIdx.x] | red[1][threadIdx.x] | red[2][threadIdx.x] | red[3][threadIdx.x];
+            uint32_t *slot = used + 4 * ((blockIdx.x + blockIdx.y * gridDim.x) % USED_SLOTS) + threadIdx.x;
+            if (u & ~__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(slot, u);
         }
     }
 }
@@ -206,20 +335,10 @@ __device__ __forceinline__ void pair_epilogue(const uint32_t (&miss)[TJ][TI], co
     }
 }
 
+// the loop over the chunks of a tile on the raw planes, as the compiler schedules it
 template <int TI, int TJ>
-__global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
-                                                         int m, int ldw, uint32_t *__restrict__ hit_out,
-                                                         uint32_t *__restrict__ dst_out, float *__restrict__ ident,
-                                                         float *__restrict__ wmat, float *__restrict__ wlow,
-                                                         int *__restrict__ undef_flag, int n_iblocks) {
-    const int lane = threadIdx.x;
-    int ib, jb;
-    pair_tile<TI, TJ>(n_iblocks, ib, jb);
-    const int i0 = ib * TI;  // uniform
-    const int j0 = jb * (64 * TJ);
-    if (j0 >= m_pad) return;
-    if (j0 + 64 * TJ - 1 <= i0) return;  // tile holds no pair with j > i: its mirror tile writes both halves
-    uint32_t hit[TJ][TI], dst[TJ][TI];
+__device__ __forceinline__ void pair_loop_plain(const uint32_t *__restrict__ planes, int nchunk, int m_pad, int i0, int j0, int lane,
+                                                uint32_t (&hit)[TJ][TI], uint32_t (&dst)[TJ][TI]) {
 #pragma unroll
     for (int u = 0; u < TJ; ++u)
 #pragma unroll
@@ -259,6 +378,23 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
             }
         }
     }
+}
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                         int m, int ldw, uint32_t *__restrict__ hit_out,
+                                                         uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                         float *__restrict__ wmat, float *__restrict__ wlow,
+                                                         int *__restrict__ undef_flag, int n_iblocks) {
+    const int lane = threadIdx.x;
+    int ib, jb;
+    pair_tile<TI, TJ>(n_iblocks, ib, jb);
+    const int i0 = ib * TI;  // uniform
+    const int j0 = jb * (64 * TJ);
+    if (j0 >= m_pad) return;
+    if (j0 + 64 * TJ - 1 <= i0) return;  // tile holds no pair with j > i: its mirror tile writes both halves
+    uint32_t hit[TJ][TI], dst[TJ][TI];
+    pair_loop_plain<TI, TJ>(planes, nchunk, m_pad, i0, j0, lane, hit, dst);
     pair_epilogue<TI, TJ>(hit, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
 }
 
@@ -377,6 +513,131 @@ __global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__
     if (c < nchunk) step(c, b0, b1);
     arrived(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
     pair_epilogue<TI, TJ>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
+}
+
+// The pair pass on dense codes (see prep_planes): NP symbol planes instead of seven and no validity term in the
+// comparison -- per pair and 32 columns  xor + (NP - 1) bitop3 + bcnt  for the misses and  or + bcnt  for the columns
+// that count: 8 VALU instructions at NP = 5 against 11 on the raw planes.  Same software pipeline as above: group A =
+// validity + code planes 0, 1 of the rows i, group B = the remaining code planes; TI = 8 rows i x 64 rows j per wave,
+// one-dimensional grid over the triangle's tiles.  The number of planes is only known on the device (`used`, filled by
+// gap_counts): the kernel branches once; with more than 62 symbols in the alignment it runs the plain loop on the
+// raw planes (prep_planes has then written those).
+template <int NP>
+__device__ __forceinline__ void pair_loop_dense(const uint32_t *__restrict__ planes, int nchunk, int m_pad, int i0, int j0, int lane,
+                                                uint32_t (&miss)[1][8], uint32_t (&dst)[1][8]) {
+    constexpr int TI = 8, NB = NP - 2;  // NB planes in group B
+    typedef const __attribute__((address_space(4))) u32x8 *c8;
+    uint32_t d[1][TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) miss[0][t] = dst[0][t] = 0;
+    const size_t ps = (size_t)nchunk * m_pad;
+    // (per-lane pointers: six 64-bit additions per chunk on the vector unit.  Wave-uniform bases with the lane as a
+    // 32-bit offset would move them to the scalar unit, but the loop already uses every SGPR: 28 instead of 12
+    // instructions per two chunks once the spills are counted)
+    const uint32_t *pjv = planes + 7 * ps + j0 + lane;          // validity of the rows j
+    const uint32_t *pj = planes + DENSE_J0 * ps + j0 + lane;    // their codes
+    const uint32_t *piv = planes + 7 * ps + i0;                 // 32-byte aligned (i0 % 8 == 0, m_pad % 128 == 0)
+    const uint32_t *pi = planes + DENSE_I0 * ps + i0;
+    struct GroupA {
+        u32x8 p[3];
+    };
+    struct GroupB {
+        u32x8 p[NB];
+    };
+    auto request_a = [&](GroupA &g, int c) {
+        const size_t off = (size_t)c * m_pad;
+        g.p[0] = *(c8)(uint64_t)(piv + off);
+        g.p[1] = *(c8)(uint64_t)(pi + off);
+        g.p[2] = *(c8)(uint64_t)(pi + off + ps);
+    };
+    auto request_b = [&](GroupB &g, int c) {
+        const uint32_t *q = pi + (size_t)c * m_pad + 2 * ps;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) g.p[p] = *(c8)(uint64_t)(q + p * ps);
+    };
+    // (the results of the phase in front of a wait pass through it: see pair_counts_pipe_kernel)
+    auto arrived_a = [&](GroupA &g, uint32_t (&pin)[1][TI]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]), "+v"(pin[0][3]),
+                       "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]));
+    };
+    auto arrived_b = [&](GroupB &g, uint32_t (&pin)[1][TI]) {
+        if constexpr (NB == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]), "+v"(pin[0][3]),
+                           "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+s"(g.p[NB - 1]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]),
+                           "+v"(pin[0][3]), "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]));
+    };
+    auto request_j = [&](uint32_t (&b)[NP + 1], int c) {
+        const size_t off = (size_t)c * m_pad;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) b[p] = pj[off + p * ps];
+        b[NP] = pjv[off];
+    };
+    GroupA ga;
+    GroupB gb;
+    uint32_t b0[NP + 1], b1[NP + 1];
+    auto step = [&](int c, uint32_t (&b)[NP + 1], uint32_t (&bn)[NP + 1]) {
+        arrived_a(ga, miss);  // group A of chunk c
+        request_b(gb, c);
+        request_j(bn, c + 1 < nchunk ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const uint32_t x = ga.p[1][t] ^ b[0];
+            d[0][t] = __builtin_amdgcn_bitop3_b32(x, ga.p[2][t], b[1], 0xF6);  // x | (y ^ z)
+            dst[0][t] += __builtin_popcount(ga.p[0][t] | b[NP]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        arrived_b(gb, d);  // group B of chunk c
+        request_a(ga, c + 1 < nchunk ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            uint32_t x = d[0][t];
+#pragma unroll
+            for (int p = 0; p < NB; ++p) x = __builtin_amdgcn_bitop3_b32(x, gb.p[p][t], b[2 + p], 0xF6);
+            miss[0][t] += __builtin_popcount(x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request_a(ga, 0);
+    request_j(b0, 0);
+    int c = 0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (; c + 1 < nchunk; c += 2) {
+        step(c, b0, b1);
+        step(c + 1, b1, b0);
+    }
+    if (c < nchunk) step(c, b0, b1);
+    arrived_a(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
+}
+
+__global__ __launch_bounds__(64) void pair_counts_dense_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad, int m,
+                                                               int ldw, uint32_t *__restrict__ hit_out,
+                                                               uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                               float *__restrict__ wmat, float *__restrict__ wlow,
+                                                               int *__restrict__ undef_flag, int n_iblocks,
+                                                               const uint32_t *__restrict__ used) {
+    constexpr int TI = 8;
+    const int lane = threadIdx.x;
+    int ib, jb;
+    pair_tile<TI, 1>(n_iblocks, ib, jb);
+    const int i0 = ib * TI, j0 = jb * 64;
+    if (j0 >= m_pad) return;
+    if (j0 + 63 <= i0) return;
+    uint32_t w[4];
+    int K, NP;
+    dense_set(used, w, K, NP, 0);
+    NP = __builtin_amdgcn_readfirstlane(NP);
+    uint32_t miss[1][TI], dst[1][TI];
+    if (NP == 5) pair_loop_dense<5>(planes, nchunk, m_pad, i0, j0, lane, miss, dst);
+    else if (NP == 6) pair_loop_dense<6>(planes, nchunk, m_pad, i0, j0, lane, miss, dst);
+    else pair_loop_plain<TI, 1>(planes, nchunk, m_pad, i0, j0, lane, miss, dst);
+    pair_epilogue<TI, 1>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
 }
 
 // (the identity row statistics -- selectMethod's sequential float32 sums -- live in msastat_simx.hip: they are
@@ -2134,6 +2395,7 @@ Tuning tuning_from_env() {
     t.pair_ti = num("MSA_PAIR_TI", 0);
     t.pair_xcd = num("MSA_PAIR_XCD", 1);
     t.pair_pipe = num("MSA_PAIR_PIPE", 1);
+    t.pair_dense = num("MSA_PAIR_DENSE", 1);
     t.bx_compact = num("MSA_BX_COMPACT", 0);
     t.bx_asm = num("MSA_BX_ASM", 0);
     t.lg_regs = num("MSA_LG_REGS", 0);
@@ -2155,19 +2417,36 @@ int set_max_lds_once(const void *kernel, int bytes) {
 }
 
 void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
-                        int nchunk, int m_pad, int *err_flag) {
+                        int nchunk, int m_pad, int *err_flag, const uint32_t *used_slots, uint32_t *used_out) {
     dim3 grid((m_pad + 255) / 256, (nchunk + 1) / 2);
-    prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag);
+    prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag, used_slots, used_out, 0);
 }
+int used_slot_words() { return 4 * USED_SLOTS; }
+// Dense codes pay from about 1500 sequences on (collecting the byte values and writing two sets of code planes cost
+// ~25 us: 3.36 -> 3.31 ms per trim at 2000 x 10000, 1.137 -> 1.12 ms at 5000 x 5000, but 0.344 -> 0.355 ms at
+// 500 x 2000); MSA_PAIR_DENSE=2 forces them at any size.
+bool pair_dense(int m) {
+    if (tuning().pair_ti == 16 || tuning().pair_ti == 32) return false;
+    return tuning().pair_dense == 2 || (tuning().pair_dense == 1 && m >= 1500);
+}
+int planes_total() { return PLANES_TOTAL; }
 
 void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
-                       int32_t *indets) {
+                       int32_t *indets, uint32_t *used) {
     dim3 grid((unsigned)((ld / 4 + 255) / 256), (m + GAP_SLAB - 1) / GAP_SLAB);
-    gap_counts_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), gaps, indets);
+    gap_counts_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), gaps, indets, used);
 }
 
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag) {
+                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag, const uint32_t *used) {
+    if (used) {
+        // dense codes (prep_planes was given the same `used`): 8 rows i x 64 rows j per wave, the triangle's tiles only
+        const int nib = (m + PAIR_TI - 1) / PAIR_TI, njb = m_pad / 64;
+        const int R = 64 / PAIR_TI, jc = (nib + R - 1) / R - 1;
+        const unsigned tiles = (unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib);
+        pair_counts_dense_kernel<<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib, used);
+        return;
+    }
     // Two rows "j" per lane reuse the wave-uniform "i" words twice, but halve the number of waves: worth it only
     // once the upper triangle still holds several waves per SIMD (m >= ~3000); m_pad is a multiple of 128.
     const int ti = tuning().pair_ti == 16 || tuning().pair_ti == 32 ? tuning().pair_ti : PAIR_TI;

@@ -34,7 +34,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
-                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI"):
+                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI", "MSA_PAIR_DENSE"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -272,15 +272,15 @@ def test_c4_full_size_pair_counts(ctx):
     assert np.array_equal(bits(ov), bits(want))
 
 
-@pytest.mark.parametrize("pipe,tri", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1"), ("2", "1")])
+@pytest.mark.parametrize("pipe,tri,dense", [("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"), ("1", "1", "0"), ("2", "1", "0"), ("1", "1", "2")])
 @pytest.mark.parametrize("shape", [(2, 5), (9, 33), (65, 64), (130, 31), (513, 97), (700, 300), (1030, 70)])
-def test_pair_kernel_variants(ctx_with, pipe, tri, shape):
+def test_pair_kernel_variants(ctx_with, pipe, tri, dense, shape):
     """the software-pipelined pair-count loop and the triangle-only grid against the plain ones and the oracle
     (odd and even chunk counts, rows that end inside a tile)"""
     m, n = shape
     a = synth_msa(m, n, 300 + m)
     ohit, odst = oracle.pair_counts(a, ord("X"))
-    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_XCD=tri)
+    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_XCD=tri, MSA_PAIR_DENSE=dense)
     ctx.upload(a, ord("X"))
     hit, dst = ctx.pair_counts()
     assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
@@ -289,12 +289,12 @@ def test_pair_kernel_variants(ctx_with, pipe, tri, shape):
     assert np.array_equal(bits(w), bits(oracle.weights(ohit, odst)))
 
 
-@pytest.mark.parametrize("pipe", ["0", "1", "2"])
-def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe):
-    """m large enough for two rows j per lane (TJ = 2): row slices against the oracle"""
+@pytest.mark.parametrize("pipe,dense", [("0", "0"), ("1", "0"), ("2", "0"), ("1", "1"), ("1", "2")])
+def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe, dense):
+    """m large enough for two rows j per lane on the raw planes (TJ = 2): row slices against the oracle"""
     m, n = 4300, 40
     a = synth_msa(m, n, 77)
-    ctx = ctx_with(MSA_PAIR_PIPE=pipe)
+    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_DENSE=dense)
     ctx.upload(a, ord("X"))
     hit, dst = ctx.pair_counts()
     assert np.array_equal(hit, hit.T) and np.array_equal(dst, dst.T)
@@ -302,6 +302,38 @@ def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe):
         ohit, odst = oracle.pair_counts(a[rows], ord("X"))
         assert np.array_equal(hit[np.ix_(rows, rows)], ohit)
         assert np.array_equal(dst[np.ix_(rows, rows)], odst)
+
+
+def _alphabet_case(m, n, letters, seed):
+    r = np.random.default_rng(seed)
+    alpha = np.frombuffer(letters, dtype=np.uint8)
+    a = alpha[r.integers(0, len(alpha), (m, n))].copy()
+    a[r.random((m, n)) < 0.15] = ord("-")
+    a[r.random((m, n)) < 0.03] = ord("X")
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("letters", [b"AC", b"ACDEFGHIKLMNPQRSTVWY", b"ACDEFGHIKLMNPQRSTVWYBZJUO*.?",  # <= 31 symbols: 5 planes
+                                     b"ACDEFGHIKLMNPQRSTVWYacdefghiklmnpqrstvwy",                      # 6 planes
+                                     bytes(range(33, 127))])                                         # raw planes
+@pytest.mark.parametrize("shape", [(70, 200), (300, 97)])
+def test_pair_counts_dense_codes_by_alphabet_size(ctx_with, letters, shape):
+    """the pair pass picks its number of code planes from the byte values that occur: 5, 6, or the raw seven"""
+    m, n = shape
+    a = _alphabet_case(m, n, letters, len(letters) + m)
+    ohit, odst = oracle.pair_counts(a, ord("X"))
+    for dense in ("2", "0"):
+        ctx = ctx_with(MSA_PAIR_DENSE=dense)
+        for _ in range(2):
+            ctx.upload(a, ord("X"))
+            hit, dst = ctx.pair_counts()
+            assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
+        # a second alignment with another alphabet on the same context (the set is collected per alignment)
+        b = _alphabet_case(m, n, b"ACGT", 5)
+        ctx.upload(b, ord("X"))
+        hit, dst = ctx.pair_counts()
+        bhit, bdst = oracle.pair_counts(b, ord("X"))
+        assert np.array_equal(hit, bhit) and np.array_equal(dst, bdst)
 
 
 def _sim_parity(ctx, a, indet=ord("X")):
