@@ -998,14 +998,14 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     rc = ungapped_lengths(c, lengths);
     if (rc) return rc;
     const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
-    const size_t words = msak::cluster_adj_words(m);
-    HIPCHK(c, c->pairs.reserve((size_t)m + 64));
-    HIPCHK(c, c->col_ok.reserve((size_t)m * words + 64));
+    HIPCHK(c, c->pairs.reserve((size_t)2 * m + 64));
+    HIPCHK(c, c->col_ok.reserve(msak::cluster_adj_buffer_words(m) + 64));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
     HIPCHK(c, c->equal.reserve(4));
-    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(2 * m, 2 * c->n) + 4));
     std::memcpy(c->h_i32.p, seq_at.data(), sizeof(int32_t) * m);
-    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+    for (int t = 0; t < m; ++t) c->h_i32.p[m + seq_at[t]] = t;  // the inverse: where each sequence stands in the order
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->equal.p, 0, sizeof(int32_t), c->stream));
     {
         ProfScope ps(c, "cluster");
@@ -1057,13 +1057,14 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     if (clusters == m) threshold = 1;
     if (clusters == 1) threshold = 0;
     const std::vector<int32_t> seq_at = msah::processing_order(lengths.data(), m);
-    HIPCHK(c, c->pairs.reserve((size_t)m + 64));
-    HIPCHK(c, c->col_ok.reserve((size_t)m * words + 64));
+    HIPCHK(c, c->pairs.reserve((size_t)2 * m + 64));
+    HIPCHK(c, c->col_ok.reserve(msak::cluster_adj_buffer_words(m) + 64));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
     HIPCHK(c, c->equal.reserve(4));
-    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * c->n) + 4));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(2 * m, 2 * c->n) + 4));
     std::memcpy(c->h_i32.p, seq_at.data(), sizeof(int32_t) * m);
-    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+    for (int t = 0; t < m; ++t) c->h_i32.p[m + seq_at[t]] = t;  // the inverse: where each sequence stands in the order
+    HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice, c->stream));
     float previous = 0, stalled = 0;
     for (;;) {
         HIPCHK(c, hipMemsetAsync(c->equal.p, 0, sizeof(int32_t), c->stream));

@@ -103,6 +103,7 @@ void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, int32_t *lengths,
                        unsigned long long *hashes);
 size_t cluster_adj_words(int m);
+size_t cluster_adj_buffer_words(int m);  // what launch_cluster's `adj` must hold
 int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *seq_at, int m, float thr, uint32_t *adj,
                    uint8_t *keep_seq, int32_t *count);
 void launch_rows_equal(hipStream_t s, const uint8_t *raw, int n, int64_t ld, const int32_t *pairs, int npairs,

@@ -2289,26 +2289,35 @@ __global__ __launch_bounds__(64) void rows_equal_kernel(const uint8_t *__restric
 // adjacency words are stored WORD-major (adj[w * m + t]: word w of vertex t), so that the threads of the clustering
 // kernel -- one vertex each, all walking the words in step -- read consecutive addresses.
 __global__ __launch_bounds__(256) void cluster_adjacency_kernel(const float *__restrict__ ident, int ldw,
-                                                                const int32_t *__restrict__ seq_at, int m, float thr,
-                                                                uint32_t *__restrict__ adj, int words) {
-    const int t = blockIdx.x * 256 + threadIdx.x;  // processing index of the row vertex
-    const int w = blockIdx.y;                      // word of earlier vertices
-    if (t >= m) return;
+                                                                const int32_t *__restrict__ seq_at,
+                                                                const int32_t *__restrict__ pos_of, int m, float thr,
+                                                                uint32_t *__restrict__ adj, int words,
+                                                                uint32_t *__restrict__ nz) {
+    // A thread owns the SEQUENCE col (its vertex is t = pos_of[col], the inverse of seq_at): the 256 threads of a block
+    // then read 256 consecutive floats of row seq_at[u] (ident is symmetric) -- with a thread per processing index
+    // the same reads were a gather inside the row, 16 times the bytes (99 -> 23 us at m = 5000).  The word is stored
+    // at the vertex's place, a scattered 4-byte store per thread.
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int w = blockIdx.y;  // word of earlier vertices
+    if (col >= m) return;
+    const int t = pos_of[col];
     uint32_t bits = 0;
     if (w * 32 < t) {  // (only earlier vertices u < t are kept)
-        const int col = seq_at[t];
-#pragma unroll 4
+#pragma unroll 8
         for (int b = 0; b < 32; ++b) {
             const int u = w * 32 + b;
-            // ident is symmetric: row seq_at[u] is shared by the 256 threads of the block
             if (u < t) bits |= (ident[(size_t)seq_at[u] * ldw + col] > thr ? 1u : 0u) << b;
         }
     }
     adj[(size_t)w * m + t] = bits;
+    // which words of vertex t hold a bit at all (bit w % 32 of nz[(w / 32) * m + t], zeroed by the launcher): the
+    // clustering kernel walks those instead of every word -- its loads depend on one another, and with few or no
+    // pairs above the threshold nearly every word is empty
+    if (bits) atomicOr(&nz[(size_t)(w >> 5) * m + t], 1u << (w & 31));
 }
 
-__global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__restrict__ adj, int m, int words,
-                                                           const int32_t *__restrict__ seq_at,
+__global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__restrict__ adj, const uint32_t *__restrict__ nz,
+                                                           int m, int words, const int32_t *__restrict__ seq_at,
                                                            uint8_t *__restrict__ keep_seq, int32_t *__restrict__ count) {
     extern __shared__ uint32_t sets[];  // rep[2][words], undec[2][words]
     uint32_t *rep = sets, *undec = sets + 2 * words;
@@ -2335,11 +2344,16 @@ __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__res
         for (int t = threadIdx.x; t < m; t += 1024) {
             if (!((uc[t >> 5] >> (t & 31)) & 1u)) continue;
             int verdict = 1;  // 1 = REP, 0 = NON-REP, -1 = blocked by an undecided earlier neighbour
-            for (int w = 0; w <= (t >> 5); ++w) {
-                const uint32_t a = adj[(size_t)w * m + t];
-                if (!a) continue;
-                if (a & rc[w]) { verdict = 0; break; }
-                if (a & uc[w]) verdict = -1;
+            // (the adjacency kernel keeps bits of earlier vertices only: every marked word is <= t / 32)
+            for (int g = 0; g <= (t >> 10) && verdict; ++g) {
+                uint32_t marked = nz[(size_t)g * m + t];
+                while (marked) {
+                    const int w = g * 32 + __builtin_ctz(marked);
+                    marked &= marked - 1;
+                    const uint32_t a = adj[(size_t)w * m + t];
+                    if (a & rc[w]) { verdict = 0; break; }
+                    if (a & uc[w]) verdict = -1;
+                }
             }
             if (verdict == 1) atomicOr(&rn[t >> 5], 1u << (t & 31));
             if (verdict >= 0) atomicAnd(&un[t >> 5], ~(1u << (t & 31)));
@@ -2622,15 +2636,20 @@ void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 }
 
 size_t cluster_adj_words(int m) { return (size_t)((m + 31) / 32); }
+// words of the adjacency buffer: the bit sets and, behind them, the map of their non-empty words
+size_t cluster_adj_buffer_words(int m) { return (size_t)m * (cluster_adj_words(m) + (cluster_adj_words(m) + 31) / 32); }
 
+// seq_at: the processing order [m] followed by its inverse [m] (position of every sequence in that order)
 int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *seq_at, int m, float thr, uint32_t *adj,
                    uint8_t *keep_seq, int32_t *count) {
     const int words = (int)cluster_adj_words(m);
     const size_t lds = (size_t)4 * words * sizeof(uint32_t);
     if (lds > 60 * 1024) return -1;  // caller falls back to the host path
     dim3 grid((m + 255) / 256, words);
-    cluster_adjacency_kernel<<<grid, 256, 0, s>>>(ident, ldw, seq_at, m, thr, adj, words);
-    cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, m, words, seq_at, keep_seq, count);
+    uint32_t *nz = adj + (size_t)m * words;
+    if (hipMemsetAsync(nz, 0, (size_t)m * ((words + 31) / 32) * sizeof(uint32_t), s) != hipSuccess) return -2;
+    cluster_adjacency_kernel<<<grid, 256, 0, s>>>(ident, ldw, seq_at, seq_at + m, m, thr, adj, words, nz);
+    cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, nz, m, words, seq_at, keep_seq, count);
     return 0;
 }
 
