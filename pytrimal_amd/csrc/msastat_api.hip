@@ -166,6 +166,8 @@ struct msa_ctx {
     bool planes_pending = false;   // prep_planes' non-ASCII flag has not been looked at yet
     PinBuf<int32_t> h_gapstage;    // gap / indetermination counts on their way to h_gaps / h_indets
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
+    PinBuf<int32_t> h_colcnt;      // residues per column over the sequences the device clustering kept (stage_kept_column_counts)
+    bool colcnt_staged = false;
     PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
     int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete, 3 enqueued on the side stream (not joined yet)
     bool pipe_active = false, pipe_gated = false;  // msa_trim's similarity pipeline is in flight (see sim_pipeline_begin)
@@ -288,6 +290,7 @@ void invalidate(msa_ctx *c) {
     c->h_indets.clear();
     c->state_zeroed = false;
     c->flags_dirty = false;
+    c->colcnt_staged = false;
 }
 
 // the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)
@@ -887,15 +890,41 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_i
             if (keep_res[j] && c->h_gaps[j] == m) keep_res[j] = 0;
         return MSA_OK;
     }
-    std::memcpy(c->h_u8.p, keep_seq, m);
-    HIPCHK(c, hipMemcpyAsync(c->keep_seq_d.p, c->h_u8.p, m, hipMemcpyHostToDevice, c->stream));
+    const int32_t *col_counts = c->h_i32.p;
+    if (c->colcnt_staged && rows_safe) {
+        // counted on the device behind the clustering, over the very mask that came back (no row was dropped since)
+        col_counts = c->h_colcnt.p;
+    } else {
+        std::memcpy(c->h_u8.p, keep_seq, m);
+        HIPCHK(c, hipMemcpyAsync(c->keep_seq_d.p, c->h_u8.p, m, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
+        msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+        SYNC(c);
+    }
+    c->colcnt_staged = false;
+    for (int j = 0; j < n; ++j)
+        if (keep_res[j] && col_counts[j] == 0) keep_res[j] = 0;
+    return MSA_OK;
+}
+
+// Residues per column over the sequences the device clustering keeps, enqueued behind it (keep_seq_d is its output):
+// remove_all_gaps needs them when sequences were dropped, and would otherwise send the mask back and wait once more.
+// Only when no sequence is empty (every ungapped length > 0): then remove_all_gaps cannot drop a sequence itself and
+// the mask it counts over is the one the clustering produced.
+int stage_kept_column_counts(msa_ctx *c, const std::vector<int32_t> &lengths) {
+    c->colcnt_staged = false;
+    for (int32_t len : lengths)
+        if (len <= 0) return MSA_OK;
+    const int m = c->m, n = c->n;
+    HIPCHK(c, c->col_cnt.reserve((size_t)n + 64));
+    HIPCHK(c, c->h_colcnt.reserve((size_t)n + 4));
     HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
     msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    SYNC(c);
-    for (int j = 0; j < n; ++j)
-        if (keep_res[j] && c->h_i32.p[j] == 0) keep_res[j] = 0;
+    HIPCHK(c, hipMemcpyAsync(c->h_colcnt.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    c->colcnt_staged = true;
     return MSA_OK;
 }
 
@@ -1014,6 +1043,7 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
             return MSA_E_FALLBACK;  // too many sequences for the LDS bit sets: host path
     }
     HIPCHK(c, hipGetLastError());
+    if ((rc = stage_kept_column_counts(c, lengths))) return rc;
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
     HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
     SYNC(c);
@@ -1090,6 +1120,7 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
             ++stalled;
         }
     }
+    if ((rc = stage_kept_column_counts(c, lengths))) return rc;
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
     HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
     SYNC(c);
@@ -1249,7 +1280,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
-    c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release();
+    c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release(); c->h_colcnt.release();
     if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
     if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
     if (c->ev_rowtot) (void)hipEventDestroy(c->ev_rowtot);
@@ -1420,6 +1451,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     TuneScope tune(c);
     c->order_ready = false;
     c->pipe_active = false;
+    c->colcnt_staged = false;
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
