@@ -208,6 +208,8 @@ int msa_trim(msa_ctx *ctx, const msa_trim_params *params, uint8_t *keep_res, uin
  * "overlap".  Returns MSA_E_INVALID for an unknown name. */
 int msa_prof_get(msa_ctx *ctx, const char *kernel, float *ms_total, int32_t *launches);
 void msa_prof_reset(msa_ctx *ctx);
+/* enable: 0 off; 1 an event pair around every kernel group; 2 around the similarity and the pair pass only (each pair
+ * costs a few microseconds of queue time per trim) */
 void msa_prof_enable(msa_ctx *ctx, int enable);
 
 #ifdef __cplusplus

@@ -296,7 +296,8 @@ class Context:
 
     # --- instrumentation ---
     def prof_enable(self, on=True):
-        self.lib.msa_prof_enable(self.h, 1 if on else 0)
+        # True / 1: every kernel group; 2: the similarity and pair passes only (cheaper: see msa_prof_enable); False / 0: off
+        self.lib.msa_prof_enable(self.h, int(on))
 
     def prof_reset(self):
         self.lib.msa_prof_reset(self.h)

@@ -176,7 +176,7 @@ struct msa_ctx {
     std::vector<int32_t> h_gaps, h_indets;
 
     // profiling
-    bool prof_on = false;
+    int prof_on = 0;  // 0 off, 1 every kernel group, 2 the similarity and pair passes only
     std::map<std::string, ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
 };
@@ -241,14 +241,18 @@ struct ProfScope {  // records an event pair around a launch sequence when profi
     const char *name;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
+    bool on_ = false;
     ProfScope(msa_ctx *ctx, const char *nm, hipStream_t on = nullptr) : c(ctx), name(nm), st(on ? on : ctx->stream) {
-        if (!c->prof_on) return;
+        // level 2: the two pairwise passes only (an event pair costs a few microseconds of queue time: seven pairs per
+        // trim are ~10 % of a 0.33 ms trim)
+        on_ = c->prof_on == 1 || (c->prof_on == 2 && (std::strcmp(nm, "sim") == 0 || std::strcmp(nm, "pairs") == 0));
+        if (!on_) return;
         a = take();
         b = take();
         (void)hipEventRecord(a, st);
     }
     ~ProfScope() {
-        if (!c->prof_on) return;
+        if (!on_) return;
         (void)hipEventRecord(b, st);
         ProfEntry &e = c->prof[name];
         e.pending.emplace_back(a, b);
@@ -1681,7 +1685,7 @@ void msa_prof_reset(msa_ctx *c) {
 }
 
 void msa_prof_enable(msa_ctx *c, int enable) {
-    if (c) c->prof_on = enable != 0;
+    if (c) c->prof_on = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
 }
 
 }  // extern "C"

@@ -2436,12 +2436,18 @@ void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t
     prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag, used_slots, used_out, 0);
 }
 int used_slot_words() { return 4 * USED_SLOTS; }
-// Dense codes pay from about 1500 sequences on (collecting the byte values and writing two sets of code planes cost
-// ~25 us: 3.36 -> 3.31 ms per trim at 2000 x 10000, 1.137 -> 1.12 ms at 5000 x 5000, but 0.344 -> 0.355 ms at
-// 500 x 2000); MSA_PAIR_DENSE=2 forces them at any size.
+// Dense codes pay between about 1500 and 4000 sequences.  Collecting the byte values and writing two sets of code
+// planes cost ~25 us, more than the pair pass gains below that (0.344 -> 0.355 ms per trim at 500 x 2000; 3.22 ->
+// 3.19 ms at 2000 x 10000); from ~4100 sequences on the raw planes are walked with two rows j per lane and a trim that
+// needs no gap counts otherwise (RepresentativeTrimmer) would run gap_counts for the byte values alone: the pair pass
+// itself gets faster (0.73 -> 0.67 ms at 5000 x 5000) but the trim does not (0.866 -> 0.875 ms).
+// MSA_PAIR_DENSE=2 forces dense codes at any size, 0 never (profiles/r02_ab_switches.txt, r02_pairs_time.jsonl).
 bool pair_dense(int m) {
     if (tuning().pair_ti == 16 || tuning().pair_ti == 32) return false;
-    return tuning().pair_dense == 2 || (tuning().pair_dense == 1 && m >= 1500);
+    if (tuning().pair_dense == 2) return true;
+    const int m_pad = ((m > 1 ? m : 1) + 20 + 127) / 128 * 128;
+    const bool two_rows = (long)((m + PAIR_TI - 1) / PAIR_TI) * (m_pad / 128) / 2 >= 8192;  // as launch_pair_counts decides
+    return tuning().pair_dense == 1 && m >= 1500 && !two_rows;
 }
 int planes_total() { return PLANES_TOTAL; }
 

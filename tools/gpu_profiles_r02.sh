@@ -25,7 +25,12 @@ cd $ROOT
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wstream tools/ubench_wstream.hip && timeout 120 /tmp/ubench_wstream > $OUT/ubench_wstream.txt 2>&1
 timeout 300 python tools/lg_sweep.py 2>/dev/null | grep "^{" > $OUT/lg_sweep.jsonl
 for k in "" q2 bx; do MSA_SIM_KERNEL=$k timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms | sed "s/^{/{\"kernel\": \"${k:-lg}\", /"; done > $OUT/bx_stamps.jsonl
-ls $OUT | head -40
+timeout 300 python tools/pairs_time.py 2>/dev/null | grep "^{" > $OUT/pairs_time.jsonl
+for sw in MSA_PAIR_DENSE=1,0 MSA_PIPELINE=1,0; do timeout 300 python tools/step_overheads.py C3 C2 C4 C5 --switch $sw 2>/dev/null | grep "ms/step"; done > $OUT/ab_switches.txt
+bash tools/gpu_pmc_pairs.sh > $OUT/pmc_pairs.txt 2>/dev/null
+bash tools/gpu_timeline.sh > /dev/null 2>&1
+for w in C3 C2 C4; do cp $ROOT/gpurun_out/tl/timeline_$w.txt $OUT/ 2>/dev/null; done
+ls $OUT | head -60
 # keep only the small csv files (the merge back is limited to 64 MiB)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 du -sh $OUT

@@ -25,7 +25,8 @@ def counters(d):
 
 family = {  # kernel -> the name bench.py's roofline uses
     "msak::similarity_bx_kernel": "sim", "msak::similarity_lg_kernel": "sim", "msak::similarity_lg_regs_kernel": "sim",
-    "msak::similarity_lg2_kernel": "sim", "msak::lg2_union_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::gap_counts_kernel": "gaps",
+    "msak::similarity_lg2_kernel": "sim", "msak::lg2_union_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::pair_counts_pipe_kernel": "pairs",
+    "msak::pair_counts_dense_kernel": "pairs", "msak::gap_counts_kernel": "gaps",
     "msak::prep_planes_kernel": "prep", "msak::identity_rows_kernel": "idstats", "msak::sim_encode_cm_kernel": "encode",
     "msak::bx_compact_kernel": "encode", "msak::cluster_mis_kernel": "cluster", "msak::cluster_adjacency_kernel": "cluster",
 }
@@ -94,7 +95,8 @@ open(os.path.join(DST, "r02_pmc_sq.txt"), "w").write("\n".join(out) + "\n")
 ub = os.path.join(SRC, "ubench_wstream.txt")
 if os.path.exists(ub):
     shutil.copy(ub, os.path.join(DST, "r02_ubench_wstream.txt"))
-for name in ("lg_sweep.jsonl", "bx_stamps.jsonl"):
+for name in ("lg_sweep.jsonl", "bx_stamps.jsonl", "pairs_time.jsonl", "ab_switches.txt", "pmc_pairs.txt", "timeline_C3.txt",
+             "timeline_C2.txt", "timeline_C4.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r02_" + name))
 print("\n".join(lines[-40:]))
