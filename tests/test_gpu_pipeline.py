@@ -168,3 +168,21 @@ def test_repeated_similarity_on_one_alignment(contexts):
                 holed[0] = -1
                 with pytest.raises(ValueError):
                     ctx.similarity(holed, dist)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_random_trims_against_the_oracle(seed):
+    """tools/fuzz_trim.py: random shapes, compositions and trimmer settings through msa_trim under six switch settings
+    (default, serial flow, side stream at any size, dense pair codes at any size, the raw pair loops) against the oracle's
+    trim: masks, the selected method and the identity mean, and errors raised exactly where the oracle raises."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_trim.py"), "8", str(seed)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mismatch"] is False and line["cases"] > 100

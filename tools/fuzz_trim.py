@@ -1,0 +1,133 @@
+"""Randomised whole-trim check: random shapes, compositions, alphabets and trimmer settings through msa_trim (contexts under
+the default switches, the serial flow, the side stream at any size, dense pair codes at any size, the raw pair loops) against
+the oracle's trim -- masks, selected method, identity means, cut points.
+  python tools/fuzz_trim.py [seconds=120] [seed=1]      (prints one JSON line; exit code 1 on the first mismatch)"""
+import ctypes, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+import oracle
+from pytrimal_amd import _lib
+from pytrimal_amd.matrix import SimilarityMatrix
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a strict trim must raise where the oracle does
+
+CONTEXTS = [dict(), dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_PAIR_DENSE="2"), dict(MSA_PAIR_DENSE="0", MSA_PAIR_PIPE="0"),
+            dict(MSA_PAIR_DENSE="0", MSA_PAIR_XCD="0")]
+ctxs = []
+for env in CONTEXTS:
+    for k in ("MSA_PIPELINE", "MSA_PAIR_DENSE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ctxs.append(_lib.Context(0))
+for k in ("MSA_PIPELINE", "MSA_PAIR_DENSE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD"):
+    os.environ.pop(k, None)
+
+mx = SimilarityMatrix.aa()
+vhash = np.ascontiguousarray(mx._vhash, dtype=np.int32)
+dist = np.ascontiguousarray(mx._dist, dtype=np.float32)
+
+
+def alignment():
+    m = int(rng.choice([2, 3, 7, 21, 40, 64, 65, 130, 300, 700])) + int(rng.integers(0, 9))
+    n = int(rng.choice([1, 5, 31, 33, 64, 100, 257, 600, 1500])) + int(rng.integers(0, 7))
+    keep = float(rng.choice([0.2, 0.45, 0.6, 0.7, 0.85, 0.97]))
+    root = AA[rng.integers(0, 20, n)]
+    a = np.where(rng.random((m, n)) < keep, root[None, :], AA[rng.integers(0, 20, (m, n))])
+    style = rng.integers(0, 4)
+    if style == 0:
+        g = rng.beta(0.6, 1.8, n)
+    elif style == 1:
+        g = np.full(n, 0.02)
+    elif style == 2:
+        g = np.where(rng.random(n) < 0.3, 0.9, 0.05)
+    else:
+        g = rng.random(n)
+    a[rng.random((m, n)) < g[None, :]] = ord("-")
+    a[(rng.random((m, n)) < 0.01) & (a != ord("-"))] = ord("X")
+    if rng.random() < 0.15:  # whole rows / columns of gaps
+        a[rng.integers(0, m)] = ord("-")
+        a[:, rng.integers(0, n)] = ord("-")
+    if rng.random() < 0.1:  # lower case and rare letters
+        sel = rng.random((m, n)) < 0.05
+        a[sel & (a >= 65) & (a <= 90)] += 32
+    if rng.random() < 0.05:
+        a[rng.integers(0, m), rng.integers(0, n)] = EXTRA[rng.integers(0, len(EXTRA))]
+    if rng.random() < 0.1 and m > 4:  # duplicated rows
+        a[rng.integers(0, m)] = a[rng.integers(0, m)]
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def settings(m, n):
+    kind = rng.integers(0, 10)
+    if kind < 4:
+        return dict(method=str(rng.choice(["automated1", "strict", "strictplus", "gappyout", "nogaps", "noallgaps", "noduplicateseqs"])))
+    if kind < 8:
+        kw = {}
+        if rng.random() < 0.7:
+            kw["gap_threshold"] = float(rng.choice([0.1, 0.5, 0.8, 0.95]))
+        if rng.random() < 0.7 or not kw:
+            kw["similarity_threshold"] = float(rng.choice([0.05, 0.2, 0.5, 0.8]))
+        if rng.random() < 0.4:
+            kw["conservation_percentage"] = float(rng.choice([20, 50, 80]))
+        if rng.random() < 0.3 and n >= 16:
+            kw[str(rng.choice(["window", "gap_window", "similarity_window"]))] = int(rng.integers(1, max(2, min(6, n // 4))))
+        return kw
+    if kind == 8 and m >= 2:
+        return dict(identity_threshold=float(rng.choice([0.2, 0.4, 0.6, 0.9]))) if rng.random() < 0.6 else dict(clusters=int(rng.integers(1, m + 1)))
+    return dict(residue_overlap=float(rng.choice([0.3, 0.6, 0.9])), sequence_overlap=float(rng.choice([20, 50, 80])))
+
+
+def params_of(kw):
+    p = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, vhash.ctypes.data, dist.ctypes.data, len(mx))
+    if "method" in kw:
+        p.method = _lib.METHOD_CODES[kw["method"]]
+    if "gap_threshold" in kw:
+        p.gap_threshold = float(np.float32(1) - np.float32(kw["gap_threshold"]))
+    for name in ("similarity_threshold", "conservation_percentage", "window", "gap_window", "similarity_window", "residue_overlap",
+                 "sequence_overlap", "clusters"):
+        if name in kw:
+            setattr(p, name, kw[name])
+    if "identity_threshold" in kw:
+        p.max_identity = kw["identity_threshold"]
+    return p
+
+
+t0 = time.time()
+cases = raised = 0
+while time.time() - t0 < budget:
+    a = alignment()
+    m, n = a.shape
+    kw = settings(m, n)
+    try:
+        res, seq, oinfo = oracle.trim(a, indet=ord("X"), matrix=(vhash, dist), **kw)
+        expect = None
+    except oracle.OracleError as e:
+        expect = e
+    p = params_of(kw)
+    for ctx, env in zip(ctxs, CONTEXTS):
+        ctx.upload(a, ord("X"))
+        try:
+            keep_res, keep_seq, info = ctx.trim(p)
+            got = None
+        except Exception as e:  # noqa: BLE001
+            got = e
+        ok = (expect is None) == (got is None)
+        if ok and expect is None:
+            ok = np.array_equal(keep_res, res) and np.array_equal(keep_seq, seq)
+            if ok and kw.get("method") == "automated1" and m > 1:
+                ok = info.selected_method == oinfo.selected and np.float32(info.avg_seq).view(np.uint32) == np.float32(oinfo.avg_seq).view(np.uint32)
+        if not ok:
+            print(json.dumps({"mismatch": True, "case": cases, "seed": seed, "shape": [m, n], "settings": kw, "context": env,
+                              "oracle_raised": repr(expect), "device_raised": repr(got)}))
+            np.save(os.path.join(ROOT, "gpurun_out", "fuzz_failure.npy"), a) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
+            sys.exit(1)
+    cases += 1
+    raised += expect is not None
+print(json.dumps({"mismatch": False, "cases": cases, "contexts_per_case": len(ctxs), "cases_where_both_raise": int(raised),
+                  "seconds": round(time.time() - t0, 1), "seed": seed}))
