@@ -168,6 +168,7 @@ struct msa_ctx {
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
     PinBuf<int32_t> h_colcnt;      // residues per column over the sequences the device clustering kept (stage_kept_column_counts)
     bool colcnt_staged = false;
+    bool byteset_ready = false;    // a pass over the bytes that collects their values is in the context's stream (gap counts or row totals)
     PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
     int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete, 3 enqueued on the side stream (not joined yet)
     bool pipe_active = false, pipe_gated = false;  // msa_trim's similarity pipeline is in flight (see sim_pipeline_begin)
@@ -295,6 +296,7 @@ void invalidate(msa_ctx *c) {
     c->state_zeroed = false;
     c->flags_dirty = false;
     c->colcnt_staged = false;
+    c->byteset_ready = false;
 }
 
 // the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)
@@ -334,8 +336,9 @@ int ensure_planes(msa_ctx *c) {
     if (c->have_planes) return MSA_OK;
     HIPCHK(c, c->planes.reserve((size_t)msak::planes_total() * c->nchunk * c->m_pad + 64));
     // (the dense codes of the planes are ranks in the set of byte values that gap_counts collects: that pass first)
+    // ... or the row totals, when they ran on this stream and the gap counts have not run (RepresentativeTrimmer)
     const bool dense = msak::pair_dense(c->m);
-    int rc = dense ? ensure_gaps(c, false) : ensure_state(c);
+    int rc = dense && !c->byteset_ready ? ensure_gaps(c, false) : ensure_state(c);
     if (rc) return rc;
     {
         ProfScope ps(c, "prep");
@@ -366,8 +369,10 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
         if (rc) return rc;
         {
             ProfScope ps(c, "gaps");
+            const bool collect = msak::pair_dense(c->m) && !c->byteset_ready;
             msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p,
-                                    msak::pair_dense(c->m) ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
+                                    collect ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
+            c->byteset_ready |= collect;
         }
         HIPCHK(c, hipGetLastError());
         c->have_gaps = true;
@@ -831,7 +836,17 @@ int stage_row_totals(msa_ctx *c, hipStream_t st = nullptr) {
     const int m = c->m, n = c->n;
     HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
     HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
-    msak::launch_row_nongap(st, c->raw, m, n, c->ld, nullptr, c->row_cnt.p);  // (no mask: every column counts)
+    // (no mask: every column counts.  On the context's stream this pass also collects the byte values for the pair
+    // pass's dense codes if nothing has yet: a trim that needs no gap counts then runs no gap_counts for them)
+    bool collect = false;
+    if (!side && msak::pair_dense(m) && !c->byteset_ready) {
+        int rc = ensure_state(c);
+        if (rc) return rc;
+        collect = true;
+    }
+    msak::launch_row_nongap(st, c->raw, m, n, c->ld, nullptr, c->row_cnt.p,
+                            collect ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
+    c->byteset_ready |= collect;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
     if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));

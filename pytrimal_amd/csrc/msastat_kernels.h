@@ -29,7 +29,7 @@ struct Tuning {
     int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
     int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, 64: W rows by buffer loads, 128: by compiler-addressed global loads -- all with MSA_SIM_MODE=64 only; 2: eight waves per workgroup; 16: two columns per wave without wave priorities)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
-    int pair_dense = 1;        // MSA_PAIR_DENSE: 0 the pair pass always on the seven raw symbol planes, 1 dense codes between 1500 and ~4000 sequences, 2 always
+    int pair_dense = 1;        // MSA_PAIR_DENSE: 0 the pair pass always on the seven raw symbol planes, 1 dense codes from 1500 sequences on, 2 always
     int pair_pipe = 1;         // MSA_PAIR_PIPE=0: the pair-count loop as the compiler schedules it instead of the software-pipelined one
     int pair_xcd = 1;          // MSA_PAIR_XCD=0: two-dimensional grid (half of its tiles return at once) instead of the triangle's tiles only
 };
@@ -96,8 +96,9 @@ int launch_similarity_pc(hipStream_t s, const void *codes32, int m, int n, int64
                          const void *tab, int npos, const int32_t *gaps_w, float *q_out, float *mdk_out, int tcols);
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
                     const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good);
+// used != nullptr: also collects the byte values of the alignment (as launch_gap_counts does)
 void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,
-                       int32_t *row_nongap);
+                       int32_t *row_nongap, uint32_t *used = nullptr);
 void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,
                        int32_t *col_nongap);
 void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, int32_t *lengths,

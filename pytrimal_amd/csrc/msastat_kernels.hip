@@ -169,7 +169,46 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
 // HBM-bound: reads m*n bytes once.
 // ------------------------------------------------------------------------------------------
 constexpr int GAP_SLAB = 64;
-constexpr int USED_SLOTS = 32;  // copies of the 128-bit set of byte values that gap_counts fills (see there)
+constexpr int USED_SLOTS = 32;  // copies of the 128-bit set of byte values that gap_counts / row_nongap fill (see gap_counts)
+
+// the set of byte values a thread has seen (see gap_counts)
+struct ByteSet {
+    uint32_t low = 0, w1 = 0, w2 = 0, w3 = 0;  // low: some byte below 0x20; w_s: bit (b & 31) for the bytes with bits 6..5 = s
+};
+// imask: 0xFF in the bytes of x that count
+__device__ __forceinline__ void byteset_add(ByteSet &b, uint32_t x, uint32_t imask) {
+    const uint32_t h = x >> 1;
+    // bit 5 of a byte of y_s: bits 6..5 of that byte of x are s (binary 11 / 10 / 01)
+    const uint32_t y3 = x & h & imask, y2 = ~x & h & imask, y1 = x & ~h & imask;
+    b.low |= zero_bytes(x & 0x60606060u) & imask;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t bit = 1u << ((x >> (8 * k)) & 31u);
+        // truth table 0xF8 = a | (b & c)
+        b.w1 = __builtin_amdgcn_bitop3_b32(b.w1, bit, (uint32_t)__builtin_amdgcn_sbfe(y1, 8 * k + 5, 1), 0xF8);
+        b.w2 = __builtin_amdgcn_bitop3_b32(b.w2, bit, (uint32_t)__builtin_amdgcn_sbfe(y2, 8 * k + 5, 1), 0xF8);
+        b.w3 = __builtin_amdgcn_bitop3_b32(b.w3, bit, (uint32_t)__builtin_amdgcn_sbfe(y3, 8 * k + 5, 1), 0xF8);
+    }
+}
+// Block union (256 threads, all of them call), then one atomic per word into one of USED_SLOTS copies of the set: all
+// waves of a launch are resident at once, and with a single copy their atomics queue up on one cache line for tens of
+// microseconds.  prep_planes folds the copies.
+__device__ __forceinline__ void byteset_publish(const ByteSet &b, uint32_t *__restrict__ used, unsigned block) {
+    __shared__ uint32_t red[4][4];
+    uint32_t v[4] = {b.low ? 0xFFFFFFFFu : 0u, b.w1, b.w2, b.w3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[q] |= __shfl_xor(v[q], off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t u = red[0][threadIdx.x] | red[1][threadIdx.x] | red[2][threadIdx.x] | red[3][threadIdx.x];
+        uint32_t *slot = used + 4 * (block % USED_SLOTS) + threadIdx.x;
+        if (u & ~__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(slot, u);
+    }
+}
 
 // `used` != nullptr: the set of byte values that occur in columns < n is OR-ed into used[0..3] (bit b of the 128 = byte
 // value b & 127; bytes >= 0x80 are an error that prep_planes reports).  Every thread keeps the three set words of the
@@ -181,7 +220,7 @@ constexpr int USED_SLOTS = 32;  // copies of the 128-bit set of byte values that
 __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
                                                          uint32_t indet4, int32_t *__restrict__ gaps,
                                                          int32_t *__restrict__ indets, uint32_t *__restrict__ used) {
-    uint32_t seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;
+    ByteSet seen;
     const int c4 = blockIdx.x * 256 + threadIdx.x;  // dword column
     const bool active = (int64_t)c4 * 4 < ld;
     if (active) {
@@ -196,20 +235,7 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
         auto take = [&](uint32_t x) {
             accg += zero_bytes(x ^ 0x2d2d2d2du) >> 7;
             acci += zero_bytes(x ^ indet4) >> 7;
-            if (used) {  // (uniform)
-                const uint32_t h = x >> 1;
-                // bit 5 of a byte of y_s: bits 6..5 of that byte of x are s (binary 11 / 10 / 01)
-                const uint32_t y3 = x & h & imask, y2 = ~x & h & imask, y1 = x & ~h & imask;
-                seen0 |= zero_bytes(x & 0x60606060u) & imask;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t bit = 1u << ((x >> (8 * k)) & 31u);
-                    // truth table 0xF8 = a | (b & c)
-                    seen1 = __builtin_amdgcn_bitop3_b32(seen1, bit, (uint32_t)__builtin_amdgcn_sbfe(y1, 8 * k + 5, 1), 0xF8);
-                    seen2 = __builtin_amdgcn_bitop3_b32(seen2, bit, (uint32_t)__builtin_amdgcn_sbfe(y2, 8 * k + 5, 1), 0xF8);
-                    seen3 = __builtin_amdgcn_bitop3_b32(seen3, bit, (uint32_t)__builtin_amdgcn_sbfe(y3, 8 * k + 5, 1), 0xF8);
-                }
-            }
+            if (used) byteset_add(seen, x, imask);  // (uniform)
         };
         int r = r0;
         for (; r + 8 <= r1; r += 8) {  // eight rows requested before the first is looked at
@@ -234,25 +260,7 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
             }
         }
     }
-    if (used) {
-        // block union, then one atomic per word into one of USED_SLOTS copies of the set (all waves of the launch are
-        // resident at once: with a single copy their atomics queue up on one cache line for tens of microseconds);
-        // prep_planes folds the copies
-        __shared__ uint32_t red[4][4];
-        uint32_t v[4] = {seen0 ? 0xFFFFFFFFu : 0u, seen1, seen2, seen3};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v[q] |= __shfl_xor(v[q], off, 64);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v[q];
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            const uint32_t u = red[0][threadIdx.x] | red[1][threadIdx.x] | red[2][threadIdx.x] | red[3][threadIdx.x];
-            uint32_t *slot = used + 4 * ((blockIdx.x + blockIdx.y * gridDim.x) % USED_SLOTS) + threadIdx.x;
-            if (u & ~__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(slot, u);
-        }
-    }
+    if (used) byteset_publish(seen, used, blockIdx.x + blockIdx.y * gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2177,29 +2185,33 @@ __global__ __launch_bounds__(256) void overlap_rows_kernel(const uint8_t *__rest
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
                                                          const uint8_t *__restrict__ keep_res,
-                                                         int32_t *__restrict__ row_nongap) {
+                                                         int32_t *__restrict__ row_nongap, uint32_t *__restrict__ used) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= m) return;
-    // 16 bytes per lane and load (rows are 64-byte aligned, ld % 64 == 0; keep_res has 64 bytes of slack); bytes at
-    // or past n are masked off.  keep_res == nullptr: every column counts.
-    const uint4 *p = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld);
-    const uint4 *k = reinterpret_cast<const uint4 *>(keep_res);
-    int cnt = 0;
-    for (int q = lane; q * 16 < n; q += 64) {
-        const uint4 x = p[q], kk = k ? k[q] : make_uint4(~0u, ~0u, ~0u, ~0u);
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ks[4] = {kk.x, kk.y, kk.z, kk.w};
+    ByteSet seen;  // used != nullptr: this pass collects the byte values instead of gap_counts (see there)
+    if (row < m) {
+        // 16 bytes per lane and load (rows are 64-byte aligned, ld % 64 == 0; keep_res has 64 bytes of slack); bytes at
+        // or past n are masked off.  keep_res == nullptr: every column counts.
+        const uint4 *p = reinterpret_cast<const uint4 *>(raw + (size_t)row * ld);
+        const uint4 *k = reinterpret_cast<const uint4 *>(keep_res);
+        int cnt = 0;
+        for (int q = lane; q * 16 < n; q += 64) {
+            const uint4 x = p[q], kk = k ? k[q] : make_uint4(~0u, ~0u, ~0u, ~0u);
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ks[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int left = n - (q * 16 + w * 4);  // bytes of this word inside the row
-            const uint32_t inside = left >= 4 ? 0x80808080u : (left <= 0 ? 0u : (0x80808080u >> (8 * (4 - left))));
-            const uint32_t kept = ~zero_bytes(ks[w]) & 0x80808080u, gap = zero_bytes(xs[w] ^ 0x2d2d2d2du);
-            cnt += __popc(kept & ~gap & inside);
+            for (int w = 0; w < 4; ++w) {
+                const int left = n - (q * 16 + w * 4);  // bytes of this word inside the row
+                const uint32_t inside = left >= 4 ? 0x80808080u : (left <= 0 ? 0u : (0x80808080u >> (8 * (4 - left))));
+                const uint32_t kept = ~zero_bytes(ks[w]) & 0x80808080u, gap = zero_bytes(xs[w] ^ 0x2d2d2d2du);
+                cnt += __popc(kept & ~gap & inside);
+                if (used) byteset_add(seen, xs[w], (inside >> 7) * 0xFFu);  // (uniform)
+            }
         }
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if (lane == 0) row_nongap[row] = cnt;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+        if (lane == 0) row_nongap[row] = cnt;
+    }
+    if (used) byteset_publish(seen, used, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void col_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
@@ -2436,18 +2448,13 @@ void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t
     prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag, used_slots, used_out, 0);
 }
 int used_slot_words() { return 4 * USED_SLOTS; }
-// Dense codes pay between about 1500 and 4000 sequences.  Collecting the byte values and writing two sets of code
-// planes cost ~25 us, more than the pair pass gains below that (0.344 -> 0.355 ms per trim at 500 x 2000; 3.22 ->
-// 3.19 ms at 2000 x 10000); from ~4100 sequences on the raw planes are walked with two rows j per lane and a trim that
-// needs no gap counts otherwise (RepresentativeTrimmer) would run gap_counts for the byte values alone: the pair pass
-// itself gets faster (0.73 -> 0.67 ms at 5000 x 5000) but the trim does not (0.866 -> 0.875 ms).
+// Dense codes pay from about 1500 sequences on: collecting the byte values (in gap_counts, or in the row-totals pass of
+// a trim that needs no gap counts) and writing two sets of code planes cost ~20 us, more than the pair pass gains
+// below that (0.344 -> 0.355 ms per trim at 500 x 2000; 3.22 -> 3.19 ms at 2000 x 10000).
 // MSA_PAIR_DENSE=2 forces dense codes at any size, 0 never (profiles/r02_ab_switches.txt, r02_pairs_time.jsonl).
 bool pair_dense(int m) {
     if (tuning().pair_ti == 16 || tuning().pair_ti == 32) return false;
-    if (tuning().pair_dense == 2) return true;
-    const int m_pad = ((m > 1 ? m : 1) + 20 + 127) / 128 * 128;
-    const bool two_rows = (long)((m + PAIR_TI - 1) / PAIR_TI) * (m_pad / 128) / 2 >= 8192;  // as launch_pair_counts decides
-    return tuning().pair_dense == 1 && m >= 1500 && !two_rows;
+    return tuning().pair_dense == 2 || (tuning().pair_dense == 1 && m >= 1500);
 }
 int planes_total() { return PLANES_TOTAL; }
 
@@ -2626,8 +2633,8 @@ void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld,
 }
 
 void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,
-                       int32_t *row_nongap) {
-    row_nongap_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, keep_res, row_nongap);
+                       int32_t *row_nongap, uint32_t *used) {
+    row_nongap_kernel<<<(m + 3) / 4, 256, 0, s>>>(raw, m, n, ld, keep_res, row_nongap, used);
 }
 
 void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,
