@@ -274,17 +274,6 @@ def main():
     params = params_for(args.workload)
     kernels, host_rows_s, info, units_per_step = {}, None, None, None
 
-    # Setup, not workload: bring the device out of its idle clocks before the warmup steps (a trim of a few ms right
-    # after seconds of host-side data generation otherwise spends its first ten steps on the clock ramp: 3.7, 3.6, 3.5,
-    # ... 3.2 ms at C3, tools/step_series.py).  Unrelated work: dense fp32 products of a scratch matrix, ~0.2 s.
-    spin = torch.randn((4096, 4096), device=device)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.2:
-        for _ in range(8):
-            spin = torch.nn.functional.normalize(spin @ spin, dim=1)
-        torch.cuda.synchronize()
-    del spin
-
     if args.workload == "C5":
         from pytrimal_amd.batch import trim_batch
 
