@@ -19,6 +19,7 @@ struct Tuning {
     int sim_serial = 0;        // MSA_SIM_SERIAL: numerator and denominator kernel on one stream
     int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
     int trace = 0;             // MSA_TRACE
+    int upload_piece_mb = 2;   // MSA_UPLOAD_PIECE_MB: rows are packed and sent in pieces of this size (0: one copy after packing everything)
     int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)

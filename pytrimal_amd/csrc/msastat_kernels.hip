@@ -2415,6 +2415,7 @@ Tuning tuning_from_env() {
     t.device_clusters = num("MSA_DEVICE_CLUSTERS", -1);
     t.trace = getenv("MSA_TRACE") != nullptr;
     t.pipeline = num("MSA_PIPELINE", 1);
+    t.upload_piece_mb = num("MSA_UPLOAD_PIECE_MB", 2);
     t.bx_cols = num("MSA_BX_COLS", 0);
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);

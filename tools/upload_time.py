@@ -1,0 +1,14 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from pytrimal_amd import _lib
+from pytrimal_amd.synth import synth_msa
+for (m, n, seed) in ((2000, 10000, 1003), (1000, 4000, 2000), (5000, 5000, 1004), (500, 2000, 1002)):
+    a = synth_msa(m, n, seed)
+    ctx = _lib.Context(0)
+    for _ in range(3): ctx.upload(a, ord("X"))
+    t = time.perf_counter()
+    for _ in range(20): ctx.upload(a, ord("X"))
+    print(m, n, "upload ms", round((time.perf_counter() - t) / 20 * 1e3, 4), flush=True)
+    g = ctx.gaps(); assert np.array_equal(g, (a == ord("-")).sum(axis=0))
+    ctx.close()
