@@ -235,6 +235,18 @@ class Context:
         check(self.lib, self.h, self.lib.msa_upload_packed(self.h, ptr(a), m, n, n, indet))
         self.shape = (m, n)
 
+    def upload_rows(self, rows, indet):
+        """`rows`: equally long bytes-like sequences, handed over as an array of row pointers (msa_upload_rows: what
+        a binding that holds one buffer per sequence would call)"""
+        bufs = [np.frombuffer(r, dtype=np.uint8) for r in rows]
+        m = len(bufs)
+        n = len(bufs[0]) if m else 0
+        if any(len(b) != n for b in bufs):
+            raise ValueError("sequences of different lengths")
+        ptrs = (ctypes.c_void_p * max(m, 1))(*[b.ctypes.data for b in bufs])
+        check(self.lib, self.h, self.lib.msa_upload_rows(self.h, ptrs, m, n, indet))
+        self.shape = (m, n)
+
     def attach(self, dev_ptr, m, n, ld, indet):
         check(self.lib, self.h, self.lib.msa_attach_device(self.h, ctypes.c_void_p(dev_ptr), m, n, ld, indet))
         self.shape = (m, n)

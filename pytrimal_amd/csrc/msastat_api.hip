@@ -1321,6 +1321,36 @@ int msa_ctx_sync(msa_ctx *c) {
     return MSA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Rows -> the device's pitched layout.  The rows are re-pitched on the host into pinned staging (a pitched copy from
+// pageable memory degenerates into a transfer per row when the rows are not 16-byte multiples: 1.5 ms for 209 x 1227
+// instead of 0.05 ms) in pieces of about 2 MB, each sent as soon as it is packed: the copy engine moves piece k while
+// the host packs piece k + 1 (20 MB: 1.0 -> 0.56 ms).  row(i) -> pointer to the n bytes of row i.
+template <typename RowAt>
+int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
+    const size_t bytes = (size_t)m * c->ld;
+    HIPCHK(c, c->h_raw.reserve(bytes));
+    const int rows_per_piece = c->tuning.upload_piece_mb > 0
+                                   ? std::max<int>(1, (int)(((size_t)c->tuning.upload_piece_mb << 20) / (size_t)c->ld))
+                                   : std::max(m, 1);
+    for (int i0 = 0; i0 < m; i0 += rows_per_piece) {
+        const int i1 = std::min(m, i0 + rows_per_piece);
+        for (int i = i0; i < i1; ++i) {
+            uint8_t *dst = c->h_raw.p + (size_t)i * c->ld;
+            std::memcpy(dst, row(i), (size_t)n);
+            std::memset(dst + n, 0, (size_t)(c->ld - n));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->raw_own.p + (size_t)i0 * c->ld, c->h_raw.p + (size_t)i0 * c->ld, (size_t)(i1 - i0) * c->ld,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    return MSA_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
     if (!c || (!rowmajor && m > 0 && n > 0) || ld < n) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1333,26 +1363,8 @@ int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n,
         if (ld == c->ld) {  // already pitched: one linear copy
             HIPCHK(c, hipMemcpyAsync(c->raw_own.p, rowmajor, (size_t)m * c->ld, hipMemcpyHostToDevice, c->stream));
         } else {
-            // Re-pitch on the host into pinned staging and send ONE linear copy: a pitched copy from pageable
-            // memory degenerates into a transfer per row when the rows are not 16-byte multiples (1.5 ms for
-            // 209 x 1227 instead of 0.05 ms).
-            // ... in pieces of about 2 MB, each sent as soon as it is packed: the copy engine moves piece k while the
-            // host packs piece k + 1 (20 MB: 1.1 -> 0.7 ms)
-            const size_t bytes = (size_t)m * c->ld;
-            HIPCHK(c, c->h_raw.reserve(bytes));
-            const int rows_per_piece = c->tuning.upload_piece_mb > 0
-                                           ? std::max<int>(1, (int)(((size_t)c->tuning.upload_piece_mb << 20) / (size_t)c->ld))
-                                           : std::max(m, 1);
-            for (int i0 = 0; i0 < m; i0 += rows_per_piece) {
-                const int i1 = std::min(m, i0 + rows_per_piece);
-                for (int i = i0; i < i1; ++i) {
-                    uint8_t *dst = c->h_raw.p + (size_t)i * c->ld;
-                    std::memcpy(dst, rowmajor + (size_t)i * ld, (size_t)n);
-                    std::memset(dst + n, 0, (size_t)(c->ld - n));
-                }
-                HIPCHK(c, hipMemcpyAsync(c->raw_own.p + (size_t)i0 * c->ld, c->h_raw.p + (size_t)i0 * c->ld, (size_t)(i1 - i0) * c->ld,
-                                         hipMemcpyHostToDevice, c->stream));
-            }
+            rc = upload_rows_pitched(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
+            if (rc) return rc;
         }
     }
     SYNC(c);  // the caller may free `rowmajor` on return
@@ -1360,10 +1372,19 @@ int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n,
 }
 
 int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet) {
-    if (!c || (!rows && m > 0)) return MSA_E_INVALID;
-    std::vector<uint8_t> packed((size_t)std::max(m, 0) * std::max(n, 0));
-    for (int i = 0; i < m; ++i) std::memcpy(packed.data() + (size_t)i * n, rows[i], (size_t)n);
-    return msa_upload_packed(c, packed.data(), m, n, n, indet);
+    if (!c || (!rows && m > 0) || m < 0 || n < 0) return MSA_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_shape(c, m, n, indet);
+    if (rc) return rc;
+    c->ld = round_up(std::max(n, 1), 64);
+    HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
+    c->raw = c->raw_own.p;
+    if (m > 0 && n > 0) {  // (straight from the row pointers into the pinned pieces: no packed copy in between)
+        rc = upload_rows_pitched(c, m, n, [&](int i) { return rows[i]; });
+        if (rc) return rc;
+    }
+    SYNC(c);  // the caller may free the rows on return
+    return MSA_OK;
 }
 
 int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n, int64_t ld, uint8_t indet) {

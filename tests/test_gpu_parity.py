@@ -304,6 +304,32 @@ def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe, dense):
         assert np.array_equal(dst[np.ix_(rows, rows)], odst)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (3, 31), (65, 64), (209, 1227), (700, 5000), (2100, 4100)])
+def test_upload_paths_agree(ctx, shape):
+    """packed matrix (re-pitched in pieces), array of row pointers, already pitched matrix: the same residues on the
+    device (gap counts and a strict trim's similarity values as the witnesses)"""
+    m, n = shape
+    a = synth_msa(m, n, 40 + m)
+    vhash, dist = oracle.aa_matrix()
+    ctx.upload(a, ord("X"))
+    g0, x0 = ctx.gaps(with_indet=True)
+    assert np.array_equal(g0, (a == ord("-")).sum(axis=0)) and np.array_equal(x0, (a == ord("X")).sum(axis=0))
+    q0 = ctx.similarity(vhash, dist)[1] if m > 1 else None
+    ctx.upload_rows([bytes(r) for r in a], ord("X"))
+    g1, x1 = ctx.gaps(with_indet=True)
+    assert np.array_equal(g1, g0) and np.array_equal(x1, x0)
+    if m > 1:
+        assert np.array_equal(bits(ctx.similarity(vhash, dist)[1]), bits(q0))
+    ld = (n + 63) // 64 * 64
+    pitched = np.zeros((m, ld), dtype=np.uint8)
+    pitched[:, :n] = a
+    check = _lib.check
+    check(ctx.lib, ctx.h, ctx.lib.msa_upload_packed(ctx.h, _lib.ptr(pitched), m, n, ld, ord("X")))
+    ctx.shape = (m, n)
+    g2, x2 = ctx.gaps(with_indet=True)
+    assert np.array_equal(g2, g0) and np.array_equal(x2, x0)
+
+
 def _alphabet_case(m, n, letters, seed):
     r = np.random.default_rng(seed)
     alpha = np.frombuffer(letters, dtype=np.uint8)
