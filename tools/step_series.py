@@ -1,5 +1,6 @@
+"""The first forty C3 trims of a process one by one (ms): the ramp after idle."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pytrimal_amd import _lib
 from pytrimal_amd.matrix import SimilarityMatrix

@@ -1,5 +1,6 @@
+"""Host rows -> device (pack into pinned pieces + H2D) by shape, ms per upload."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pytrimal_amd import _lib
 from pytrimal_amd.synth import synth_msa
