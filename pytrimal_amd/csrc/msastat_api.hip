@@ -1570,7 +1570,11 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     const bool pipelined = column_mode && (sim_always || method == MSA_METHOD_AUTOMATED1) && sim_pipeline_applies(c, p, sim_hw);
     if (pipelined) {
         rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
-        if (rc) return rc;
+        if (rc) {  // (nothing of a half-built pipeline may stay in flight over the staging buffers)
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
         trace.mark("pipeline enqueued");
     } else {
         // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps

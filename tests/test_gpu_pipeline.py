@@ -127,6 +127,23 @@ def test_shapes_alternate_on_one_context(contexts):
     del keepalive, keepalive2
 
 
+def test_trims_repeated_on_one_upload(contexts):
+    """several trims of ONE upload (cached planes, matrices and gap counts; the gate word of an earlier automated1 still
+    set when a method that always needs the similarity values follows)"""
+    for name in ("conserved", "diverged"):
+        a = family(*CASES[name])
+        plan = [("automated1", AutomaticTrimmer("automated1", platform="hip")), ("strict", AutomaticTrimmer("strict", platform="hip")),
+                ("automated1", AutomaticTrimmer("automated1", platform="hip")), ("gappyout", AutomaticTrimmer("gappyout", platform="hip")),
+                ("strictplus", AutomaticTrimmer("strictplus", platform="hip"))]
+        expected = {method: oracle.trim(a, method=method)[0] for method, _ in plan}
+        for ctx in contexts:
+            ctx.upload(a, ord("X"))
+            for method, trimmer in plan:
+                p, keepalive = params_of(trimmer)
+                assert np.array_equal(ctx.trim(p)[0], expected[method]), (name, method)
+                del keepalive
+
+
 def test_bad_residue_only_matters_when_similarity_is_used(contexts):
     """automated1 encodes the columns for the similarity pass before it knows whether strict will be selected: a
     symbol outside the matrix must raise exactly when the reference would have reached the similarity statistic"""
