@@ -135,6 +135,12 @@ def host_info():
                                          timeout=10).stdout.strip() or None
     except Exception:
         info["git_sha"] = None
+    if not info.get("git_sha"):  # (no .git on the GPU box: __graft_entry__.build() leaves the commit beside the library)
+        try:
+            with open(os.path.join(ROOT, "pytrimal_amd", "_build_info.json")) as f:
+                info["git_sha"] = json.load(f).get("git_sha")
+        except Exception:
+            pass
     return info
 
 
