@@ -317,7 +317,9 @@ class Alignment:
 
     @property
     def names(self):
-        return [self._names[i] for i in self._seq_idx]
+        if len(self._seq_idx) == len(self._names):  # every sequence visible: no per-element indexing through numpy ints
+            return list(self._names)
+        return [self._names[i] for i in self._seq_idx.tolist()]
 
     @property
     def sequences(self):
