@@ -79,7 +79,10 @@ def detect_alignment_type(matrix):
         width = min(n, width * 4)
     seen = k > 0
     kf = np.maximum(k, 1).astype(np.float32)
-    protein = seen & ((hd + dg).astype(np.float32) / kf < 0.7) & ((hr + dg).astype(np.float32) / kf < 0.7)
+    # (upstream compares the float32 quotient with the DOUBLE literal 0.7: 14 / 20 = 0.7f = 0.69999998... is below it.
+    # numpy would compare in float32, where 0.7 rounds to the same 0.7f and the test fails)
+    protein = (seen & (((hd + dg).astype(np.float32) / kf).astype(np.float64) < 0.7) &
+               (((hr + dg).astype(np.float32) / kf).astype(np.float64) < 0.7))
     if protein.any():  # upstream returns AA at the first such sequence
         return 4
     g_rna = int((seen & (hr > hd) & (dg == 0)).sum())

@@ -181,3 +181,35 @@ def test_gap_fixture_through_product_host_code(lib):
     lib.msa_clean_gaps(p(g), n, cut, 60.0, p(keep))
     _, es = oracle.read_fasta(data_path("ENOG411BWBU.cons60.gt90.fasta"))
     assert [bytes(r[keep.astype(bool)]) for r in a] == es
+
+
+def test_alignment_type_detection_matches_the_oracle():
+    """`Alignment._alignment_type` (the host mirror of utils::checkAlignmentType, which picks the default matrix and the
+    indetermination symbol) against the oracle's restatement on random alignments -- among them rows whose nucleotide
+    share is exactly 0.7f, which upstream compares with the double literal 0.7."""
+    from pytrimal_amd.alignment import detect_alignment_type
+
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    nt = np.frombuffer(b"ACGTNRYKMSWBDHVU", dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    seen = set()
+    for it in range(1500):
+        m = int(rng.choice([1, 2, 5, 9, 13, 30])) + int(rng.integers(0, 3))
+        n = int(rng.choice([10, 20, 33, 100, 250, 700])) + int(rng.integers(0, 7))
+        alpha = aa if it % 3 else nt
+        a = alpha[rng.integers(0, len(alpha), (m, n))].copy()
+        if it % 5 == 0:  # mixtures around the 70 % line
+            mix = rng.random((m, n)) < rng.choice([0.6, 0.7, 0.8])
+            a = np.where(mix, nt[rng.integers(0, 5, (m, n))], a)
+        a[rng.random((m, n)) < rng.beta(0.6, 1.8, n)[None, :]] = ord("-")
+        if it % 7 == 0:
+            a[rng.random((m, n)) < 0.1] = rng.choice([ord("."), ord("?")])
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        t = detect_alignment_type(a)
+        assert t == oracle.alignment_type(a), (m, n, it)
+        seen.add(t)
+    # the exact edge: 14 nucleotide-or-degenerate letters of 20
+    row = np.frombuffer(b"ACGTACGTRYKMSW" + b"LLLLLL", dtype=np.uint8)
+    edge = np.stack([row, row])
+    assert detect_alignment_type(edge) == oracle.alignment_type(edge) == 4
+    assert {1, 4} <= seen

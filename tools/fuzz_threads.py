@@ -1,0 +1,63 @@
+"""Four threads, each with its own contexts, trimming random alignments against the oracle at the same time (what
+ThreadPool.map(trimmer.trim, alignments) does to the library): python tools/fuzz_threads.py [seconds=60] [threads=4]"""
+import json, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+import oracle
+from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, RepresentativeTrimmer
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+failures, counts = [], [0] * nthreads
+
+
+def worker(k):
+    rng = np.random.default_rng(1000 + k)
+    t0 = time.time()
+    while time.time() - t0 < budget and not failures:
+        m = int(rng.choice([5, 40, 130, 400, 900, 1700])) + int(rng.integers(0, 9))
+        n = int(rng.choice([33, 100, 600, 2000])) + int(rng.integers(0, 7))
+        keep = float(rng.choice([0.3, 0.6, 0.9]))
+        root = AA[rng.integers(0, 20, n)]
+        a = np.where(rng.random((m, n)) < keep, root[None, :], AA[rng.integers(0, 20, (m, n))])
+        a[rng.random((m, n)) < rng.beta(0.6, 1.8, n)[None, :]] = ord("-")
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            kw, tr = dict(method="automated1"), AutomaticTrimmer("automated1", platform="hip")
+        elif kind == 1:
+            kw, tr = dict(method="strictplus"), AutomaticTrimmer("strictplus", platform="hip")
+        elif kind == 2:
+            kw = dict(gap_threshold=0.6, similarity_threshold=0.2)
+            tr = ManualTrimmer(platform="hip", **kw)
+        else:
+            kw = dict(identity_threshold=0.5)
+            tr = RepresentativeTrimmer(platform="hip", **kw)
+        ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+        try:
+            res, seq, _ = oracle.trim(a, **kw)
+            expect = None
+        except oracle.OracleError as e:  # (e.g. a tiny alignment detected as nucleotides: its letters are not in that matrix)
+            expect = e
+        try:
+            t = tr.trim(ali)
+            got = None
+        except ValueError as e:
+            got = e
+        if (expect is None) != (got is None):
+            failures.append({"thread": k, "shape": [m, n], "settings": kw, "oracle": repr(expect), "device": repr(got)})
+        elif expect is None and (t.residues_mask != [bool(x) for x in res] or t.sequences_mask != [bool(x) for x in seq]):
+            failures.append({"thread": k, "shape": [m, n], "settings": kw})
+        counts[k] += 1
+
+
+ts = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
+for t in ts:
+    t.start()
+for t in ts:
+    t.join()
+print(json.dumps({"mismatch": bool(failures), "failures": failures[:3], "trims_per_thread": counts, "threads": nthreads, "seconds": budget}))
+sys.exit(1 if failures else 0)
