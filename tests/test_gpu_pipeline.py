@@ -203,3 +203,19 @@ def test_random_trims_against_the_oracle(seed):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["mismatch"] is False and line["cases"] > 100
+
+
+def test_public_api_from_threads_against_the_oracle():
+    """tools/fuzz_threads.py: four threads trimming random protein / DNA / RNA alignments through the four trimmer classes
+    (type detection, default matrices, per-thread contexts) against the oracle's trim at the same time."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_threads.py"), "10", "4"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mismatch"] is False and min(line["trims_per_thread"]) > 20, line

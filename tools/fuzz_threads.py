@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 import oracle
-from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, RepresentativeTrimmer
+from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -21,21 +21,37 @@ def worker(k):
         m = int(rng.choice([5, 40, 130, 400, 900, 1700])) + int(rng.integers(0, 9))
         n = int(rng.choice([33, 100, 600, 2000])) + int(rng.integers(0, 7))
         keep = float(rng.choice([0.3, 0.6, 0.9]))
-        root = AA[rng.integers(0, 20, n)]
-        a = np.where(rng.random((m, n)) < keep, root[None, :], AA[rng.integers(0, 20, (m, n))])
+        flavour = int(rng.integers(0, 6))  # 0-2 protein, 3 DNA, 4 RNA, 5 nucleotides with degenerate letters
+        alpha = AA if flavour < 3 else np.frombuffer({3: b"ACGT", 4: b"ACGU", 5: b"ACGTRYKMSWN"}[flavour], dtype=np.uint8)
+        root = alpha[rng.integers(0, len(alpha), n)]
+        a = np.where(rng.random((m, n)) < keep, root[None, :], alpha[rng.integers(0, len(alpha), (m, n))])
         a[rng.random((m, n)) < rng.beta(0.6, 1.8, n)[None, :]] = ord("-")
+        if rng.random() < 0.3:
+            a[(rng.random((m, n)) < 0.02) & (a != ord("-"))] = ord("X") if flavour < 3 else ord("N")
+        if rng.random() < 0.15:
+            low = (rng.random((m, n)) < 0.1) & (a >= 65) & (a <= 90)
+            a = np.where(low, a + 32, a)
         a = np.ascontiguousarray(a, dtype=np.uint8)
-        kind = int(rng.integers(0, 4))
-        if kind == 0:
-            kw, tr = dict(method="automated1"), AutomaticTrimmer("automated1", platform="hip")
-        elif kind == 1:
-            kw, tr = dict(method="strictplus"), AutomaticTrimmer("strictplus", platform="hip")
-        elif kind == 2:
-            kw = dict(gap_threshold=0.6, similarity_threshold=0.2)
+        kind = int(rng.integers(0, 8))
+        if kind <= 2:
+            method = str(rng.choice(["automated1", "strict", "strictplus", "gappyout", "nogaps", "noallgaps", "noduplicateseqs"]))
+            kw, tr = dict(method=method), AutomaticTrimmer(method, platform="hip")
+        elif kind <= 4:
+            kw = dict(gap_threshold=float(rng.choice([0.3, 0.6, 0.9])), similarity_threshold=float(rng.choice([0.1, 0.2, 0.6])))
+            if rng.random() < 0.4 and n >= 40:
+                kw[str(rng.choice(["window", "gap_window", "similarity_window"]))] = int(rng.integers(1, 5))
+            if rng.random() < 0.3:
+                kw["conservation_percentage"] = float(rng.choice([30, 60]))
             tr = ManualTrimmer(platform="hip", **kw)
-        else:
-            kw = dict(identity_threshold=0.5)
+        elif kind == 5:
+            kw = dict(identity_threshold=float(rng.choice([0.3, 0.5, 0.8])))
             tr = RepresentativeTrimmer(platform="hip", **kw)
+        elif kind == 6:
+            kw = dict(clusters=int(rng.integers(1, m + 1)))
+            tr = RepresentativeTrimmer(platform="hip", **kw)
+        else:
+            kw = dict(residue_overlap=float(rng.choice([0.3, 0.6, 0.9])), sequence_overlap=float(rng.choice([20, 50, 80])))
+            tr = OverlapTrimmer(kw["sequence_overlap"], kw["residue_overlap"], platform="hip")
         ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
         try:
             res, seq, _ = oracle.trim(a, **kw)
@@ -45,7 +61,7 @@ def worker(k):
         try:
             t = tr.trim(ali)
             got = None
-        except ValueError as e:
+        except (ValueError, RuntimeError) as e:
             got = e
         if (expect is None) != (got is None):
             failures.append({"thread": k, "shape": [m, n], "settings": kw, "oracle": repr(expect), "device": repr(got)})
