@@ -387,11 +387,12 @@ class TrimmedAlignment(Alignment):
 
         rows = self._matrix[np.flatnonzero(self._seq_mask)]
         res = self._res_mask.copy()
-        free = np.zeros(0, dtype=np.int64)
         if rows.size:
             ctx = _lib.thread_context()
             ctx.upload(rows, ord("X"))
             free = np.flatnonzero(ctx.gaps() == 0)
+        else:  # (no sequence left: no column holds a gap -- the statistic over nothing, as the oracle restates it)
+            free = np.arange(self._matrix.shape[1], dtype=np.int64)
         if free.size == 0:
             raise RuntimeError("the alignment has no column without gaps: terminal-only trimming is not possible")
         res[free[0]:free[-1] + 1] = True

@@ -431,3 +431,14 @@ def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
         Alignment.load(io.BytesIO(b"CLUSTAL\n\na ACGT\nb AC\n"), "clustal")
     with pytest.raises(ValueError):
         Alignment.load(io.BytesIO(b"CLUSTAL\n\na AC!T\nb ACGT\n"), "clustal")
+
+
+def test_terminal_only_without_sequences_left():
+    """every sequence dropped: the gap statistic over nothing holds no gap, every column is restored (the oracle's
+    reading 0 of Cleaner::removeOnlyTerminal); needs no device"""
+    import oracle
+
+    a = oracle.pack(["AC-DE", "A--DE", "-C-DE"])
+    t = TrimmedAlignment([b"a", b"b", b"c"], ["AC-DE", "A--DE", "-C-DE"], sequences_mask=[False] * 3, residues_mask=[False] * 5)
+    want = oracle.terminal_only(a, [False] * 5, [False] * 3, reading=0)
+    assert want is not None and t.terminal_only().residues_mask == [bool(x) for x in want] == [True] * 5

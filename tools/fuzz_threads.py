@@ -67,6 +67,14 @@ def worker(k):
             failures.append({"thread": k, "shape": [m, n], "settings": kw, "oracle": repr(expect), "device": repr(got)})
         elif expect is None and (t.residues_mask != [bool(x) for x in res] or t.sequences_mask != [bool(x) for x in seq]):
             failures.append({"thread": k, "shape": [m, n], "settings": kw})
+        elif expect is None and rng.random() < 0.3:  # TrimmedAlignment.terminal_only against the oracle's reading 0
+            want = oracle.terminal_only(a, res, seq, reading=0)
+            try:
+                have = t.terminal_only().residues_mask
+            except RuntimeError:
+                have = None
+            if (want is None) != (have is None) or (want is not None and have != [bool(x) for x in want]):
+                failures.append({"thread": k, "shape": [m, n], "settings": kw, "terminal_only": True})
         counts[k] += 1
 
 
