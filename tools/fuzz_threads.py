@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 import oracle
-from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer
+from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer, SimilarityMatrix
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -53,13 +53,20 @@ def worker(k):
             kw = dict(residue_overlap=float(rng.choice([0.3, 0.6, 0.9])), sequence_overlap=float(rng.choice([20, 50, 80])))
             tr = OverlapTrimmer(kw["sequence_overlap"], kw["residue_overlap"], platform="hip")
         ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+        okw, custom = dict(kw), None
+        if rng.random() < 0.15:  # a custom similarity matrix over a random alphabet (letters may be missing from it)
+            letters = "".join(sorted(set(rng.choice(list("ABCDEFGHIKLMNPQRSTUVWXYZ"), size=int(rng.integers(4, 25))))))
+            sim = rng.integers(-4, 10, (len(letters), len(letters))).astype(np.float32)
+            sim = (sim + sim.T) / 2
+            custom = SimilarityMatrix(sim.tolist(), alphabet=letters)
+            okw["matrix"] = oracle.make_matrix(sim, letters)
         try:
-            res, seq, _ = oracle.trim(a, **kw)
+            res, seq, _ = oracle.trim(a, **okw)
             expect = None
         except oracle.OracleError as e:  # (e.g. a tiny alignment detected as nucleotides: its letters are not in that matrix)
             expect = e
         try:
-            t = tr.trim(ali)
+            t = tr.trim(ali, custom) if custom is not None else tr.trim(ali)
             got = None
         except (ValueError, RuntimeError) as e:
             got = e
@@ -75,6 +82,25 @@ def worker(k):
                 have = None
             if (want is None) != (have is None) or (want is not None and have != [bool(x) for x in want]):
                 failures.append({"thread": k, "shape": [m, n], "settings": kw, "terminal_only": True})
+        if expect is None and got is None and not failures and rng.random() < 0.25 and res.any() and seq.any():
+            # a second trim of the trimmed alignment: the reference materialises the kept part first (_trimal.pyx:1324-1327)
+            sub = np.ascontiguousarray(a[np.flatnonzero(seq)][:, np.flatnonzero(res)])
+            kw2 = dict(method=str(rng.choice(["gappyout", "strict", "automated1", "noallgaps"])))
+            tr2 = AutomaticTrimmer(kw2["method"], platform="hip")
+            try:
+                res2, seq2, _ = oracle.trim(sub, **kw2)
+                expect2 = None
+            except oracle.OracleError as e:
+                expect2 = e
+            try:
+                t2 = tr2.trim(t)
+                got2 = None
+            except (ValueError, RuntimeError) as e:
+                got2 = e
+            if (expect2 is None) != (got2 is None) or (expect2 is None and (t2.residues_mask != [bool(x) for x in res2] or
+                                                                           t2.sequences_mask != [bool(x) for x in seq2])):
+                failures.append({"thread": k, "shape": list(sub.shape), "settings": [kw, kw2], "chained": True,
+                                 "oracle": repr(expect2), "device": repr(got2)})
         counts[k] += 1
 
 
