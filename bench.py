@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MSA statistics path (BASELINE.json metric).
 
-Workloads (BASELINE.json configs; `--workload`, default C3 = the headline):
+Workloads (BASELINE.json configs; `--workload`; default: C3 = the headline at one GPU, C5 = BASELINE config 5 when
+`--gpus N` > 1):
   C3  AutomaticTrimmer('automated1') on a synthetic 2 000 x 10 000 protein MSA (seed 1003 + rank)
   C2  ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5) on 500 x 2 000 (seed 1002 + rank)
   C4  RepresentativeTrimmer(identity_threshold=0.5) on 5 000 x 5 000 (seed 1004 + rank)
   C5  the batch of 64 alignments of 1 000 x 4 000 (seeds 2000..2063), AutomaticTrimmer('automated1'), through
-      `pytrimal_amd.batch.trim_batch(threads=4)`: sharded round-robin over the ranks, masks gathered over RCCL.
-One "step" = one pass of the whole path over the workload's input.  For C2-C4 the residue bytes are resident in
-HBM when the timed region starts (`value`); the same steps from host rows (pack + H2D included) are timed right
-after and reported as `value_host_rows` (SURVEY 8d's primary metric).  C5 always starts from host rows.
+      `pytrimal_amd.batch.trim_batch`: sharded round-robin over the ranks (strong scaling), masks gathered over RCCL.
+  REF the reference's own protocol (/root/reference/bench/bench.py:48-57,94-101): 3583 x 7287, the four statistic ->
+      trimmer mappings, whole `trimmer.trim(alignment)` calls through the public API, median of 3.
+One "step" = one pass of the whole path over the workload's input, FROM HOST ROWS: pack + H2D, kernels, D2H, host
+selection logic -- SURVEY 8(d)'s metric, `value` / `ms_per_step`.  For C2-C4 the same steps with the residue bytes
+already resident in HBM (`value_resident`) and through the public API (`AutomaticTrimmer(...).trim(Alignment)` ->
+`TrimmedAlignment`: `value_public_api`) are timed right after.
 
 `python bench.py --gpus N` starts N rank processes itself when it was not launched by torchrun (RANK unset): the
 parent never touches a GPU, every child is `bench.py` again with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a
@@ -64,6 +68,7 @@ WORKLOADS = {
     "C2": (500, 2000, 1002),
     "C4": (5000, 5000, 1004),
     "C5": (1000, 4000, 2000),
+    "REF": (3583, 7287, 3583),
 }
 C5_BATCH = 64
 
@@ -205,16 +210,86 @@ def cpu_baseline(a, trimmer_kw, ncols, value, with_similarity=True):
     return out, speedups
 
 
+def run_reference_protocol(args, device):
+    """The reference's own benchmark (bench/bench.py:48-57,94-101; README.md:156-160): 3583 sequences x 7287 columns,
+    the four statistic -> trimmer mappings, `trimmer.trim(alignment)` timed with a wall clock around the whole call
+    through the public API (host rows -> TrimmedAlignment), one untimed call first (the reference's first run of a fresh
+    process is its cold one too), median of 3.  The reference's alignment (example.014.AA.EggNOG.COG0591.fasta) is not
+    in its tree: the same shape from the seeded synthetic generator.  ONE JSON line: `value` = columns/s of the
+    Similarity trim (the statistic BASELINE.md derives its 990 columns/s from), the four results under `results`."""
+    from pytrimal_amd import Alignment, ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer, _lib
+    from pytrimal_amd.synth import synth_msa
+
+    m, n, seed = WORKLOADS["REF"]
+    a = synth_msa(m, n, seed)
+    ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+    # medians of 3 at 3583 sequences, AVX2 / SSE2 / platform=None, i7-10710U one core (BASELINE.md section 1)
+    published = {"Gaps": (0.0052, 0.0055, 0.127), "Similarity": (7.34, 7.43, 75.9), "Overlap": (7.68, 9.84, 143.0),
+                 "Identity": (8.57, 11.3, 131.9)}
+    trimmers = {"Gaps": ManualTrimmer(gap_threshold=0.5, platform="hip"),
+                "Similarity": ManualTrimmer(similarity_threshold=0.5, platform="hip"),
+                "Overlap": OverlapTrimmer(60.0, 0.5, platform="hip"),
+                "Identity": RepresentativeTrimmer(identity_threshold=0.5, platform="hip")}
+    results = []
+    for name, tr in trimmers.items():
+        tr.trim(ali)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = tr.trim(ali)
+            times.append(time.perf_counter() - t0)
+        sec = float(np.median(times))
+        ctx = _lib.thread_context()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        tr.trim(ali)
+        kern = {}
+        for nm in ("gaps", "prep", "pairs", "encode", "sim", "overlap", "cluster", "idstats"):
+            ms, k = ctx.prof_get(nm)
+            if k:
+                kern[nm] = round(ms / k, 4)
+        ctx.prof_enable(False)
+        avx2, sse2, scalar = published[name]
+        results.append({"statistic": name, "trimmer": repr(tr), "sequences": m, "residues": n, "times": [round(t, 6) for t in times],
+                        "median": round(sec, 6), "columns_per_s": round(n / sec, 1), "kernels_ms": kern,
+                        "kept": [int(sum(out.residues_mask)), int(sum(out.sequences_mask))],
+                        "reference_published_median_s": {"avx2": avx2, "sse2": sse2, "platform_none": scalar,
+                                                         "hardware": "i7-10710U @ 1.10 GHz, one core",
+                                                         "data": "example.014.AA.EggNOG.COG0591.fasta (not in the reference tree)"},
+                        "published_avx2_over_this": round(avx2 / sec, 1)})
+    if args.out:
+        with open(args.out, "w") as f:
+            for r in results:
+                f.write(json.dumps(r) + "\n")
+    sim = next(r for r in results if r["statistic"] == "Similarity")
+    print(json.dumps({
+        "metric": "MSA columns/s (gap+similarity+identity)", "value": sim["columns_per_s"], "unit": "columns/s", "n_gpus": 1,
+        "steps": 3, "warmup": 1, "ms_per_step": round(sim["median"] * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8/f32", "data": "synthetic",
+        "config": {"workload": f"the reference's own protocol (bench/bench.py: four statistic -> trimmer mappings, whole trim() calls "
+                               f"through the public API from host rows, median of 3) on a synthetic {m} seq x {n} col protein MSA; value = "
+                               f"the Similarity trim (ManualTrimmer(similarity_threshold=0.5))", "m": m, "n": n},
+        "results": results,
+        "note": "BASELINE.md's published times are for the same shape on other data and other hardware (one laptop core): quoted "
+                "beside each result, never as vs_baseline",
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: C3 (the headline) at one GPU, C5 (BASELINE config 5, strong scaling) with --gpus N > 1")
+    ap.add_argument("--out", default=None, help="REF: also write the four result lines to this file (JSON lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=4000)
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.workload is None:
+        # BASELINE.json's multi-GPU config is the batch of 64 (config 5): that is what a scaling run measures unless told otherwise
+        args.workload = "C5" if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else "C3"
 
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args)  # does not return
@@ -227,7 +302,7 @@ def main():
 
     import torch
 
-    from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
+    from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, RepresentativeTrimmer, _lib
     from pytrimal_amd.matrix import SimilarityMatrix
     from pytrimal_amd.synth import synth_msa
 
@@ -240,6 +315,11 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=device)
+
+    if args.workload == "REF":
+        if world > 1:
+            raise SystemExit("--workload REF is the reference's single-process protocol: run it with --gpus 1")
+        return run_reference_protocol(args, device)
 
     m, n, seed = WORKLOADS[args.workload]
     matrix = SimilarityMatrix.aa()
@@ -278,7 +358,7 @@ def main():
 
     ctx = _lib.Context(local_rank)
     params = params_for(args.workload)
-    kernels, host_rows_s, info, units_per_step = {}, None, None, None
+    kernels, resident_s, public_api_s, info, units_per_step = {}, None, None, None, None
 
     if args.workload == "C5":
         from pytrimal_amd.batch import trim_batch
@@ -336,8 +416,19 @@ def main():
             finish(keep_res)
             return keep_res, keep_seq, info
 
+        trimmer_obj = {"C3": lambda: AutomaticTrimmer("automated1", platform="hip"),
+                       "C2": lambda: ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5, platform="hip"),
+                       "C4": lambda: RepresentativeTrimmer(identity_threshold=0.5, platform="hip")}[args.workload]()
+        ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+
+        def step_public_api():
+            t = trimmer_obj.trim(ali)  # host rows -> TrimmedAlignment, the call a user of the reference makes
+            finish(t._res_mask)
+            return t
+
         for _ in range(args.warmup):
-            step()
+            step_host_rows()
+        # THE TIMED REGION (value / ms_per_step): every step starts from the host rows -- SURVEY 8(d).
         # HIP event pairs around the two pairwise passes -- the dominant kernels, what `roofline` is computed from -- over
         # the timed region (level 2); the small kernels are timed in a few untimed steps afterwards: seven more event
         # pairs per step cost ~10 % of a 0.33 ms step (tools/step_overheads.py)
@@ -346,7 +437,7 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            keep_res, keep_seq, info = step()
+            keep_res, keep_seq, info = step_host_rows()
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         ctx.prof_enable(False)
@@ -360,13 +451,23 @@ def main():
             step()
         fence()
         ctx.prof_enable(False)
-        step_host_rows()
+        # the same steps with the residue bytes resident in HBM (no pack, no H2D)
+        step()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step_host_rows()
+            step()
         fence()
-        host_rows_s = max_over_ranks(time.perf_counter() - t0)
+        resident_s = max_over_ranks(time.perf_counter() - t0)
+        # ... and through the public API: Alignment -> trimmer.trim -> TrimmedAlignment (its own per-thread context)
+        api_masks = step_public_api()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_public_api()
+        fence()
+        public_api_s = max_over_ranks(time.perf_counter() - t0)
+        assert np.array_equal(api_masks._res_mask, keep_res) and np.array_equal(api_masks._seq_mask, keep_seq)
         kept = int(info.kept_residues)
 
     for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "simnum", "simden", "overlap", "cluster"):
@@ -433,7 +534,7 @@ def main():
                         f"host rows to gathered masks")
         else:
             workload = (f"{trimmer_repr} on synthetic {m} seq x {n} col protein MSA ({args.workload}, seed {seed}+rank), one "
-                        f"alignment per GPU per step, residues resident in HBM")
+                        f"alignment per GPU per step, every step from host rows (pack + H2D, kernels, D2H, host selection) to masks")
         out = {
             "metric": "MSA columns/s (gap+similarity+identity)",
             "value": round(value, 2),
@@ -459,12 +560,15 @@ def main():
             "roofline": roofline,
             "roofline_all_kernels": roofline_all,
             "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in kernels.items()},
-            "kernels_ms_source": ("HIP events: pairs and sim over the timed region, the other kernels over 5 untimed steps after it"
+            "kernels_ms_source": ("HIP events: pairs and sim over the timed (host-rows) region, the other kernels over 5 untimed steps after it"
                                   if args.workload != "C5" else "HIP events over 3 untimed trims of one alignment of the batch"),
         }
-        if host_rows_s is not None:
-            out["value_host_rows"] = round(units_per_step * args.steps / host_rows_s, 2)
-            out["ms_per_step_host_rows"] = round(host_rows_s / args.steps * 1e3, 4)
+        if resident_s is not None:
+            out["value_resident"] = round(units_per_step * args.steps / resident_s, 2)
+            out["ms_per_step_resident"] = round(resident_s / args.steps * 1e3, 4)
+        if public_api_s is not None:
+            out["value_public_api"] = round(units_per_step * args.steps / public_api_s, 2)
+            out["ms_per_step_public_api"] = round(public_api_s / args.steps * 1e3, 4)
         if not args.no_cpu_baseline and world == 1:
             sample = synth_msa(m, n, seed) if args.workload == "C5" else a
             ncols = args.cpu_sample_cols if args.workload != "C4" else min(args.cpu_sample_cols, 600)

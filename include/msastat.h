@@ -77,6 +77,13 @@ int msa_attach_device(msa_ctx *ctx, const void *rowmajor_dev, int32_t m, int32_t
  * indetermination symbol per column (used by the overlap pass). */
 int msa_gaps(msa_ctx *ctx, int32_t *gaps_out, int32_t *indet_out);
 
+/* The (windowed) gap vector of the current alignment if its counts are already on the host -- i.e. a trim or msa_gaps
+ * has fetched them -- without any device work: returns MSA_OK and fills out[n] (half_window as in msa_window_i32, 0 =
+ * the plain counts), or 1 when the context holds no host copy (nothing is written).  This is what lets
+ * TrimmedAlignment.terminal_only (Cleaner::removeOnlyTerminal, cleaner.pxd:38) read the gap statistics the trim
+ * computed, as trimAl's trimmed alignment shares the statistics object of its source (statistics.pxd:47-51). */
+int msa_gaps_cached(msa_ctx *ctx, int32_t half_window, int32_t *out);
+
 /* ---- a2/a5  pairwise identity counts: Cleaner::calculateSeqIdentity (cleaner.pxd:42) and
  *             Similarity::calculateMatrixIdentity (statistics.pxd:56) share them -------------- */
 /* hit[m*m], dst[m*m] (either nullable): symmetric, diagonal 0. */
@@ -201,6 +208,32 @@ enum {
  * 0/1 bytes, i.e. TrimmedAlignment.residues_mask / sequences_mask (_trimal.pyx:1085-1121). */
 int msa_trim(msa_ctx *ctx, const msa_trim_params *params, uint8_t *keep_res, uint8_t *keep_seq,
              msa_trim_info *info);
+
+/* ---- batches of independent alignments: the reference's `ThreadPool.map(trimmer.trim, alignments)` (README.md:136-152;
+ *      possible there because trim releases the interpreter lock, _trimal.pyx:1334-1359) as one native call --------------
+ * A batch object owns `workers` threads, each with its own context (device buffers + streams) on `device`.
+ * msa_trim_batch trims `count` independent alignments: alignment k = m[k] rows of n[k] residue bytes, row-major at data[k]
+ * with leading dimension ld[k] >= n[k], indetermination symbol indet[k], parameters params[k] (one entry per alignment:
+ * the similarity matrix follows the alignment's type); keep_res[k] (n[k] bytes), keep_seq[k] (m[k] bytes), info[k]
+ * (nullable array) and rc[k] receive what msa_trim would return for it.  The workers take the alignments largest first;
+ * each uploads its alignment without waiting for the copy (the rows must stay valid until the call returns) and trims it,
+ * so uploads, kernels and the host selection logic of different alignments overlap on the device.  Returns MSA_OK or the
+ * first non-zero rc[k].  One call at a time per batch object; different batch objects are independent. */
+typedef struct msa_batch msa_batch;
+int msa_batch_create(int device, int32_t workers, msa_batch **out);
+void msa_batch_destroy(msa_batch *b);
+int32_t msa_batch_workers(const msa_batch *b);
+int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, const int32_t *m, const int32_t *n,
+                   const int64_t *ld, const uint8_t *indet, const msa_trim_params *params, uint8_t *const *keep_res,
+                   uint8_t *const *keep_seq, msa_trim_info *info, int32_t *rc);
+/* the rows behind MSA_W_ONLY_GAPS_SEQUENCES of alignment k of the last call (as msa_trim_only_gaps_rows) */
+int msa_batch_only_gaps_rows(msa_batch *b, int32_t k, int32_t *rows, int32_t cap);
+const char *msa_batch_last_hip_error(const msa_batch *b, int32_t worker);
+
+/* The sequences the last msa_trim of this context removed because the trimming left them with gaps only (the rows behind
+ * MSA_W_ONLY_GAPS_SEQUENCES; trimAl reports each of them): writes at most cap indices, returns their number (>= 0)
+ * or a negative error code. */
+int msa_trim_only_gaps_rows(msa_ctx *ctx, int32_t *rows, int32_t cap);
 
 /* ---- instrumentation ---------------------------------------------------------------------- */
 /* device time (ms, HIP events on the context stream) and launch count of the named kernel

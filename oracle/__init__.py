@@ -395,14 +395,17 @@ def trim(a, method=None, gap_threshold=None, gap_absolute_threshold=None, simila
     return save_res != -1, save_seq != -1, info
 
 
-def terminal_only(a, residues_mask, sequences_mask, reading=0):
+def terminal_only(a, residues_mask, sequences_mask, reading=2, gaps_w=None):
     """`TrimmedAlignment.terminal_only` (Cleaner::removeOnlyTerminal, _trimal.pyx:1144-1157; [R], see the C source):
-    -> the new residues mask, or None when no column is free of gaps (upstream reports an error)."""
+    -> the new residues mask, or None when no column is free of gaps (upstream reports an error).  reading 2 (the
+    product's): boundaries from the gap vector of the ORIGINAL alignment (`gaps_w`: the trim's windowed counts, or
+    None = counted over all sequences); 0: gaps over the kept sequences; 1: first / last kept column."""
     a = pack(a)
     m, n = a.shape
     save_res = np.where(np.asarray(residues_mask, dtype=bool), np.arange(n), -1).astype(np.int32)
     save_seq = np.where(np.asarray(sequences_mask, dtype=bool), np.arange(m), -1).astype(np.int32)
-    ok = lib().orc_terminal_only(_p(a), m, n, n, _p(save_seq), _p(save_res), int(reading))
+    gw = None if gaps_w is None else np.ascontiguousarray(gaps_w, dtype=np.int32)
+    ok = lib().orc_terminal_only(_p(a), m, n, n, _p(save_seq), _p(save_res), int(reading), _p(gw))
     return (save_res != -1) if ok else None
 
 

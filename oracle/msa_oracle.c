@@ -537,20 +537,27 @@ void orc_remove_all_gaps(const uint8_t *a, int m, int n, int ld, int32_t *save_s
 }
 
 /* Cleaner::removeOnlyTerminal (cleaner.pxd:38, called by TrimmedAlignment.terminal_only, _trimal.pyx:1144-1157).
- * The body is not in the reference tree: [R] both readings are restated, the product follows reading 0.
- *   reading 0 [R, the recollection of upstream Cleaner.cpp]: the gap statistics of the alignment (its kept
- *     sequences, every original column) give the first and the last column WITHOUT gaps; every column between
- *     the two (inclusive) is restored, the columns outside keep the trimmer's decision.  Returns 0 (and changes
- *     nothing) when no column is free of gaps -- upstream reports an error there.
+ * The body is not in the reference tree: [R] three readings are restated, the product follows reading 2.
+ *   reading 2 [R, the recollection of upstream Cleaner.cpp + statistics/Manager copy semantics]: the trimmed
+ *     alignment shares the gap statistics object of the alignment it was trimmed from, so the boundaries are the
+ *     first and the last column WITHOUT gaps in the (windowed) gap vector of the ORIGINAL alignment -- all its
+ *     sequences, whatever the trimmer kept.  gaps_w: that vector when the caller has it (the trim's own windowed
+ *     counts), NULL: counted here over all m rows, no window.  Every column between the two boundaries (inclusive)
+ *     is restored, the columns outside keep the trimmer's decision.  Returns 0 (and changes nothing) when no column
+ *     is free of gaps -- upstream reports an error there (LeftBoundaryBiggerThanRightBoundary [R]).
+ *   reading 0 (round 2 of this repository): as reading 2, but the gaps are counted over the KEPT sequences only.
  *   reading 1 (round 1 of this repository): the boundaries are the first and the last KEPT column.
  * save_res is updated in place (-1 dropped, else the column index); returns 1 on success. */
-int orc_terminal_only(const uint8_t *a, int m, int n, int ld, const int32_t *save_seq, int32_t *save_res, int reading) {
+int orc_terminal_only(const uint8_t *a, int m, int n, int ld, const int32_t *save_seq, int32_t *save_res, int reading,
+                      const int32_t *gaps_w) {
     int left = n, right = -1;
-    if (reading == 0) {
+    if (reading == 0 || reading == 2) {
         for (int c = 0; c < n; c++) {
             int gaps = 0;
-            for (int i = 0; i < m; i++)
-                if (save_seq[i] != -1 && a[(size_t)i * ld + c] == '-') gaps++;
+            if (reading == 2 && gaps_w) gaps = gaps_w[c];
+            else
+                for (int i = 0; i < m; i++)
+                    if ((reading == 2 || save_seq[i] != -1) && a[(size_t)i * ld + c] == '-') gaps++;
             if (gaps == 0) {
                 if (left == n) left = c;
                 right = c;

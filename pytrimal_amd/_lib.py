@@ -38,11 +38,12 @@ METHOD_CODES = {
 EXPORTS = [
     "msa_strerror", "msa_device_count", "msa_last_hip_error", "msa_ctx_create", "msa_ctx_destroy",
     "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_attach_device",
-    "msa_gaps", "msa_pair_counts", "msa_identities", "msa_identity_stats", "msa_similarity",
+    "msa_gaps", "msa_gaps_cached", "msa_pair_counts", "msa_identities", "msa_identity_stats", "msa_similarity",
     "msa_overlap", "msa_window_i32", "msa_window_f32", "msa_gaps_cutpoint",
     "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
-    "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_prof_get", "msa_prof_reset",
+    "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_trim_only_gaps_rows", "msa_batch_create", "msa_batch_destroy", "msa_batch_workers", "msa_trim_batch",
+    "msa_batch_only_gaps_rows", "msa_batch_last_hip_error", "msa_prof_get", "msa_prof_reset",
     "msa_prof_enable", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
 ]
 
@@ -124,6 +125,7 @@ def load():
         L.msa_upload_packed.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
         L.msa_attach_device.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
         L.msa_gaps.argtypes = [vp, vp, vp]
+        L.msa_gaps_cached.argtypes = [vp, i32, vp]
         L.msa_pair_counts.argtypes = [vp, vp, vp]
         L.msa_identities.argtypes = [vp, vp, vp]
         L.msa_identity_stats.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]
@@ -151,6 +153,16 @@ def load():
         L.msa_cutpoint_clusters.argtypes = [vp, vp, i32, i32]
         L.msa_cutpoint_clusters.restype = f32
         L.msa_trim.argtypes = [vp, ctypes.POINTER(TrimParams), vp, vp, ctypes.POINTER(TrimInfo)]
+        L.msa_trim_only_gaps_rows.argtypes = [vp, vp, i32]
+        L.msa_batch_create.argtypes = [ctypes.c_int, i32, ctypes.POINTER(vp)]
+        L.msa_batch_destroy.argtypes = [vp]
+        L.msa_batch_destroy.restype = None
+        L.msa_batch_workers.argtypes = [vp]
+        L.msa_batch_workers.restype = i32
+        L.msa_trim_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.msa_batch_only_gaps_rows.argtypes = [vp, i32, vp, i32]
+        L.msa_batch_last_hip_error.argtypes = [vp, i32]
+        L.msa_batch_last_hip_error.restype = ctypes.c_char_p
         L.msa_prof_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(f32), ctypes.POINTER(i32)]
         L.msa_prof_reset.argtypes = [vp]
         L.msa_prof_reset.restype = None
@@ -259,6 +271,16 @@ class Context:
         check(self.lib, self.h, self.lib.msa_gaps(self.h, ptr(g), ptr(x)))
         return (g, x) if with_indet else g
 
+    def gaps_cached(self, half_window=0):
+        """The windowed gap vector if the context already holds the counts on the host (no device work), else None."""
+        _, n = self.shape
+        out = np.empty(n, dtype=np.int32)
+        rc = self.lib.msa_gaps_cached(self.h, int(half_window), ptr(out))
+        if rc == 1:
+            return None
+        check(self.lib, self.h, rc)
+        return out
+
     def pair_counts(self):
         m, _ = self.shape
         hit = np.zeros((m, m), dtype=np.uint32)
@@ -306,6 +328,15 @@ class Context:
         check(self.lib, self.h, rc, info.err)
         return keep_res.astype(bool), keep_seq.astype(bool), info
 
+    def only_gaps_rows(self):
+        """The sequences the last `trim` removed because it left them with gaps only."""
+        n = self.lib.msa_trim_only_gaps_rows(self.h, None, 0)
+        if n <= 0:
+            return []
+        rows = np.empty(n, dtype=np.int32)
+        self.lib.msa_trim_only_gaps_rows(self.h, ptr(rows), n)
+        return [int(r) for r in rows]
+
     # --- instrumentation ---
     def prof_enable(self, on=True):
         # True / 1: every kernel group; 2: the similarity and pair passes only (cheaper: see msa_prof_enable); False / 0: off
@@ -325,6 +356,91 @@ class Context:
     @property
     def stream(self):
         return self.lib.msa_ctx_stream(self.h)
+
+
+class Batch:
+    """One `msa_batch`: native worker threads, each with its own device context, that trim the alignments of a call side
+    by side (`msa_trim_batch`: the reference's `ThreadPool.map(trimmer.trim, ...)` without the interpreter)."""
+
+    def __init__(self, device=None, workers=6):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("PYTRIMAL_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = self.lib.msa_device_count()
+            if n > 0:
+                device %= n
+        h = ctypes.c_void_p()
+        rc = self.lib.msa_batch_create(int(device), int(workers), ctypes.byref(h))
+        if rc != OK:
+            raise RuntimeError(f"cannot create a batch of {workers} HIP contexts on device {device}: "
+                               f"{self.lib.msa_strerror(rc).decode()} (there is no CPU fallback)")
+        self.h, self.device, self.workers = h, int(device), int(workers)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.msa_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trim(self, items):
+        """`items`: [(matrix uint8[m, n] (C-contiguous rows, any row stride), indet, TrimParams), ...] ->
+        [(keep_res bool[n], keep_seq bool[m], TrimInfo, rc, only_gaps_rows), ...].  The interpreter lock is released for
+        the whole call."""
+        count = len(items)
+        if count == 0:
+            return []
+        data = (ctypes.c_void_p * count)()
+        ms = np.empty(count, dtype=np.int32)
+        ns = np.empty(count, dtype=np.int32)
+        lds = np.empty(count, dtype=np.int64)
+        indets = np.empty(count, dtype=np.uint8)
+        params = (TrimParams * count)()
+        total = 0
+        for k, (a, indet, p) in enumerate(items):
+            if a.dtype != np.uint8 or a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != 1):
+                raise ValueError("batch items must be uint8 matrices with contiguous rows")
+            data[k] = a.ctypes.data
+            ms[k], ns[k] = a.shape
+            lds[k] = a.strides[0] if a.shape[0] > 1 else max(a.shape[1], 1)
+            indets[k] = indet
+            params[k] = p
+            total += a.shape[0] + a.shape[1]
+        masks = np.ones(max(total, 1), dtype=np.uint8)
+        kres = (ctypes.c_void_p * count)()
+        kseq = (ctypes.c_void_p * count)()
+        pos, views = 0, []
+        for k, (a, _, _) in enumerate(items):
+            m, n = a.shape
+            kres[k] = masks.ctypes.data + pos
+            kseq[k] = masks.ctypes.data + pos + n
+            views.append((pos, n, m))
+            pos += n + m
+        infos = (TrimInfo * count)()
+        rcs = np.zeros(count, dtype=np.int32)
+        self.lib.msa_trim_batch(self.h, count, data, ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, kres, kseq, infos, ptr(rcs))
+        out = []
+        for k, (pos, n, m) in enumerate(views):
+            rows = []
+            if infos[k].warnings & W_ONLY_GAPS_SEQUENCES:
+                cnt = self.lib.msa_batch_only_gaps_rows(self.h, k, None, 0)
+                if cnt > 0:
+                    buf = np.empty(cnt, dtype=np.int32)
+                    self.lib.msa_batch_only_gaps_rows(self.h, k, ptr(buf), cnt)
+                    rows = [int(r) for r in buf]
+            out.append((masks[pos:pos + n].astype(bool), masks[pos + n:pos + n + m].astype(bool), infos[k], int(rcs[k]), rows))
+        return out
+
+    def check(self, rc, info):
+        """Raise what `Context.trim` would raise for this return code."""
+        if rc == E_HIP:
+            msgs = [self.lib.msa_batch_last_hip_error(self.h, w).decode() for w in range(self.workers)]
+            raise MsaError(rc, self.lib.msa_strerror(rc).decode() + ": " + "; ".join(x for x in msgs if x), info.err)
+        check(self.lib, None, rc, info.err)
 
 
 _tls = threading.local()

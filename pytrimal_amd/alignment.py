@@ -253,7 +253,10 @@ class Alignment:
             fast = _load_native(cls, data, file, fmt)
             if fast is not None:
                 return fast
-            names, seqs = (_parse_fasta if fmt == "fasta" else _parse_clustal)(data)
+            try:
+                names, seqs = (_parse_fasta if fmt == "fasta" else _parse_clustal)(data)
+            except ValueError as err:
+                raise RuntimeError(f"Failed to recognize format {format!r} in {file!r}") from err
         elif fmt in _PARSERS:
             try:
                 names, seqs = _PARSERS[fmt](data)
@@ -376,31 +379,40 @@ class TrimmedAlignment(Alignment):
         """Get a trimmed alignment where only the terminal residues are removed.
 
         ``Cleaner::removeOnlyTerminal`` (``/root/reference/src/pytrimal/_trimal.pyx:1144-1157``,
-        ``include/trimal/cleaner.pxd:38``).  Its body is not in the reference tree; this follows the recalled
-        upstream behaviour [R]: the gap statistics of the kept sequences over every
-        original column give the first and the last column without gaps, every column between the two is
-        restored and the columns outside keep the trimmer's decision.  `RuntimeError` when no column is free of
-        gaps (upstream reports an error there).  The gap counts come from the HIP path (`msa_gaps`), like every
-        other statistic of this package.
+        ``include/trimal/cleaner.pxd:38``).  **Unverified**: the body is not in the reference tree and no fixture
+        of the reference exercises it; this follows the recalled upstream behaviour [R].  A
+        trimmed alignment shares the gap statistics of the alignment it was trimmed from, so the boundaries are the
+        first and the last column without gaps in the gap vector of the ORIGINAL alignment -- every sequence,
+        whatever the trimmer kept; the windowed vector of the trim that produced this object when it computed
+        one, the plain counts otherwise.  Every column between the two boundaries is restored, the columns outside
+        keep the trimmer's decision.  `RuntimeError` when no column is free of gaps (upstream reports an error).
+        No device work: the counts are the ones the trim fetched, or a host count over the bytes.
         """
-        from . import _lib
+        gaps = getattr(self, "_gaps_w", None)
+        if gaps is None:
+            m, n = self._matrix.shape
+            gaps = (self._matrix == _GAP).sum(axis=0, dtype=np.int32) if m else np.zeros(n, dtype=np.int32)
+            hw = getattr(self, "_gap_hw", 0)
+            if hw > 0 and n:  # the window of the trim that produced this object (pure host function of the library)
+                from . import _lib
 
-        rows = self._matrix[np.flatnonzero(self._seq_mask)]
+                out = np.empty(n, dtype=np.int32)
+                gaps = np.ascontiguousarray(gaps, dtype=np.int32)
+                if _lib.load().msa_window_i32(_lib.ptr(gaps), n, hw, _lib.ptr(out)) == 0:
+                    gaps = out
         res = self._res_mask.copy()
-        if rows.size:
-            ctx = _lib.thread_context()
-            ctx.upload(rows, ord("X"))
-            free = np.flatnonzero(ctx.gaps() == 0)
-        else:  # (no sequence left: no column holds a gap -- the statistic over nothing, as the oracle restates it)
-            free = np.arange(self._matrix.shape[1], dtype=np.int64)
+        free = np.flatnonzero(np.asarray(gaps) == 0)
         if free.size == 0:
             raise RuntimeError("the alignment has no column without gaps: terminal-only trimming is not possible")
         res[free[0]:free[-1] + 1] = True
-        return TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, res)
+        out = TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, res)
+        out._gaps_w, out._gap_hw = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0)
+        return out
 
     def copy(self):
-        return TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask,
-                                            self._res_mask)
+        out = TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, self._res_mask)
+        out._gaps_w, out._gap_hw = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0)
+        return out
 
 
 # --- minimal readers --------------------------------------------------------------------------
@@ -596,7 +608,12 @@ def _parse_pir(data):
 def _parse_clustal(data):
     names, seqs = [], {}
     lines = data.splitlines()
-    for line in lines[1:]:
+    head = 0
+    while head < len(lines) and not lines[head].strip():
+        head += 1
+    if head == len(lines) or not lines[head].strip().upper().startswith((b"CLUSTAL", b"MUSCLE")):
+        raise ValueError("not a Clustal file")
+    for line in lines[head + 1:]:
         if not line.strip() or line[:1] in (b" ", b"\t"):
             continue
         parts = line.split()
@@ -665,8 +682,13 @@ def _write_fasta(out, names, seqs, datatype):
 
 
 def _write_clustal(out, names, seqs, datatype):
+    # Name column = longest name + 5, blocks of 60 residues, two empty lines behind every block: byte for byte the
+    # body of the one trimAl-written Clustal file in the reference tree (tests/data/example.001.gt90.w3.clw).  That
+    # file's first line, "CLUSTAL 2.0.12 multiple sequence alignment", is the header of the ClustalW file it was
+    # trimmed from: trimAl carries the input's header line over when input and output format agree; an alignment
+    # built in memory has none, and gets trimAl's default line.
     out.write("CLUSTAL multiple sequence alignment\n\n")
-    width = max((len(x) for x in names), default=0) + 6
+    width = max((len(x) for x in names), default=0) + 5
     n = len(seqs[0]) if seqs else 0
     for k in range(0, n, 60):
         for name, seq in zip(names, seqs):

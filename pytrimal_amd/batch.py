@@ -11,7 +11,9 @@ and a gather of the kept-column / kept-sequence masks to rank 0 (`torch.distribu
 Import order matters in a process that uses PyTorch-ROCm: this module imports torch before the
 HIP library is loaded (see pytrimal_amd._lib).
 """
-from multiprocessing.pool import ThreadPool
+import atexit
+import os
+import threading
 
 import numpy as np
 import torch
@@ -19,15 +21,40 @@ import torch.distributed as dist
 
 from .alignment import Alignment, TrimmedAlignment
 
+# One native batch object (worker threads + their device contexts: O(m^2) buffers each) per (device, workers), kept
+# between calls, closed at exit, rebuilt in a child process (worker threads do not survive a fork).
+_BATCHES = {}
+_BATCHES_PID = None
+_BATCHES_LOCK = threading.Lock()
 
-_POOLS = {}  # worker threads are kept: each owns a device context (stream, buffers) worth reusing across calls
+
+def _close_batches():
+    for b in list(_BATCHES.values()):
+        try:
+            b.close()
+        except Exception:
+            pass
+    _BATCHES.clear()
 
 
-def _pool(threads):
-    pool = _POOLS.get(threads)
-    if pool is None:
-        pool = _POOLS[threads] = ThreadPool(threads)
-    return pool
+atexit.register(_close_batches)
+
+
+def _native_batch(device_index, workers):
+    from . import _lib
+
+    global _BATCHES_PID
+    with _BATCHES_LOCK:
+        if _BATCHES_PID != os.getpid():
+            _BATCHES.clear()  # (inherited across a fork: the threads are gone and the handles belong to the parent)
+            _BATCHES_PID = os.getpid()
+        key = (device_index, workers)
+        b = _BATCHES.get(key)
+        if b is None:
+            for other in [k for k in _BATCHES if k[0] == device_index]:  # one set of contexts per device
+                _BATCHES.pop(other).close()
+            b = _BATCHES[key] = _lib.Batch(device_index, workers)
+        return b
 
 
 def shard_indices(n_items, world_size, rank):
@@ -53,40 +80,56 @@ def _pack_masks(results):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
 
-def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=4):
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
 
-    Within a rank the shard is trimmed by `threads` worker threads (`trim` is re-entrant, one device context and
-    stream per thread; the pool is kept between calls): one 1000 x 4000 alignment does not fill the chip and the
-    host side of a trim (list building, selection logic, synchronisations) is serial, so alignments in flight side
-    by side raise the throughput of a GPU (config 5, 64 alignments on one GPU: 5.1 M columns/s with 4 threads).
+    Within a rank the shard goes to the native batch path (`msa_trim_batch`, include/msastat.h): `threads` worker
+    threads inside the library, each with its own device context, take the alignments largest first; uploads, kernels
+    and host selection logic of different alignments overlap on the GPU and the interpreter lock is released for
+    the whole shard (one 1000 x 4000 alignment does not fill the chip, and the host side of a trim is serial).
 
-    `trim_fn(alignment) -> TrimmedAlignment` replaces `trimmer.trim` (used by the CPU tests,
-    which have no device).
+    `trim_fn(alignment) -> TrimmedAlignment` replaces the device path (used by the CPU tests,
+    which have no device): the shard is then trimmed one alignment after the other in the calling thread.
     """
-    if trim_fn is None:
-        def trim_fn(ali):
-            return trimmer.trim(ali, matrix)
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     mine = shard_indices(len(alignments), world, rank)
 
-    def one(i):
-        t = trim_fn(alignments[i])
-        # (the masks as the arrays they already are: the public properties build Python lists element by element,
-        # ~0.4 ms per 1000 x 4000 alignment with the interpreter lock held)
-        res, seq = getattr(t, "_res_mask", None), getattr(t, "_seq_mask", None)
-        if res is None or seq is None:
-            res, seq = t.residues_mask, t.sequences_mask
-        return np.asarray(res, dtype=bool), np.asarray(seq, dtype=bool), t
-
-    if threads > 1 and len(mine) > 1:
-        local = _pool(min(threads, len(mine))).map(one, mine, chunksize=1)
+    if trim_fn is not None:
+        local = []
+        for i in mine:
+            t = trim_fn(alignments[i])
+            res, seq = getattr(t, "_res_mask", None), getattr(t, "_seq_mask", None)
+            if res is None or seq is None:
+                res, seq = t.residues_mask, t.sequences_mask
+            local.append((np.asarray(res, dtype=bool), np.asarray(seq, dtype=bool), t))
     else:
-        local = [one(i) for i in mine]
+        from . import _lib
+
+        prepared = [trimmer._prepare(alignments[i], matrix) for i in mine]
+        index = device.index if isinstance(device, torch.device) and device.index is not None else None
+        if index is None:
+            index = int(os.environ.get("PYTRIMAL_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        todo = [k for k, (_, dense, _, _, _) in enumerate(prepared) if dense.shape[0] and dense.shape[1]]
+        results = {}
+        if todo:
+            batch = _native_batch(index, max(1, min(int(threads), 64)))
+            outs = batch.trim([(prepared[k][1], prepared[k][2], prepared[k][3]) for k in todo])
+            for k, out in zip(todo, outs):
+                if out[3] != _lib.OK:
+                    batch.check(out[3], out[2])
+                results[k] = out
+        local = []
+        for k, (names, dense, indet, params, _keep) in enumerate(prepared):
+            if k in results:
+                res, seq, info, _, rows = results[k]
+            else:  # an empty alignment never reaches the device
+                res, seq, info, rows = np.ones(dense.shape[1], dtype=bool), np.ones(dense.shape[0], dtype=bool), None, None
+            t = trimmer._finish(names, dense, alignments[mine[k]]._datatype, res, seq, info, rows, None, params)
+            local.append((res, seq, t))
     if not distributed or world == 1:
         # (what the workers produced, as it is: rebuilding 64 results from their masks in the calling thread was a serial
         # tail of ~4 ms behind a 35 ms batch)

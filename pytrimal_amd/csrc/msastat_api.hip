@@ -4,7 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -151,7 +158,7 @@ struct msa_ctx {
     DevView<unsigned long long> errkey;  // first bad residue of the similarity pass, complemented (0 = none): state block
     DevView<int> errflag;                // prep_planes' non-ASCII flag (state block)
     DevView<int> pairflag;               // set by the pair pass when some pair has dst = 0 (undefined identity; state block)
-    bool pairflag_pending = false;
+    int pairflag_state = 0;  // 0 no pair pass since the flag was last read, 1 enqueued and its flag word not fetched yet, 2 fetched (h_flags holds it)
     DevBuf<uint32_t> col_ok;
     DevBuf<int32_t> good, row_cnt, col_cnt, lengths, pairs, equal;
     DevBuf<uint8_t> keep_res_d, keep_seq_d;
@@ -175,6 +182,7 @@ struct msa_ctx {
 
     // host copies valid for the current alignment
     std::vector<int32_t> h_gaps, h_indets;
+    std::vector<int32_t> only_gaps_rows;  // the sequences the last msa_trim removed because the trimming left them with gaps only
 
     // profiling
     int prof_on = 0;  // 0 off, 1 every kernel group, 2 the similarity and pair passes only
@@ -211,6 +219,7 @@ enum {
 // Every wait on the context's stream goes through here: it fetches the flag words when a kernel that may have raised
 // one ran since the last fetch (one 64-byte copy in front of the wait) and settles the asynchronous fetches above.
 static int sync_stream(msa_ctx *c) {
+    const bool fetching = c->flags_dirty && c->state.p;
     if (c->flags_dirty && c->state.p) {
         hipError_t e = c->h_flags.reserve(ST_FLAGS);
         if (e == hipSuccess)
@@ -220,6 +229,7 @@ static int sync_stream(msa_ctx *c) {
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
+    if (fetching && c->pairflag_state == 1) c->pairflag_state = 2;  // (the pair pass's flag word came with this fetch)
     if (c->gaps_staged == 1) c->gaps_staged = 2;
     if (c->rowtot_staged == 1) c->rowtot_staged = 2;
     if (c->planes_pending) {
@@ -286,7 +296,7 @@ void prof_collect(msa_ctx *c) {
 
 void invalidate(msa_ctx *c) {
     c->have_planes = c->have_gaps = c->have_ident = c->have_w = false;
-    c->pairflag_pending = false;
+    c->pairflag_state = 0;
     c->h_gaps.clear();
     c->gaps_staged = 0;
     c->rowtot_staged = 0;
@@ -450,7 +460,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
     }
     HIPCHK(c, hipGetLastError());
     c->flags_dirty = true;
-    c->pairflag_pending = true;  // (read after the next synchronisation of the stream)
+    c->pairflag_state = 1;  // (its flag word arrives with the next flag fetch: sync_stream)
     if (need_ident) c->have_ident = true;
     if (need_w) c->have_w = true;
     return MSA_OK;
@@ -549,8 +559,18 @@ int fetch_similarity_finish(msa_ctx *c, int n, float *mdk_out, float *q_out, msa
         }
         return ((key >> 8) & 1ull) ? MSA_E_UNDEFINED_SYMBOL : MSA_E_INCORRECT_SYMBOL;
     }
-    std::memcpy(mdk_out, c->h_f32.p, sizeof(float) * n);
-    if (q_out) std::memcpy(q_out, c->h_f32.p + n, sizeof(float) * n);
+    // (a NaN is a value whose exponential the device would not vouch for -- sim_finish_kernel: evaluated here, as the
+    // reference does it, from the bit-exact Q)
+    const float *dm = c->h_f32.p, *dq = c->h_f32.p + n;
+    for (int i = 0; i < n; ++i) {
+        float v = dm[i];
+        if (v != v) {
+            v = static_cast<float>(std::exp(-static_cast<double>(dq[i])));
+            if (v > 1.0f) v = 1.0f;
+        }
+        mdk_out[i] = v;
+    }
+    if (q_out) std::memcpy(q_out, dq, sizeof(float) * n);
     return MSA_OK;
 }
 int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_detail *detail) {
@@ -896,6 +916,7 @@ int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_i
     for (int i = 0; i < m; ++i) {
         if (keep_seq[i] && c->h_i32.p[i] == 0) {
             keep_seq[i] = 0;
+            c->only_gaps_rows.push_back(i);
             if (info) {
                 if (!(info->warnings & MSA_W_ONLY_GAPS_SEQUENCES)) info->warn_row = i;
                 info->warnings |= MSA_W_ONLY_GAPS_SEQUENCES;
@@ -1324,34 +1345,131 @@ int msa_ctx_sync(msa_ctx *c) {
 }  // extern "C"
 
 namespace {
+// A few helper threads that pack upload pieces (memcpy into pinned staging) beside the calling thread: one core copies
+// ~12 - 35 GB/s from pageable memory, the link takes > 50 GB/s.  Process-wide, created on first use, never destroyed
+// (the threads sleep on a condition variable; a leaked singleton has no destruction-order problems at exit).
+struct PackJob {
+    std::atomic<int> next{0};
+    int npieces = 0;
+    std::function<void(int)> pack;
+    std::unique_ptr<std::atomic<unsigned char>[]> done;
+};
+class PackPool {
+  public:
+    static PackPool &get() {
+        static PackPool *pool = new PackPool();
+        return *pool;
+    }
+    void submit(const std::shared_ptr<PackJob> &job) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_.push_back(job);
+        }
+        cv_.notify_all();
+    }
+    int helpers() const { return (int)threads_.size(); }
+
+  private:
+    PackPool() {
+        const char *e = std::getenv("MSA_PACK_THREADS");
+        int k = e ? std::atoi(e) : 3;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0) k = std::min(k, std::max(0, hw - 1));
+        for (int i = 0; i < k; ++i) {
+            threads_.emplace_back([this] { run(); });
+            threads_.back().detach();
+        }
+    }
+    void run() {
+        for (;;) {
+            std::shared_ptr<PackJob> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return !jobs_.empty(); });
+                job = jobs_.front();
+                if (job->next.load(std::memory_order_relaxed) >= job->npieces) {
+                    jobs_.pop_front();
+                    continue;
+                }
+            }
+            for (;;) {
+                const int p = job->next.fetch_add(1, std::memory_order_relaxed);
+                if (p >= job->npieces) break;
+                job->pack(p);
+                job->done[p].store(1, std::memory_order_release);
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<PackJob>> jobs_;
+    std::vector<std::thread> threads_;
+};
+
 // Rows -> the device's pitched layout.  The rows are re-pitched on the host into pinned staging (a pitched copy from
 // pageable memory degenerates into a transfer per row when the rows are not 16-byte multiples: 1.5 ms for 209 x 1227
-// instead of 0.05 ms) in pieces of about 2 MB, each sent as soon as it is packed: the copy engine moves piece k while
-// the host packs piece k + 1 (20 MB: 1.0 -> 0.56 ms).  row(i) -> pointer to the n bytes of row i.
+// instead of 0.05 ms) in pieces of about 1 MB, each sent as soon as it is packed: the copy engine moves piece k while
+// the host packs the pieces behind it -- the calling thread and the helper threads of PackPool, pieces taken in order
+// (20 MB: 1.0 ms packed by one thread before the copy, 0.56 ms piece by piece, see DESIGN.md for the helpers).
+// row(i) -> pointer to the n bytes of row i.
 template <typename RowAt>
 int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
     const size_t bytes = (size_t)m * c->ld;
     HIPCHK(c, c->h_raw.reserve(bytes));
-    const int rows_per_piece = c->tuning.upload_piece_mb > 0
-                                   ? std::max<int>(1, (int)(((size_t)c->tuning.upload_piece_mb << 20) / (size_t)c->ld))
+    const int rows_per_piece = c->tuning.upload_piece_kb > 0
+                                   ? std::max<int>(1, (int)(((size_t)c->tuning.upload_piece_kb << 10) / (size_t)c->ld))
                                    : std::max(m, 1);
-    for (int i0 = 0; i0 < m; i0 += rows_per_piece) {
-        const int i1 = std::min(m, i0 + rows_per_piece);
+    const int npieces = (m + rows_per_piece - 1) / rows_per_piece;
+    auto pack_piece = [c, m, n, rows_per_piece, row](int p) {
+        const int i0 = p * rows_per_piece, i1 = std::min(m, i0 + rows_per_piece);
         for (int i = i0; i < i1; ++i) {
             uint8_t *dst = c->h_raw.p + (size_t)i * c->ld;
             std::memcpy(dst, row(i), (size_t)n);
             std::memset(dst + n, 0, (size_t)(c->ld - n));
         }
+    };
+    auto send_piece = [&](int p) -> int {
+        const int i0 = p * rows_per_piece, i1 = std::min(m, i0 + rows_per_piece);
         HIPCHK(c, hipMemcpyAsync(c->raw_own.p + (size_t)i0 * c->ld, c->h_raw.p + (size_t)i0 * c->ld, (size_t)(i1 - i0) * c->ld,
                                  hipMemcpyHostToDevice, c->stream));
+        return MSA_OK;
+    };
+    PackPool &pool = PackPool::get();
+    if (npieces < 4 || pool.helpers() == 0) {  // small: the calling thread alone
+        for (int p = 0; p < npieces; ++p) {
+            pack_piece(p);
+            const int rc = send_piece(p);
+            if (rc) return rc;
+        }
+        return MSA_OK;
     }
-    return MSA_OK;
+    auto job = std::make_shared<PackJob>();
+    job->npieces = npieces;
+    job->pack = pack_piece;
+    job->done.reset(new std::atomic<unsigned char>[npieces]);
+    for (int p = 0; p < npieces; ++p) job->done[p].store(0, std::memory_order_relaxed);
+    pool.submit(job);
+    int rc = MSA_OK;
+    for (int p = 0; p < npieces; ++p) {
+        // help until piece p is packed (by whoever took it), then send it: the copies go out in order
+        while (!job->done[p].load(std::memory_order_acquire)) {
+            const int q = job->next.fetch_add(1, std::memory_order_relaxed);
+            if (q < npieces) {
+                pack_piece(q);
+                job->done[q].store(1, std::memory_order_release);
+            } else {
+                std::this_thread::yield();
+            }
+        }
+        if (rc == MSA_OK) rc = send_piece(p);  // (after an error: keep draining, the helpers still write into h_raw)
+    }
+    return rc;
 }
 }  // namespace
 
 extern "C" {
 
-int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
+static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet, bool wait) {
     if (!c || (!rowmajor && m > 0 && n > 0) || ld < n) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_shape(c, m, n, indet);
@@ -1367,8 +1485,12 @@ int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n,
             if (rc) return rc;
         }
     }
-    SYNC(c);  // the caller may free `rowmajor` on return
+    if (wait) SYNC(c);  // the caller may free `rowmajor` on return
     return MSA_OK;
+}
+
+int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
+    return upload_packed(c, rowmajor, m, n, ld, indet, true);
 }
 
 int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet) {
@@ -1416,6 +1538,12 @@ int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
     if (gaps_out) std::copy(c->h_gaps.begin(), c->h_gaps.end(), gaps_out);
     if (indet_out) std::copy(c->h_indets.begin(), c->h_indets.end(), indet_out);
     return MSA_OK;
+}
+
+int msa_gaps_cached(msa_ctx *c, int32_t half_window, int32_t *out) {
+    if (!c || !out || half_window < 0) return MSA_E_INVALID;
+    if (c->n <= 0 || (int)c->h_gaps.size() != c->n) return 1;  // no host copy for the current alignment
+    return msah::window_i32(c->h_gaps.data(), c->n, half_window, out);
 }
 
 int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
@@ -1501,6 +1629,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     c->order_ready = false;
     c->pipe_active = false;
     c->colcnt_staged = false;
+    c->only_gaps_rows.clear();
     msa_trim_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));
@@ -1509,6 +1638,7 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     std::fill(keep_res, keep_res + n, 1);
     std::fill(keep_seq, keep_seq + m, 1);
     if (m == 0 || n == 0) return MSA_OK;
+    if (p->method == MSA_METHOD_AUTOMATED2) return MSA_E_NOT_IMPLEMENTED;  // (no body in the reference tree, no surviving pin)
     int rc = MSA_OK;
 
     // trimAlManager::set_window_size
@@ -1654,7 +1784,6 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             info->selected_method = msah::select_method(info->avg_seq, info->max_seq, m);
             method = info->selected_method == 1 ? MSA_METHOD_GAPPYOUT : MSA_METHOD_STRICT;
         }
-        if (method == MSA_METHOD_AUTOMATED2) return MSA_E_NOT_IMPLEMENTED;
         if (method == MSA_METHOD_GAPPYOUT) {
             if ((rc = need_gaps())) return rc;
             if (!have_gap_cut) info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
@@ -1705,11 +1834,19 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
     info->kept_residues = static_cast<int32_t>(std::count(keep_res, keep_res + n, 1));
     info->kept_sequences = static_cast<int32_t>(std::count(keep_seq, keep_seq + m, 1));
     if (info->kept_residues == 0) info->warnings |= MSA_W_NO_COLUMNS_LEFT;
-    if (c->pairflag_pending) {  // (remove_all_gaps synchronised the stream: the pair pass's flag has landed)
-        c->pairflag_pending = false;
+    if (c->pairflag_state) {
+        if (c->pairflag_state == 1) SYNC(c);  // no wait since the pair pass fetched the flag words: fetch them now
+        c->pairflag_state = 0;
         if (c->h_flags.p && c->h_flags.p[ST_PAIRFLAG]) info->warnings |= MSA_W_UNDEFINED_IDENTITY;
     }
     return MSA_OK;
+}
+
+int msa_trim_only_gaps_rows(msa_ctx *c, int32_t *rows, int32_t cap) {
+    if (!c || cap < 0 || (!rows && cap > 0)) return MSA_E_INVALID;
+    const int count = (int)c->only_gaps_rows.size();
+    std::copy_n(c->only_gaps_rows.begin(), std::min(count, (int)cap), rows);
+    return count;
 }
 
 int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
@@ -1735,6 +1872,155 @@ void msa_prof_reset(msa_ctx *c) {
 
 void msa_prof_enable(msa_ctx *c, int enable) {
     if (c) c->prof_on = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+}
+
+}  // extern "C"
+
+// ---- batches of independent alignments ----------------------------------------------------------------------------
+// The reference's batch idiom is a thread pool over `trimmer.trim` (README.md:136-152), possible because its `trim`
+// releases the interpreter lock for the whole computation (_trimal.pyx:1334-1359).  Here the pool is native: worker
+// threads, each with its own context (device buffers, streams), take the alignments of a call largest first; a worker
+// uploads its alignment without waiting (the caller's rows outlive the call) and trims it, so that the upload of one
+// alignment, the kernels of others and the host selection logic of yet others overlap on one GPU, with nothing of the
+// interpreter in between.
+struct msa_batch {
+    int device = 0;
+    std::vector<msa_ctx *> ctxs;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint64_t generation = 0;
+    bool stop = false;
+    int running = 0;
+    // the call in flight
+    int32_t count = 0;
+    const uint8_t *const *data = nullptr;
+    const int32_t *m = nullptr, *n = nullptr;
+    const int64_t *ld = nullptr;
+    const uint8_t *indet = nullptr;
+    const msa_trim_params *params = nullptr;
+    uint8_t *const *keep_res = nullptr, *const *keep_seq = nullptr;
+    msa_trim_info *info = nullptr;
+    int32_t *rc = nullptr;
+    std::vector<int32_t> order;
+    std::atomic<int32_t> next{0};
+    std::vector<std::vector<int32_t>> only_gaps;  // per alignment: the rows behind MSA_W_ONLY_GAPS_SEQUENCES
+};
+
+namespace {
+void batch_worker(msa_batch *b, int w) {
+    (void)hipSetDevice(b->device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv_work.wait(lk, [&] { return b->stop || b->generation != seen; });
+            if (b->stop) return;
+            seen = b->generation;
+        }
+        msa_ctx *c = b->ctxs[w];
+        for (;;) {
+            const int32_t slot = b->next.fetch_add(1, std::memory_order_relaxed);
+            if (slot >= b->count) break;
+            const int32_t k = b->order[slot];
+            msa_trim_info local;
+            msa_trim_info *info = b->info ? b->info + k : &local;
+            int rc = upload_packed(c, b->data[k], b->m[k], b->n[k], b->ld[k], b->indet[k], false);
+            if (rc == MSA_OK) rc = msa_trim(c, b->params + k, b->keep_res[k], b->keep_seq[k], info);
+            else {
+                std::memset(info, 0, sizeof(*info));
+                (void)hipStreamSynchronize(c->stream);  // (nothing of a failed upload may stay in flight over the caller's rows)
+            }
+            b->only_gaps[k] = c->only_gaps_rows;
+            b->rc[k] = rc;
+        }
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            if (--b->running == 0) b->cv_done.notify_all();
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int msa_batch_create(int device, int32_t workers, msa_batch **out) {
+    if (!out || workers < 1 || workers > 64) return MSA_E_INVALID;
+    *out = nullptr;
+    msa_batch *b = new (std::nothrow) msa_batch();
+    if (!b) return MSA_E_NOMEM;
+    b->device = device;
+    for (int w = 0; w < workers; ++w) {
+        msa_ctx *c = nullptr;
+        const int rc = msa_ctx_create(device, &c);
+        if (rc != MSA_OK) {
+            for (msa_ctx *x : b->ctxs) msa_ctx_destroy(x);
+            delete b;
+            return rc;
+        }
+        b->ctxs.push_back(c);
+    }
+    for (int w = 0; w < workers; ++w) b->workers.emplace_back(batch_worker, b, w);
+    *out = b;
+    return MSA_OK;
+}
+
+void msa_batch_destroy(msa_batch *b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;
+    }
+    b->cv_work.notify_all();
+    for (std::thread &t : b->workers) t.join();
+    for (msa_ctx *c : b->ctxs) msa_ctx_destroy(c);
+    delete b;
+}
+
+int32_t msa_batch_workers(const msa_batch *b) { return b ? (int32_t)b->workers.size() : 0; }
+
+int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, const int32_t *m, const int32_t *n, const int64_t *ld,
+                   const uint8_t *indet, const msa_trim_params *params, uint8_t *const *keep_res, uint8_t *const *keep_seq,
+                   msa_trim_info *info, int32_t *rc) {
+    if (!b || count < 0 || (count > 0 && (!data || !m || !n || !ld || !indet || !params || !keep_res || !keep_seq || !rc)))
+        return MSA_E_INVALID;
+    if (count == 0) return MSA_OK;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        if (b->running) return MSA_E_INVALID;  // one call at a time per batch object
+        b->count = count;
+        b->data = data, b->m = m, b->n = n, b->ld = ld, b->indet = indet, b->params = params;
+        b->keep_res = keep_res, b->keep_seq = keep_seq, b->info = info, b->rc = rc;
+        // largest first (cost ~ m^2 n): the last alignments to finish are the small ones
+        b->order.resize(count);
+        for (int32_t k = 0; k < count; ++k) b->order[k] = k;
+        std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t x, int32_t y) {
+            return (double)m[x] * m[x] * n[x] > (double)m[y] * m[y] * n[y];
+        });
+        b->only_gaps.assign(count, {});
+        b->next.store(0);
+        b->running = (int)b->workers.size();
+        ++b->generation;
+    }
+    b->cv_work.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_done.wait(lk, [&] { return b->running == 0; });
+    }
+    for (int32_t k = 0; k < count; ++k)
+        if (rc[k] != MSA_OK) return rc[k];
+    return MSA_OK;
+}
+
+int msa_batch_only_gaps_rows(msa_batch *b, int32_t k, int32_t *rows, int32_t cap) {
+    if (!b || k < 0 || k >= (int32_t)b->only_gaps.size() || cap < 0 || (!rows && cap > 0)) return MSA_E_INVALID;
+    const std::vector<int32_t> &v = b->only_gaps[k];
+    std::copy_n(v.begin(), std::min((int)v.size(), (int)cap), rows);
+    return (int)v.size();
+}
+
+const char *msa_batch_last_hip_error(const msa_batch *b, int32_t worker) {
+    return (b && worker >= 0 && worker < (int32_t)b->ctxs.size()) ? b->ctxs[worker]->hip_err : "";
 }
 
 }  // extern "C"

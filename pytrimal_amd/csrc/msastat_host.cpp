@@ -17,6 +17,8 @@
 #include <cstring>
 #include <numeric>
 #include <string_view>
+#include <cctype>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -584,8 +586,10 @@ namespace {
 // Calls line(name_begin, name_end, res_begin, res_end) for every data line: not the header (first line), not
 // blank, not a conservation line (one that starts with a blank); fields are separated by blanks, the first is
 // the sequence name, the second its residues of this block, anything behind (a running count) is ignored.
+// The header is the first line that is not blank; it must start with "CLUSTAL" or "MUSCLE" (either case), otherwise
+// the text is not Clustal and the walk reports so (returns false) without calling `line`.
 template <class Line>
-void clustal_walk(const uint8_t *data, int64_t len, Line &&line) {
+bool clustal_walk(const uint8_t *data, int64_t len, Line &&line) {
     const uint8_t *p = data, *end = data + len;
     bool first = true;
     while (p < end) {
@@ -594,6 +598,17 @@ void clustal_walk(const uint8_t *data, int64_t len, Line &&line) {
         const uint8_t *a = p;
         p = eol + 1;
         if (first) {
+            const uint8_t *h = a;
+            while (h < eol && fasta_space(*h)) ++h;
+            if (h == eol) continue;  // blank lines in front of the header
+            auto starts = [&](const char *word) {
+                const size_t k = std::strlen(word);
+                if (static_cast<size_t>(eol - h) < k) return false;
+                for (size_t i = 0; i < k; ++i)
+                    if (std::toupper(h[i]) != word[i]) return false;
+                return true;
+            };
+            if (!starts("CLUSTAL") && !starts("MUSCLE")) return false;
             first = false;
             continue;
         }
@@ -607,6 +622,7 @@ void clustal_walk(const uint8_t *data, int64_t len, Line &&line) {
         while (re < eol && !fasta_space(*re)) ++re;
         line(a, ne, rb, re);
     }
+    return !first;  // (no header at all: not Clustal either)
 }
 inline bool same_name(const uint8_t *a, const uint8_t *ae, const uint8_t *b, int32_t blen) {
     return ae - a == blen && std::memcmp(a, b, static_cast<size_t>(blen)) == 0;
@@ -622,7 +638,7 @@ extern "C" int msa_clustal_scan(const uint8_t *data, int64_t len, int32_t *m_out
     int32_t first_len = 0;
     int64_t m = 0, n = 0;
     bool first_block = true;
-    clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
+    const bool is_clustal = clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
         const std::string_view name(reinterpret_cast<const char *>(a), static_cast<size_t>(ae - a));
         if (!first) {
             first = a;
@@ -634,6 +650,7 @@ extern "C" int msa_clustal_scan(const uint8_t *data, int64_t len, int32_t *m_out
         }
         if (same_name(a, ae, first, first_len)) n += re - rb;
     });
+    if (!is_clustal) return MSA_E_INVALID;  // no "CLUSTAL ..." / "MUSCLE ..." header: the caller's own parser reports it
     if (m > INT32_MAX || n > INT32_MAX) return MSA_E_INVALID;
     *m_out = static_cast<int32_t>(m);
     *n_out = static_cast<int32_t>(n);
@@ -644,6 +661,8 @@ extern "C" int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int
                                 int64_t *name_off, int32_t *name_len, const uint8_t *valid, msa_err_detail *detail) {
     if (!data || len < 0 || m < 0 || n < 0 || (!matrix && (int64_t)m * n > 0) || !name_off || !name_len) return MSA_E_INVALID;
     std::vector<int64_t> col(static_cast<size_t>(m), 0);
+    std::unordered_map<std::string_view, int32_t> rows;  // name -> row (the first block's names, as they appear)
+    rows.reserve(static_cast<size_t>(m) * 2);
     int32_t known = 0, expect = 0;  // names seen so far; the row the next line should belong to (block order)
     int rc = MSA_OK;
     auto fail = [&](int code, int64_t r, int64_t c, int byte) {
@@ -655,14 +674,15 @@ extern "C" int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int
             detail->byte = byte;
         }
     };
-    clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
+    const bool is_clustal = clustal_walk(data, len, [&](const uint8_t *a, const uint8_t *ae, const uint8_t *rb, const uint8_t *re) {
         if (rc != MSA_OK) return;
         int32_t row = -1;
         if (expect < known && same_name(a, ae, data + name_off[expect], name_len[expect])) {
             row = expect;  // the usual case: every block lists the sequences in the same order
         } else {
-            for (int32_t r = 0; r < known && row < 0; ++r)
-                if (same_name(a, ae, data + name_off[r], name_len[r])) row = r;
+            const std::string_view name(reinterpret_cast<const char *>(a), static_cast<size_t>(ae - a));
+            const auto it = rows.find(name);
+            if (it != rows.end()) row = it->second;
             if (row < 0) {
                 if (known >= m) {  // a name the scan did not count (it appears after the first block only)
                     fail(MSA_E_INVALID, known, 0, 0);
@@ -671,6 +691,7 @@ extern "C" int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int
                 row = known++;
                 name_off[row] = a - data;
                 name_len[row] = static_cast<int32_t>(ae - a);
+                rows.emplace(name, row);
             }
         }
         expect = row + 1 < m ? row + 1 : 0;
@@ -685,6 +706,7 @@ extern "C" int msa_clustal_fill(const uint8_t *data, int64_t len, int32_t m, int
             dst[c] = *q;
         }
     });
+    if (!is_clustal) return MSA_E_INVALID;
     if (rc != MSA_OK) return rc;
     if (known != m) return MSA_E_INVALID;
     for (int32_t r = 0; r < m; ++r)

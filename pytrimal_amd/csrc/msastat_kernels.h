@@ -19,7 +19,7 @@ struct Tuning {
     int sim_serial = 0;        // MSA_SIM_SERIAL: numerator and denominator kernel on one stream
     int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
     int trace = 0;             // MSA_TRACE
-    int upload_piece_mb = 2;   // MSA_UPLOAD_PIECE_MB: rows are packed and sent in pieces of this size (0: one copy after packing everything)
+    int upload_piece_kb = 1024;  // MSA_UPLOAD_PIECE_KB: rows are packed and sent in pieces of this size (0: one copy after packing everything)
     int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int bx_cols = 0;           // MSA_BX_COLS: columns per wave of the binade-exact kernel (0 = default)
@@ -29,6 +29,7 @@ struct Tuning {
     int bx_asm = 0;            // MSA_BX_ASM=1: the round loop with the table read folded into the multiply (inline asm; experimental)
     int lg_regs = 0;           // MSA_LG_REGS=1: the per-lane-grid kernel keeps the lane's table column in registers (not LDS)
     int lg_dbg = 0;            // MSA_LG_DBG: diagnostics of that kernel (1: no W loads, 64: W rows by buffer loads, 128: by compiler-addressed global loads -- all with MSA_SIM_MODE=64 only; 2: eight waves per workgroup; 16: two columns per wave without wave priorities)
+    int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per wave of the pair-count kernel (8, 16, 32; 0 = default)
     int pair_dense = 1;        // MSA_PAIR_DENSE: 0 the pair pass always on the seven raw symbol planes, 1 dense codes from 1500 sequences on, 2 always
     int pair_pipe = 1;         // MSA_PAIR_PIPE=0: the pair-count loop as the compiler schedules it instead of the software-pipelined one

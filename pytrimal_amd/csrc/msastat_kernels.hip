@@ -1127,8 +1127,7 @@ __global__ __launch_bounds__(512) void similarity_pc_kernel(
             float q = 0.0f, v = 0.0f;
             if (!skip && acc.y != 0.0f) {
                 q = acc.x / acc.y;
-                v = (float)exp(-(double)q);
-                v = v > 1.0f ? 1.0f : v;
+                v = __uint_as_float(0x7FC00000u);  // (the host evaluates the exponential: see sim_finish_kernel)
             }
             if (q_out) q_out[c] = q;
             mdk_out[c] = v;
@@ -2105,10 +2104,16 @@ __global__ __launch_bounds__(512) void similarity_num_kernel(
     }
 }
 
-// MDK from the two sums (Similarity::calculateVectors tail): 0 for >= 80 % gaps or an empty denominator
+// MDK from the two sums (Similarity::calculateVectors tail): 0 for >= 80 % gaps or an empty denominator, else
+// min(1, (float)exp(-(double)Q)).  Q = num / den is bit-exact; the exponential is the device library's, which may differ
+// from the host's in the last place of the DOUBLE -- and then in the float only when the double lies within a few of
+// its own ulps of a point where the conversion to float changes its result.  Such a value (and one in the float
+// denormal range, where flush modes could differ) is not trusted: it goes out as a NaN and the host evaluates
+// (float)exp(-(double)Q) itself (fetch_similarity_finish).  Both libraries are accurate to an ulp, so every value that
+// passes the test rounds to the same float on both sides: MDK is bit-identical to the host computation by construction.
 __global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict__ num, const float *__restrict__ den,
                                                          const int32_t *__restrict__ gaps_w, int m, int n,
-                                                         float *__restrict__ q_out, float *__restrict__ mdk_out) {
+                                                         float *__restrict__ q_out, float *__restrict__ mdk_out, int all_on_host) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
@@ -2116,8 +2121,15 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict
     const float d = den[c];
     if (!skip && d != 0.0f) {
         q = num[c] / d;
-        v = (float)exp(-(double)q);
-        v = v > 1.0f ? 1.0f : v;
+        const double e = exp(-(double)q);
+        v = (float)e;
+        bool safe = e >= 1e-37 && !all_on_host;
+        if (safe) {
+            const double up = (double)__uint_as_float(__float_as_uint(v) + 1u), dn = (double)__uint_as_float(__float_as_uint(v) - 1u);
+            const double tol = e * 0x1p-49;  // eight ulps of the double
+            safe = (0.5 * (up + (double)v) - e) > tol && (e - 0.5 * (dn + (double)v)) > tol;
+        }
+        v = safe ? (v > 1.0f ? 1.0f : v) : __uint_as_float(0x7FC00000u);
     }
     if (q_out) q_out[c] = q;
     mdk_out[c] = v;
@@ -2415,7 +2427,7 @@ Tuning tuning_from_env() {
     t.device_clusters = num("MSA_DEVICE_CLUSTERS", -1);
     t.trace = getenv("MSA_TRACE") != nullptr;
     t.pipeline = num("MSA_PIPELINE", 1);
-    t.upload_piece_mb = num("MSA_UPLOAD_PIECE_MB", 2);
+    t.upload_piece_kb = num("MSA_UPLOAD_PIECE_KB", 1024);
     t.bx_cols = num("MSA_BX_COLS", 0);
     t.bx_r0 = num("MSA_BX_R0", -1);
     t.bx_waves = num("MSA_BX_WAVES", 0);
@@ -2427,6 +2439,7 @@ Tuning tuning_from_env() {
     t.bx_asm = num("MSA_BX_ASM", 0);
     t.lg_regs = num("MSA_LG_REGS", 0);
     t.lg_dbg = num("MSA_LG_DBG", 0);
+    t.mdk_host = num("MSA_MDK_HOST", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {
@@ -2624,7 +2637,7 @@ int launch_similarity_num(hipStream_t s, const void *codes8, int m, int n, int64
 
 void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,
                        float *q_out, float *mdk_out) {
-    sim_finish_kernel<<<(n + 255) / 256, 256, 0, s>>>(num, den, gaps_w, m, n, q_out, mdk_out);
+    sim_finish_kernel<<<(n + 255) / 256, 256, 0, s>>>(num, den, gaps_w, m, n, q_out, mdk_out, tuning().mdk_host);
 }
 
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,

@@ -129,6 +129,14 @@ class SimilarityMatrix:
                 dist[i, j] = dist[j, i] = np.float32(math.sqrt(float(total)))
         self._dist = dist
 
+    def _device_arrays(self):
+        """(vhash int32[26], dist float32[size * size]), C-contiguous: what `msa_trim_params` points into (built once)."""
+        arrs = getattr(self, "_c_arrays", None)
+        if arrs is None:
+            arrs = self._c_arrays = (np.ascontiguousarray(self._vhash, dtype=np.int32),
+                                     np.ascontiguousarray(self._dist, dtype=np.float32))
+        return arrs
+
     def __len__(self):
         return self._size
 

@@ -8,6 +8,7 @@ instead; the only compute platform of this package is ``"hip"``.
 """
 import ctypes
 import functools
+import logging
 import warnings
 
 import numpy as np
@@ -16,6 +17,7 @@ from . import _lib
 from .alignment import Alignment, TrimmedAlignment
 from .matrix import SimilarityMatrix
 
+_log = logging.getLogger("pytrimal_amd")
 
 @functools.lru_cache(maxsize=None)
 def _default_matrix(kind):
@@ -42,21 +44,25 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
-def _raise_warnings(info, names):
-    """The `MSA_W_*` bits of `msa_trim_info.warnings` as `RuntimeWarning`, the category the reference gives to
-    trimAl's warnings (``/root/reference/src/trimal/source/reportsystem.cpp:132-173``)."""
+def _raise_warnings(info, names, only_gaps_rows):
+    """trimAl's warnings as `RuntimeWarning`, the category the reference gives them
+    (``/root/reference/src/trimal/source/reportsystem.cpp:132-173``).  Only what maps to a trimAl `WarningCode`
+    is raised: one warning per sequence removed because the trimming left it with gaps only
+    (RemovingOnlyGapsSequence [R], reported per sequence by Cleaner::removeAllGapsSeqsAndCols).  The other `MSA_W_*`
+    bits (every column removed, undefined identities) have no counterpart among the reference's warnings: a caller
+    running with `-W error` must not see exceptions the reference would not raise, so they go to the
+    `pytrimal_amd` logger instead."""
     w = info.warnings
     if not w:
         return
     if w & _lib.W_ONLY_GAPS_SEQUENCES:
-        first = names[info.warn_row].decode("ascii", "replace") if 0 <= info.warn_row < len(names) else "?"
-        warnings.warn(f"removing sequences composed only by gaps after the trimming (first: {first!r})",
-                      RuntimeWarning, stacklevel=3)
+        for i in only_gaps_rows or [info.warn_row]:
+            name = names[i].decode("ascii", "replace") if 0 <= i < len(names) else "?"
+            warnings.warn(f"Removing sequence '{name}' composed only by gaps", RuntimeWarning, stacklevel=3)
     if w & _lib.W_NO_COLUMNS_LEFT:
-        warnings.warn("the trimming removed every column of the alignment", RuntimeWarning, stacklevel=3)
+        _log.info("the trimming removed every column of the alignment")
     if w & _lib.W_UNDEFINED_IDENTITY:
-        warnings.warn("some pairs of sequences share no residue column: their identity is taken as 0",
-                      RuntimeWarning, stacklevel=3)
+        _log.info("some pairs of sequences share no residue column: their identity is taken as 0")
 
 
 def _check_range(value, name, lo, hi, cast=float):
@@ -119,11 +125,9 @@ class BaseTrimmer:
     def _configure(self, params):
         pass
 
-    def trim(self, alignment, matrix=None):
-        """Trim the provided alignment and return a `TrimmedAlignment`.
-
-        Re-entrant: each thread works on its own device context and stream.
-        """
+    def _prepare(self, alignment, matrix=None):
+        """What `trim` hands to the C ABI for one alignment: (names, dense residue matrix, indetermination symbol,
+        parameter block, objects the block points into)."""
         if not isinstance(alignment, Alignment):
             raise TypeError(f"expected Alignment, found {type(alignment).__name__}")
         if matrix is not None and not isinstance(matrix, SimilarityMatrix):
@@ -134,8 +138,6 @@ class BaseTrimmer:
                 "(platform=None / no visible device); construct the trimmer with platform='hip' on a GPU host")
         # a TrimmedAlignment is first materialised to its kept sequences / residues (_trimal.pyx:1324-1327)
         dense = alignment._dense()
-        names = alignment.names
-        m, n = dense.shape
         ty = alignment._alignment_type()
         indet = ord("X") if (ty & 4) else ord("N")
         if matrix is None:
@@ -144,23 +146,41 @@ class BaseTrimmer:
                 matrix = _default_matrix("aa")
             else:
                 matrix = _default_matrix("ntdeg" if ty & 8 else "nt")
-
         params = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
         self._configure(params)
-        vhash = np.ascontiguousarray(matrix._vhash, dtype=np.int32)
-        dist = np.ascontiguousarray(matrix._dist, dtype=np.float32)
+        vhash, dist = matrix._device_arrays()
         params.vhash = vhash.ctypes.data_as(ctypes.c_void_p)
         params.dist = dist.ctypes.data_as(ctypes.c_void_p)
         params.npos = len(matrix)
+        return alignment.names, dense, indet, params, (vhash, dist, matrix)
 
+    @staticmethod
+    def _finish(names, dense, datatype, keep_res, keep_seq, info, only_gaps_rows, gaps_w, params):
+        """masks -> `TrimmedAlignment` (+ the warnings trimAl would have reported)"""
+        if info is not None and info.warnings:
+            _raise_warnings(info, names, only_gaps_rows)
+        out = TrimmedAlignment._from_parts(names, dense, datatype, keep_seq, keep_res)
+        # what `terminal_only` needs of the gap statistics this trim computed (trimAl's trimmed alignment shares the
+        # statistics object of its source): the half window, and the windowed vector itself when the trim fetched it
+        out._gap_hw = max(params.window if params.window != -1 else params.gap_window, 0)
+        out._gaps_w = gaps_w
+        return out
+
+    def trim(self, alignment, matrix=None):
+        """Trim the provided alignment and return a `TrimmedAlignment`.
+
+        Re-entrant: each thread works on its own device context and stream.
+        """
+        names, dense, indet, params, _keep = self._prepare(alignment, matrix)
+        m, n = dense.shape
         if m == 0 or n == 0:
-            keep_res, keep_seq = np.ones(n, dtype=bool), np.ones(m, dtype=bool)
-        else:
-            ctx = _lib.thread_context()
-            ctx.upload(dense, indet)
-            keep_res, keep_seq, info = ctx.trim(params)
-            _raise_warnings(info, names)
-        return TrimmedAlignment._from_parts(names, dense, alignment._datatype, keep_seq, keep_res)
+            return self._finish(names, dense, alignment._datatype, np.ones(n, dtype=bool), np.ones(m, dtype=bool), None, None, None, params)
+        ctx = _lib.thread_context()
+        ctx.upload(dense, indet)
+        keep_res, keep_seq, info = ctx.trim(params)
+        rows = ctx.only_gaps_rows() if info.warnings & _lib.W_ONLY_GAPS_SEQUENCES else None
+        hw = max(params.window if params.window != -1 else params.gap_window, 0)
+        return self._finish(names, dense, alignment._datatype, keep_res, keep_seq, info, rows, ctx.gaps_cached(hw), params)
 
 
 class AutomaticTrimmer(BaseTrimmer):
@@ -177,6 +197,15 @@ class AutomaticTrimmer(BaseTrimmer):
             raise TypeError(f"expected str, found {type(method).__name__}")
         if method not in self.METHODS:
             raise ValueError(f"Invalid value for `method`: {method!r}")
+        if method == "automated2":
+            # A name of the reference's API (`_trimal.pyx:1384,1417,1494-1495`) whose algorithm is not in the reference
+            # tree (trimAl submodule empty) and whose only test fixture is a dangling symlink: there is nothing to
+            # restate it from and nothing to check a restatement against.  Refused here, where the method is chosen,
+            # not from inside `trim()`.
+            raise NotImplementedError(
+                "method 'automated2' is not available in this build: trimAl's implementation is not part of the reference "
+                "checkout and no fixture of it survives, so it could be neither restated nor verified; use 'automated1', "
+                "'gappyout', 'strict' or 'strictplus'")
         self.method = method
 
     def __repr__(self):

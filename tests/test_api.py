@@ -38,6 +38,9 @@ def test_automatic_trimmer_validation_and_repr():
     assert repr(AutomaticTrimmer("automated1")) == "AutomaticTrimmer('automated1')"
     assert AutomaticTrimmer.METHODS == frozenset({"strict", "strictplus", "gappyout", "nogaps", "noallgaps",
                                                   "automated1", "automated2", "noduplicateseqs"})
+    # a name of the reference's API that this build cannot honour: refused where the method is chosen, with the reason
+    with pytest.raises(NotImplementedError, match="automated2"):
+        AutomaticTrimmer("automated2")
     if BEST == "hip":
         assert repr(AutomaticTrimmer("noduplicateseqs", platform=None)) == "AutomaticTrimmer('noduplicateseqs', platform=None)"
 
@@ -394,6 +397,63 @@ def test_trimmed_alignment_dumps_only_kept_cells():
         assert back.names == [n for n, k in zip(names, keep_seq) if k]
 
 
+# --- writers against files the reference's tests hold (written by trimAl): byte for byte.  The masks come from the CPU
+# --- oracle (no device here); the GPU suite checks that the device produces the same masks.
+
+def _enog_alignment():
+    import oracle
+
+    names, seqs = oracle.read_fasta(data_path("ENOG411BWBU.seq40.res60.fasta"))
+    return names, oracle.pack(seqs)
+
+
+@pytest.mark.parametrize("kw,fname", [
+    (dict(gap_threshold=0.9, conservation_percentage=60), "ENOG411BWBU.cons60.gt90.fasta"),
+    (dict(gap_threshold=0.4, conservation_percentage=40), "ENOG411BWBU.cons40.gt40.fasta"),
+    (dict(sequence_overlap=80, residue_overlap=0.8), "ENOG411BWBU.seq80.res80.fasta"),
+    (dict(sequence_overlap=40, residue_overlap=0.6), "ENOG411BWBU.seq40.res60.fasta"),
+    (dict(identity_threshold=0.75), "ENOG411BWBU.maxidentity75.fasta"),
+    (dict(identity_threshold=0.7), "ENOG411BWBU.id70.fasta"),
+    (dict(identity_threshold=0.5), "ENOG411BWBU.id50.fasta"),
+    (dict(method="noduplicateseqs"), "ENOG411BWBU.noduplicateseqs.fasta"),
+])
+def test_fasta_writer_reproduces_the_reference_fixtures_byte_for_byte(tmp_path, kw, fname):
+    """`TrimmedAlignment.dumps("fasta")` / `dump` (reference `_trimal.pyx:604-731`) of the P1-P4 results = the files
+    trimAl wrote for the reference's tests (60 residues per line, the name alone on the header line)."""
+    import oracle
+
+    names, a = _enog_alignment()
+    res, seq, _ = oracle.trim(a, **kw)
+    t = TrimmedAlignment._from_parts(names, a, 0, seq, res)
+    with open(data_path(fname), "rb") as f:
+        expected = f.read()
+    assert t.dumps("fasta").encode() == expected
+    out = tmp_path / "out.fasta"
+    t.dump(str(out), "fasta")
+    assert out.read_bytes() == expected
+    buf = io.BytesIO()
+    t.dump(buf, "fasta")
+    assert buf.getvalue() == expected
+
+
+def test_clustal_writer_reproduces_the_reference_fixture_body():
+    """The one trimAl-written Clustal file of the reference (`example.001.gt90.w3.clw`, the expected result of
+    `tests/test_manual_trimmer.py:37-42`): every byte behind the header line.  The header line itself
+    ("CLUSTAL 2.0.12 ...") is the header of the ClustalW file trimAl read, carried over; an in-memory alignment has
+    no such line and gets trimAl's default one."""
+    import oracle
+
+    a = oracle.pack(EXAMPLE_001)
+    res, seq, _ = oracle.trim(a, gap_threshold=0.9, window=3)
+    t = TrimmedAlignment._from_parts(list(EXAMPLE_001_NAMES), a, 0, seq, res)
+    with open(data_path("example.001.gt90.w3.clw"), "rb") as f:
+        expected = f.read()
+    got = t.dumps("clustal").encode()
+    assert got.split(b"\n", 1)[0] == b"CLUSTAL multiple sequence alignment"
+    assert expected.split(b"\n", 1)[0] == b"CLUSTAL 2.0.12 multiple sequence alignment"
+    assert got.split(b"\n", 1)[1] == expected.split(b"\n", 1)[1]
+
+
 def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
     """`msa_clustal_scan` / `msa_clustal_fill` (C ABI, host code) against the line-splitting parser they replace:
     the reference's fixture, the 6 x 46 example in three blocks with counts and conservation lines, blocks whose
@@ -433,12 +493,31 @@ def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
         Alignment.load(io.BytesIO(b"CLUSTAL\n\na AC!T\nb ACGT\n"), "clustal")
 
 
-def test_terminal_only_without_sequences_left():
-    """every sequence dropped: the gap statistic over nothing holds no gap, every column is restored (the oracle's
-    reading 0 of Cleaner::removeOnlyTerminal); needs no device"""
+def test_terminal_only_mask_logic_without_a_device():
+    """`TrimmedAlignment.terminal_only` (Cleaner::removeOnlyTerminal, [R] unverified): boundaries = first / last column
+    without gaps in the gap vector of the ORIGINAL alignment (every sequence, kept or not), everything between them
+    restored, the outside untouched -- against the oracle's restatement (reading 2), on masks built by hand.  No
+    device: the counts are host counts over the bytes."""
     import oracle
 
-    a = oracle.pack(["AC-DE", "A--DE", "-C-DE"])
-    t = TrimmedAlignment([b"a", b"b", b"c"], ["AC-DE", "A--DE", "-C-DE"], sequences_mask=[False] * 3, residues_mask=[False] * 5)
-    want = oracle.terminal_only(a, [False] * 5, [False] * 3, reading=0)
-    assert want is not None and t.terminal_only().residues_mask == [bool(x) for x in want] == [True] * 5
+    seqs = ["-AC-DE-", "-A--DEF", "--C-DEF", "-ACGDE-"]
+    a = oracle.pack(seqs)
+    names = [b"a", b"b", b"c", b"d"]
+    for seq_mask in ([True] * 4, [True, False, True, True], [False] * 4):
+        for res_mask in ([False] * 7, [c % 2 == 0 for c in range(7)], [True] * 7):
+            t = TrimmedAlignment(names, seqs, sequences_mask=seq_mask, residues_mask=res_mask)
+            want = oracle.terminal_only(a, res_mask, seq_mask, reading=2)
+            got = t.terminal_only()
+            assert got.residues_mask == [bool(x) for x in want] and got.sequences_mask == list(seq_mask)
+            # columns 4 and 5 (D, E) are the only ones without a gap: restored, like everything between them
+            assert got.residues_mask[4] and got.residues_mask[5] and got.residues_mask[:4] == list(res_mask[:4])
+    # a windowed gap vector cached by the trim that produced the object takes the place of the host count
+    t = TrimmedAlignment(names, seqs, residues_mask=[False] * 7)
+    t._gaps_w = np.array([4, 1, 0, 3, 0, 0, 2], dtype=np.int32)
+    want = oracle.terminal_only(a, [False] * 7, [True] * 4, reading=2, gaps_w=t._gaps_w)
+    assert t.terminal_only().residues_mask == [bool(x) for x in want] == [False, False, True, True, True, True, False]
+    assert t.terminal_only().terminal_only().residues_mask == t.terminal_only().residues_mask
+    # no column without gaps: an error, as upstream reports one
+    with pytest.raises(RuntimeError):
+        TrimmedAlignment([b"a", b"b"], ["A-", "-C"]).terminal_only()
+    assert oracle.terminal_only(oracle.pack(["A-", "-C"]), [True, True], [True, True], reading=2) is None

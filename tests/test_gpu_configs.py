@@ -92,6 +92,67 @@ def test_c5_batch_golden(golden):
         assert single.residues_mask == out[k].residues_mask and single.sequences_mask == out[k].sequences_mask
 
 
+def test_native_batch_equals_one_by_one():
+    """`msa_trim_batch` (native worker threads, one context each) on a mixed bag -- shapes from 3 x 40 to 700 x 900,
+    protein and DNA, every trimmer class, an empty alignment, windows -- against `trimmer.trim` one alignment at a
+    time and the oracle; then an alignment with a residue outside the similarity matrix (the batch raises what the
+    single trim raises); then the per-sequence warnings of a trim that leaves sequences with gaps only."""
+    import warnings
+
+    import oracle
+    from pytrimal_amd import ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer
+    from pytrimal_amd.batch import trim_batch
+
+    rng = np.random.default_rng(5)
+    alis, mats = [], []
+    for k, (m, n) in enumerate([(3, 40), (64, 256), (700, 900), (65, 129), (200, 2000), (31, 33), (128, 64), (330, 700)]):
+        a = synth_msa(m, n, 900 + k)
+        if k % 3 == 1:  # DNA
+            a = np.frombuffer(b"ACGT-", dtype=np.uint8)[rng.integers(0, 5, (m, n))].copy()
+        mats.append(np.ascontiguousarray(a))
+        alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a]))
+    alis.append(Alignment([], []))
+    mats.append(np.zeros((0, 0), dtype=np.uint8))
+    cases = [(AutomaticTrimmer("automated1", platform="hip"), dict(method="automated1")),
+             (AutomaticTrimmer("strictplus", platform="hip"), dict(method="strictplus")),
+             (ManualTrimmer(gap_threshold=0.6, similarity_threshold=0.2, window=2, platform="hip"),
+              dict(gap_threshold=0.6, similarity_threshold=0.2, window=2)),
+             (OverlapTrimmer(50, 0.6, platform="hip"), dict(sequence_overlap=50, residue_overlap=0.6)),
+             (RepresentativeTrimmer(identity_threshold=0.4, platform="hip"), dict(identity_threshold=0.4))]
+    for trimmer, okw in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = trim_batch(trimmer, alis, threads=5)
+            single = [trimmer.trim(x) for x in alis]
+        assert len(out) == len(alis)
+        for a, t, s1 in zip(mats, out, single):
+            assert t.residues_mask == s1.residues_mask and t.sequences_mask == s1.sequences_mask
+            assert t.names == s1.names and list(t.sequences) == list(s1.sequences)
+            if a.size:
+                res, seq, _ = oracle.trim(a, **okw)
+                assert t.residues_mask == [bool(x) for x in res] and t.sequences_mask == [bool(x) for x in seq]
+                ends = []
+                for x in (t, s1):  # (the batch result counts the gaps on the host, the single trim reuses the trim's vector)
+                    try:
+                        ends.append(x.terminal_only().residues_mask)
+                    except RuntimeError:
+                        ends.append(None)
+                assert ends[0] == ends[1]
+    bad = Alignment([b"a", b"b", b"c"], ["MKKBO", "MKKAY", "MKRAY"])  # 'O' is not in the amino-acid matrix
+    with pytest.raises(ValueError):
+        AutomaticTrimmer("strict", platform="hip").trim(bad)
+    with pytest.raises(ValueError):
+        trim_batch(AutomaticTrimmer("strict", platform="hip"), alis[:3] + [bad], threads=3)
+    gappy = Alignment([b"x", b"y", b"z", b"w"], ["A--A", "-CC-", "-DD-", "-EE-"])
+    for run in (lambda: [ManualTrimmer(gap_threshold=0.6, platform="hip").trim(gappy)],
+                lambda: trim_batch(ManualTrimmer(gap_threshold=0.6, platform="hip"), [gappy, alis[0]], threads=2)):
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            t = run()[0]
+        assert t.sequences_mask == [False, True, True, True] and t.residues_mask == [False, True, True, False]
+        assert [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)] == ["Removing sequence 'x' composed only by gaps"]
+
+
 def test_batch_module_in_a_fresh_process():
     """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
     package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`

@@ -2,7 +2,9 @@
 
 Bit-exact for every integer output (gap counts, hit/dst, masks) and for the float32 identity /
 weight matrices and the similarity quotient Q (the reference's sequential accumulation order is
-reproduced); MDK = exp(-Q) is held to the 1e-6 absolute tolerance BASELINE.json states.
+reproduced) and for MDK = min(1, (float)exp(-(double)Q)): the device only keeps an exponential that
+provably rounds to the same float as the host's (sim_finish_kernel), the others are evaluated on the host.
+No float tolerance anywhere in this suite.
 """
 import os
 
@@ -16,7 +18,6 @@ from pytrimal_amd.synth import synth_msa
 
 pytestmark = pytest.mark.gpu
 
-MDK_TOL = 1e-6  # BASELINE.json north_star: "within 1e-6 for float similarity"
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +35,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
-                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI", "MSA_PAIR_DENSE"):
+                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI", "MSA_PAIR_DENSE"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -86,7 +87,7 @@ def all_stats(ctx, a, indet=ord("X"), matrix=None):
         return err
     mdk, q = ctx.similarity(vhash, dist)
     assert np.array_equal(bits(q), bits(oq)), "similarity quotient must be bit-exact (reference order)"
-    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL if n else True
+    assert np.array_equal(bits(mdk), bits(omdk)), "MDK must be bit-exact"
     for thr in (0.5, 0.8):
         ov = ctx.overlap(thr)
         assert np.array_equal(bits(ov), bits(oracle.overlap(a, thr, indet)))
@@ -180,12 +181,28 @@ def test_windowed_gap_cut_vector(ctx):
     omdk, oq = oracle.similarity(a, oracle.weights(hit, dst), gw, vhash, dist)
     mdk, q = ctx.similarity(vhash, dist, gw)
     assert np.array_equal(bits(q), bits(oq))
-    assert np.max(np.abs(mdk - omdk)) <= MDK_TOL
+    assert np.array_equal(bits(mdk), bits(omdk))
 
 
 def test_c2_full_size(ctx):
     # BASELINE config 2: 500 x 2000, every statistic against the oracle
     all_stats(ctx, synth_msa(500, 2000, 1002))
+
+
+def test_mdk_exponentials_device_and_host_agree(ctx_with):
+    """MDK values the device vouches for (sim_finish_kernel's rounding test) against the same values with every
+    exponential handed to the host (MSA_MDK_HOST=1): identical bits, and both equal to the oracle's."""
+    a = synth_msa(300, 6000, 77)
+    vhash, dist = oracle.aa_matrix()
+    out = []
+    for env in ({}, {"MSA_MDK_HOST": "1"}):
+        c = ctx_with(**env)
+        c.upload(a, ord("X"))
+        out.append(c.similarity(vhash, dist))
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(bits(out[0][1]), bits(out[1][1]))
+    hit, dst = oracle.pair_counts(a)
+    omdk, _ = oracle.similarity(a, oracle.weights(hit, dst), oracle.gaps(a)[0], vhash, dist)
+    assert np.array_equal(bits(out[0][0]), bits(omdk))
 
 
 def test_attach_device_buffer(ctx):
@@ -242,7 +259,7 @@ def test_c3_full_size_properties(ctx):
         sl = slice(c0, c0 + 64)
         omdk, oq = oracle.similarity(np.ascontiguousarray(a[:, sl]), w, g[sl], vhash, dist)
         assert np.array_equal(bits(q[sl]), bits(oq))
-        assert np.max(np.abs(mdk[sl] - omdk)) <= MDK_TOL
+        assert np.array_equal(bits(mdk[sl]), bits(omdk))
     assert (mdk[(g / np.float32(m)) >= np.float32(0.8)] == 0).all()
     assert ((mdk >= 0) & (mdk <= 1)).all()
     avg, mx = ctx.identity_stats()
@@ -371,7 +388,7 @@ def _sim_parity(ctx, a, indet=ord("X")):
     omdk, oq = oracle.similarity(a, ow, og, vhash, dist, indet)
     mdk, q = ctx.similarity(vhash, dist)
     assert np.array_equal(bits(q), bits(oq)), "similarity quotient must be bit-exact (reference order)"
-    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
+    assert np.array_equal(bits(mdk), bits(omdk))
 
 
 # binade-exact with per-lane grids: one column per wave (default = "lg") / two columns per wave; its
@@ -558,7 +575,7 @@ def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
     omdk, oq = oracle.similarity(a, oracle.weights(ohit, odst), og, *matrix, ord("X"))
     mdk, q = ctx.similarity(*matrix)
     assert np.array_equal(bits(q), bits(oq))
-    assert np.max(np.abs(mdk.astype(np.float64) - omdk)) <= MDK_TOL
+    assert np.array_equal(bits(mdk), bits(omdk))
 
 
 @pytest.mark.parametrize("seed", [21, 22])

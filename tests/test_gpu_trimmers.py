@@ -21,6 +21,7 @@ from pytrimal_amd import (
     SimilarityMatrix,
     TrimmedAlignment,
 )
+from pytrimal_amd import _lib
 from pytrimal_amd.synth import synth_msa
 
 pytestmark = pytest.mark.gpu
@@ -113,9 +114,18 @@ def test_strictplus_readme_example():
                                        "GIYLSWYLAWLGLEINMMAII", "GFLLTWFQLWQGLDLNKMPVF", "GLHMAWFQAWGGLEINKQAIL"]
 
 
-def test_automated2_is_not_implemented(enog_ali):
-    with pytest.raises(RuntimeError):
-        AutomaticTrimmer("automated2", platform=PLATFORM).trim(enog_ali)
+def test_automated2_is_refused_by_the_c_abi(enog_ali):
+    """The Python constructor refuses the method (tests/test_api.py); a caller of the C ABI gets a return code."""
+    import ctypes
+
+    ctx = _lib.Context(0)
+    names, seqs = enog_ali.names, list(enog_ali.sequences)
+    ctx.upload(oracle.pack(seqs), ord("X"))
+    P = _lib.TrimParams(_lib.METHOD_CODES["automated2"], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
+    with pytest.raises(_lib.MsaError) as err:
+        ctx.trim(P)
+    assert err.value.code == _lib.E_NOT_IMPLEMENTED
+    ctx.close()
 
 
 def test_custom_similarity_matrix(enog_ali):
@@ -260,7 +270,11 @@ def test_terminal_only_against_oracle(enog_ali):
     cases.append(TrimmedAlignment([b"a"], ["ACDEFG"], residues_mask=[False, True, False, True, True, False]))
     for t in cases:
         a = oracle.pack(list(t.original_alignment().sequences))
-        want = oracle.terminal_only(a, t.residues_mask, t.sequences_mask, reading=0)
+        # reading 2: the gap vector of the original alignment -- the trim's own (windowed) counts when it fetched them
+        gw = getattr(t, "_gaps_w", None)
+        if gw is not None:
+            assert np.array_equal(gw, oracle.gaps(a)[0])  # (no window in these trims)
+        want = oracle.terminal_only(a, t.residues_mask, t.sequences_mask, reading=2, gaps_w=gw)
         if want is None:
             with pytest.raises(RuntimeError):
                 t.terminal_only()

@@ -205,7 +205,8 @@ def test_alignment_type_detection():
 
 
 def test_terminal_only_readings():
-    """The two readings of Cleaner::removeOnlyTerminal the oracle restates ([R]; the product follows reading 0)."""
+    """The readings of Cleaner::removeOnlyTerminal the oracle restates ([R], unverified; the product follows reading 2:
+    the gap vector of the original alignment, every sequence)."""
     a = oracle.pack(["A-CDEF-H", "ABC-EFGH", "ABCDEFG-"])
     keep = np.array([1, 0, 1, 0, 0, 1, 0, 1], dtype=bool)
     seqs = np.ones(3, dtype=bool)
@@ -216,6 +217,16 @@ def test_terminal_only_readings():
     # dropping the second sequence makes column 3 gap free and column 1 not
     assert oracle.terminal_only(a, keep, np.array([1, 0, 1], dtype=bool), reading=0).tolist() == [True] * 6 + [False, True]
     assert oracle.terminal_only(oracle.pack(["A-", "-B"]), [True, False], [True, True], reading=0) is None
+    # reading 2: the dropped sequence still counts (column 3 keeps its gap); with all sequences kept it equals reading 0
+    assert oracle.terminal_only(a, keep, np.array([1, 0, 1], dtype=bool), reading=2).tolist() == [True] * 6 + [False, True]
+    assert oracle.terminal_only(a, keep, seqs, reading=2).tolist() == oracle.terminal_only(a, keep, seqs, reading=0).tolist()
+    b = oracle.pack(["AB-D-", "A-CDE", "ABCDE"])
+    only_last = np.array([0, 0, 1], dtype=bool)
+    assert oracle.terminal_only(b, [False] * 5, only_last, reading=0).tolist() == [True] * 5   # the kept sequence holds no gap
+    # the original alignment: columns 0 and 3 are free of gaps -> 0 .. 3 come back, column 4 keeps the trimmer's decision
+    assert oracle.terminal_only(b, [False] * 5, only_last, reading=2).tolist() == [True] * 4 + [False]
+    assert oracle.terminal_only(b, [False] * 5, only_last, reading=2, gaps_w=[1, 0, 0, 1, 1]).tolist() == [False, True, True, False, False]
+
 
 
 @pytest.mark.skipif(oracle.lib_avx2() is None, reason="host CPU without AVX2")
