@@ -22,6 +22,7 @@
 #ifndef MSASTAT_H
 #define MSASTAT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -68,6 +69,11 @@ int msa_ctx_sync(msa_ctx *ctx);
 int msa_upload_rows(msa_ctx *ctx, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet);
 /* one packed row-major host buffer, leading dimension ld >= n */
 int msa_upload_packed(msa_ctx *ctx, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet);
+/* Page-lock the caller's rows so that uploads of them are one DMA copy at the link's rate, straight from where they lie
+ * (no staging, no packing).  Worth it for rows that are uploaded more than once; the range must be unregistered before
+ * its memory is released.  msa_upload_packed recognises page-locked memory by itself. */
+int msa_host_register(const void *rows, size_t bytes);
+int msa_host_unregister(const void *rows);
 /* residue matrix already resident in device memory (not copied, must outlive its use) */
 int msa_attach_device(msa_ctx *ctx, const void *rowmajor_dev, int32_t m, int32_t n, int64_t ld, uint8_t indet);
 

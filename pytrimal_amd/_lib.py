@@ -37,7 +37,7 @@ METHOD_CODES = {
 # every symbol include/msastat.h declares (tests check the library exports all of them)
 EXPORTS = [
     "msa_strerror", "msa_device_count", "msa_last_hip_error", "msa_ctx_create", "msa_ctx_destroy",
-    "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_attach_device",
+    "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_host_register", "msa_host_unregister", "msa_attach_device",
     "msa_gaps", "msa_gaps_cached", "msa_pair_counts", "msa_identities", "msa_identity_stats", "msa_similarity",
     "msa_overlap", "msa_window_i32", "msa_window_f32", "msa_gaps_cutpoint",
     "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
@@ -123,6 +123,8 @@ def load():
         L.msa_ctx_sync.argtypes = [vp]
         L.msa_upload_rows.argtypes = [vp, vp, i32, i32, ctypes.c_uint8]
         L.msa_upload_packed.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
+        L.msa_host_register.argtypes = [vp, ctypes.c_size_t]
+        L.msa_host_unregister.argtypes = [vp]
         L.msa_attach_device.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
         L.msa_gaps.argtypes = [vp, vp, vp]
         L.msa_gaps_cached.argtypes = [vp, i32, vp]
@@ -184,6 +186,30 @@ def ptr(arr):
     return None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
 
 
+_pinned = {}  # id(array) -> finalizer: arrays whose memory is page-locked for as long as the array object lives
+
+
+def pin_array(a):
+    """Page-lock the memory of a C-contiguous array (`msa_host_register`) until the array object dies: uploads of it are
+    then one DMA copy straight from its rows.  Returns False (and changes nothing) when that is not possible."""
+    import weakref
+
+    if id(a) in _pinned:
+        return True
+    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.nbytes == 0:
+        return False
+    lib, address = load(), a.ctypes.data
+    if lib.msa_host_register(ctypes.c_void_p(address), a.nbytes) != OK:
+        return False
+
+    def release(key=id(a)):
+        _pinned.pop(key, None)
+        lib.msa_host_unregister(ctypes.c_void_p(address))
+
+    _pinned[id(a)] = weakref.finalize(a, release)  # runs when the array is collected, before numpy frees the buffer
+    return True
+
+
 class MsaError(RuntimeError):
     def __init__(self, code, message, detail=None):
         super().__init__(message)
@@ -241,8 +267,12 @@ class Context:
             pass
 
     # --- uploads ---
-    def upload(self, matrix, indet):
+    def upload(self, matrix, indet, pin=False):
+        """`pin`: page-lock the rows first (once per array object; kept until the array dies) -- for rows that are
+        uploaded again and again."""
         a = np.ascontiguousarray(matrix, dtype=np.uint8)
+        if pin and a is matrix:
+            pin_array(a)
         m, n = a.shape
         check(self.lib, self.h, self.lib.msa_upload_packed(self.h, ptr(a), m, n, n, indet))
         self.shape = (m, n)

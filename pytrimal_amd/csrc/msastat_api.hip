@@ -87,15 +87,15 @@ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 }  // namespace
 
-struct SimOrder {  // the similarity kernel's column list: entries (padded), waves per workgroup of the two-column variant
-    int npad = 0, pair_waves = 0;
+struct SimOrder {  // the similarity kernel's column list: entries (padded)
+    int npad = 0;
 };
 
 struct msa_ctx {
     int device = 0;
     int cus = 256;  // compute units of the device
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // the similarity denominators run beside the numerator kernel
+    hipStream_t stream2 = nullptr;  // the side stream of msa_trim's pipeline (codes, lists, row totals beside the pair pass)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_digest = nullptr;  // behind the copies of row_digest_begin
     hipEvent_t ev_rowtot = nullptr;  // behind the copy of stage_row_totals
@@ -126,27 +126,23 @@ struct msa_ctx {
     bool have_gaps = false;
     DevBuf<float> ident, wmat;
     DevBuf<float> wlow;        // strictly lower triangular mirror of wmat (binade-exact similarity kernel)
+    DevBuf<float> wbar;        // mean weight of every row over its later partners (that kernel's predictor)
     DevBuf<uint8_t> codeT;     // column-major similarity codes of that kernel
     DevBuf<uint32_t> bx_off;   // ... and the compacted lists of every column's valid rows: W row offset,
     DevBuf<uint16_t> bx_row;   //     row index,
     DevBuf<uint8_t> bx_code;   //     code,
     DevBuf<uint16_t> bx_trow;  //     byte offset of the residue's row in a [row][64 lanes] float table
-    DevBuf<uint32_t> u_off, u_tt;  // union lists of the column pairs (two columns per wave): W row offset, two table-row offsets,
-    DevBuf<float> u_ee;            //     the two 1/0 flags,
-    DevBuf<int32_t> u_n;           //     entries per pair
     DevBuf<int32_t> bx_nvalid;
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
     PinBuf<int32_t> h_simcols;
-    std::vector<int32_t> sort_order, sort_bins;  // scratch of the column ordering
+    std::vector<int32_t> sort_bins;  // scratch of the column ordering
     SimOrder order;                 // the column list in h_simcols when order_ready (built ahead of similarity() by msa_trim)
-    bool order_ready = false, order_pairs2 = false;
+    bool order_ready = false;
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, row_min;
     DevView<float> stats2;  // {mean, max} of the identity rows (state block)
-    DevBuf<unsigned long long> pairmasks;  // denominator kernel: bit-interleaved validity words of row pairs
-    DevBuf<uint32_t> simcodes;  // similarity codes: [G8 + 1][ld] x 8 B (codes8) or [G8 + 1][2][ld] x 16 B (codes32)
     DevBuf<float> tables;  // {distance, both-valid} table followed by the byte -> code LUT: one upload, cached by content
     DevView<uint8_t> lut;
     DevView<float> tab;
@@ -175,7 +171,6 @@ struct msa_ctx {
     int gaps_staged = 0;           // 0 none, 1 copy enqueued, 2 copy complete (a synchronisation followed)
     PinBuf<int32_t> h_colcnt;      // residues per column over the sequences the device clustering kept (stage_kept_column_counts)
     bool colcnt_staged = false;
-    bool byteset_ready = false;    // a pass over the bytes that collects their values is in the context's stream (gap counts or row totals)
     PinBuf<int32_t> h_rowtot;      // residues (non-gap symbols) per sequence over all columns, fetched asynchronously
     int rowtot_staged = 0;         // 0 none, 1 copy enqueued, 2 copy complete, 3 enqueued on the side stream (not joined yet)
     bool pipe_active = false, pipe_gated = false;  // msa_trim's similarity pipeline is in flight (see sim_pipeline_begin)
@@ -210,10 +205,8 @@ int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
 // flag words of the state block
 enum {
     ST_ERRFLAG = 0, ST_PAIRFLAG = 1, ST_ERRKEY = 2 /* 2 words */, ST_STATS = 4 /* 2 floats */, ST_GATE = 6,
-    ST_USED = 8 /* 4 words: the byte values that occur in the alignment, for the pair pass's dense codes (prep_planes) */,
     ST_FLAGS = 16 /* the words fetched with every wait */,
-    ST_USED_SLOTS = 16 /* 128 words: the copies of that set that gap_counts fills */,
-    ST_WORDS = 160
+    ST_WORDS = 32
 };
 
 // Every wait on the context's stream goes through here: it fetches the flag words when a kernel that may have raised
@@ -306,7 +299,6 @@ void invalidate(msa_ctx *c) {
     c->state_zeroed = false;
     c->flags_dirty = false;
     c->colcnt_staged = false;
-    c->byteset_ready = false;
 }
 
 // the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)
@@ -333,8 +325,7 @@ int set_shape(msa_ctx *c, int m, int n, uint8_t indet) {
     c->n = n;
     c->indet = indet;
     c->nchunk = (n + 31) / 32;
-    // + 20: the denominator kernel reads the validity plane one 20-row group past the last row (zeros)
-    c->m_pad = round_up(std::max(m, 1) + 20, 128);
+    c->m_pad = round_up(std::max(m, 1), 128);
     c->ldw = round_up(std::max(m, 1), 64);
     invalidate(c);
     return MSA_OK;
@@ -345,16 +336,11 @@ int ensure_gaps(msa_ctx *c, bool to_host);
 int ensure_planes(msa_ctx *c) {
     if (c->have_planes) return MSA_OK;
     HIPCHK(c, c->planes.reserve((size_t)msak::planes_total() * c->nchunk * c->m_pad + 64));
-    // (the dense codes of the planes are ranks in the set of byte values that gap_counts collects: that pass first)
-    // ... or the row totals, when they ran on this stream and the gap counts have not run (RepresentativeTrimmer)
-    const bool dense = msak::pair_dense(c->m);
-    int rc = dense && !c->byteset_ready ? ensure_gaps(c, false) : ensure_state(c);
+    int rc = ensure_state(c);
     if (rc) return rc;
     {
         ProfScope ps(c, "prep");
-        msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad, c->errflag.p,
-                                 dense ? reinterpret_cast<const uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr,
-                                 reinterpret_cast<uint32_t *>(c->state.p + ST_USED));
+        msak::launch_prep_planes(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->planes.p, c->nchunk, c->m_pad, c->errflag.p);
     }
     HIPCHK(c, hipGetLastError());
     // the non-ASCII verdict comes back with the next synchronisation of the stream (sync_stream): every caller
@@ -379,10 +365,7 @@ int ensure_gaps(msa_ctx *c, bool to_host) {
         if (rc) return rc;
         {
             ProfScope ps(c, "gaps");
-            const bool collect = msak::pair_dense(c->m) && !c->byteset_ready;
-            msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p,
-                                    collect ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
-            c->byteset_ready |= collect;
+            msak::launch_gap_counts(c->stream, c->raw, c->m, c->n, c->ld, c->indet, c->gaps.p, c->indets.p);
         }
         HIPCHK(c, hipGetLastError());
         c->have_gaps = true;
@@ -455,8 +438,11 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
         msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, c->m, c->ldw,
                                  want_counts ? c->hit.p : nullptr, want_counts ? c->dst.p : nullptr,
                                  need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr,
-                                 c->pairflag.p,
-                                 msak::pair_dense(c->m) ? reinterpret_cast<const uint32_t *>(c->state.p + ST_USED) : nullptr);
+                                 c->pairflag.p);
+    }
+    if (need_w) {
+        HIPCHK(c, c->wbar.reserve((size_t)c->m + 128));
+        msak::launch_w_row_means(c->stream, c->wmat.p, c->m, c->ldw, c->wbar.p);
     }
     HIPCHK(c, hipGetLastError());
     c->flags_dirty = true;
@@ -583,19 +569,14 @@ int fetch_similarity(msa_ctx *c, int n, float *mdk_out, float *q_out, msa_err_de
 // The columns the binade-exact kernels evaluate (not zeroed by the ">= 80 % gaps" rule), the ones with the most valid
 // rows first (their waves run longest), into the pinned staging list.  Host work only: msa_trim calls it while the pair
 // pass runs, similarity() otherwise.
-int build_sim_order(msa_ctx *c, const int32_t *gaps_windowed, bool pairs2, SimOrder *out) {
+int build_sim_order(msa_ctx *c, const int32_t *gaps_windowed, SimOrder *out) {
     const int m = c->m, n = c->n;
-    // the columns to evaluate: not zeroed by the ">= 80 % gaps" rule; the ones with the most valid rows first (their
-    // waves run longest).  With q = bx_cols_per_wave() > 1 consecutive entries share a wave: the heaviest column
-    // goes with the lightest, the second with the second to last, ...
     const int32_t *gw_host = gaps_windowed ? gaps_windowed : c->h_gaps.data();
-    const int q = c->tuning.sim_kernel == 3 ? msak::bx_cols_per_wave() : 1;
-    HIPCHK(c, c->h_simcols.reserve((size_t)2 * n + 64 * (size_t)std::max(1, c->cus) + 64));
+    HIPCHK(c, c->h_simcols.reserve((size_t)n + 128));
     // (counting sort by the number of rows that take no part, stable, in ordinary memory: the pinned staging
     // buffer is only written once, front to back)
     int32_t *list = c->h_simcols.p;
-    std::vector<int32_t> &order = c->sort_order, &bins = c->sort_bins;
-    order.resize((size_t)n + 1);
+    std::vector<int32_t> &bins = c->sort_bins;
     bins.assign((size_t)m + 2, 0);
     int nact = 0;
     for (int j = 0; j < n; ++j)
@@ -603,42 +584,10 @@ int build_sim_order(msa_ctx *c, const int32_t *gaps_windowed, bool pairs2, SimOr
     for (int g = 0; g <= m; ++g) bins[g + 1] += bins[g];
     for (int j = 0; j < n; ++j)
         if (!(((float)gw_host[j] / (float)m) >= 0.8f)) {
-            order[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
+            list[bins[std::min(c->h_gaps[j] + c->h_indets[j], m)]++] = j;
             ++nact;
         }
-    int npad = 0;
-    if (q == 2) {
-        for (int i = 0, k = nact - 1; i <= k; ++i, --k) {
-            list[npad++] = order[i];
-            list[npad++] = i < k ? order[k] : n;  // (an odd count leaves the middle column alone: column n is all skipped)
-        }
-    } else {
-        for (int i = 0; i < nact; ++i) list[npad++] = order[i];
-        while (npad % (pairs2 ? 2 : q)) list[npad++] = n;  // (column n: all skipped)
-    }
-    int pair_waves = 0;
-    if (pairs2 && npad) {
-        // Two columns per wave, neighbours in the order above.  Every pair is resident from the start (no wave slot
-        // is ever refilled), so the time is set by the CU with the most work: two workgroups per CU, and the pairs
-        // dealt to the workgroups in serpentine order (heaviest with lightest) so that all carry the same load.
-        const int np = npad / 2;
-        int nwg = std::max(1, 2 * c->cus);
-        pair_waves = (np + nwg - 1) / nwg;
-        if (pair_waves > msak::lg2_max_waves()) {
-            pair_waves = msak::lg2_max_waves();
-            nwg = (np + pair_waves - 1) / pair_waves;
-        }
-        order.assign(list, list + npad);
-        npad = 0;
-        for (int g = 0; g < nwg; ++g)
-            for (int w = 0; w < pair_waves; ++w) {
-                const int pi = w * nwg + ((w & 1) ? nwg - 1 - g : g);
-                list[npad++] = pi < np ? order[2 * pi] : n;
-                list[npad++] = pi < np ? order[2 * pi + 1] : n;
-            }
-    }
-    out->npad = npad;
-    out->pair_waves = pair_waves;
+    out->npad = nact;
     return MSA_OK;
 }
 
@@ -670,35 +619,21 @@ int sim_order_enqueue(msa_ctx *c, const SimOrder &ord, hipStream_t st) {
 }
 // 3. the kernel and the MDK values (context's stream).  gate: device word that, when non-zero, turns the kernel into
 //    a no-op (automated1: raised by the identity statistics when they select gappyout); one-column kernel only.
-int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, bool pairs2, const int32_t *gw_dev, const int *gate) {
+int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t *gw_dev, const int *gate) {
     const int m = c->m, n = c->n;
-    const int npad = ord.npad, pair_waves = ord.pair_waves;
     HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
     HIPCHK(c, c->simnum.reserve((size_t)n + 64));
     HIPCHK(c, c->simden.reserve((size_t)n + 64));
     // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
     {
         ProfScope ps(c, "sim");
-        int e;
-        if (pairs2) {
-            // neighbours in the order by valid rows share a wave and the W rows of the union of their valid rows
-            const size_t usz = (size_t)(npad / 2 + 1) * msak::bx_ldk(m) + 64;
-            HIPCHK(c, c->u_off.reserve(usz));
-            HIPCHK(c, c->u_tt.reserve(usz));
-            HIPCHK(c, c->u_ee.reserve(2 * usz));
-            HIPCHK(c, c->u_n.reserve((size_t)npad / 2 + 64));
-            e = msak::launch_similarity_lg2(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, npos, c->bx_nvalid.p, c->codeT.p, m, n,
-                                            c->simcols.p, npad, pair_waves, c->u_off.p, c->u_tt.p, c->u_ee.p, c->u_n.p, c->wlow.p,
-                                            c->wmat.p, c->ldw, c->tab.p, c->simnum.p, c->simden.p);
-        } else
-            e = c->tuning.sim_kernel == 3
-                          ? msak::launch_similarity_bx(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_nvalid.p, c->codeT.p,
-                                                       m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p, c->ldw, c->tab.p,
-                                                       c->simnum.p, c->simden.p)
+        const int e = c->tuning.sim_kernel == 1
+                          ? msak::launch_similarity_seq(c->stream, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wmat.p, c->ldw, c->tab.p,
+                                                        c->simnum.p, c->simden.p)
                           : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, npos,
-                                                       c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, npad, c->wlow.p, c->wmat.p,
-                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate);
-        if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_bx");
+                                                       c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wlow.p, c->wmat.p,
+                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate, c->wbar.p);
+        if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
     HIPCHK(c, hipGetLastError());
@@ -716,8 +651,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     };
     int rc = run_pairs(c, false, true, false);
     if (rc) return rc;
-    const bool bx_family = c->tuning.sim_kernel == 0 || c->tuning.sim_kernel >= 3;
-    rc = ensure_gaps(c, bx_family);  // (the binade-exact kernel's column list is built on the host)
+    rc = ensure_gaps(c, true);  // (the kernel's column list is built on the host)
     if (rc) return rc;
     const int m = c->m, n = c->n;
     rc = ensure_tables(c, vhash, dist, npos);
@@ -735,93 +669,26 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
         HIPCHK(c, hipMemcpyAsync(c->gaps_w.p, c->h_i32.p, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
         gw_dev = c->gaps_w.p;
     }
-    const int G8 = (m + 7) / 8;
-    // Kernel choice (MSA_SIM_KERNEL, read when the context was created): the binade-exact kernel by default;
-    // "chain" = the numerator + denominator chain kernels of round 1, "pc" = the single-chain producer/consumer
-    // kernel.  All three are bit-exact and parity-tested against each other and the oracle.
-    // (its compacted lists hold 16-bit row indices and 32-bit W offsets: larger alignments take the chain kernels)
-    const bool bx_fits = m < 32000;
-    if (bx_family && bx_fits) {
-        // 0 / 4 "lg": one column per wave (measured at least as fast as two columns per wave at every shape tried:
-        // tools/lg_sweep.py); 5 "q2": two columns per wave sharing the W loads (alphabets up to 22 letters);
-        // 3 "bx": the one-grid-per-round predecessor
-        const bool pairs2 = c->tuning.sim_kernel == 5 && msak::lg2_fits(npos);
-        rc = sim_lists_enqueue(c, npos, gw_dev, c->stream);
-        if (rc) return rc;
-        mark("lists enqueued");
-        SimOrder ord;
-        if (c->order_ready && c->order_pairs2 == pairs2) {
-            ord = c->order;  // built by msa_trim while the pair pass ran
-        } else {
-            rc = build_sim_order(c, gaps_windowed, pairs2, &ord);
-            if (rc) return rc;
-        }
-        c->order_ready = false;
-        mark("columns sorted");
-        rc = sim_order_enqueue(c, ord, c->stream);
-        if (rc) return rc;
-        rc = sim_kernel_enqueue(c, npos, ord, pairs2, gw_dev, nullptr);
-        if (rc) return rc;
-        mark("kernel enqueued");
-        rc = fetch_similarity(c, n, mdk_out, q_out, detail);
-        mark("results fetched");
-        return rc;
-    }
-    const bool split = c->tuning.sim_kernel != 2;
-    const int cus_num = split ? std::max(c->cus - msak::sim_den_workgroups((n + 31) / 32, m), c->cus / 2) : c->cus;
-    const int tcols = msak::sim_tile_cols(n, cus_num, split ? msak::sim_num_min_cols() : 16);
-    HIPCHK(c, c->simcodes.reserve((size_t)8 * (G8 + 2) * (c->ld + 64) + 64));  // sized for the larger format (codes32)
-    HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
-    if (split) {
-        // numerators and denominators are independent sequential sums: two kernels, two streams
-        rc = ensure_planes(c);
-        if (rc) return rc;
-        HIPCHK(c, c->simnum.reserve((size_t)n + 64));
-        HIPCHK(c, c->simden.reserve((size_t)c->nchunk * 32 + 64));
-        HIPCHK(c, c->pairmasks.reserve((size_t)c->nchunk * msak::den2_pm_ld(m) + 64));
-        if (!c->stream2) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        ProfScope ps(c, "sim");
-        const bool serial = c->tuning.sim_serial != 0;  // diagnostics: both kernels on one stream
-        hipStream_t sden = serial ? c->stream : c->stream2;
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(sden, c->ev_fork, 0));
-        {
-            ProfScope pd(c, "simden", sden);
-            const int e = msak::launch_sim_den(sden, c->planes.p, c->nchunk, c->m_pad, m, n, c->wmat.p, c->ldw,
-                                               c->simden.p, c->pairmasks.p);
-            if (e) return fail_hip(c, (hipError_t)e, "launch_sim_den");
-        }
-        HIPCHK(c, hipEventRecord(c->ev_join, sden));
-        {
-            ProfScope pe(c, "encode");
-            msak::launch_sim_encode8(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p, tcols);
-        }
-        {
-            ProfScope pn(c, "simnum");
-            const int e = msak::launch_similarity_num(c->stream, c->simcodes.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p,
-                                                      npos, c->simnum.p, tcols);
-            if (e) return fail_hip(c, (hipError_t)e, "launch_similarity_num");
-        }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
+    rc = sim_lists_enqueue(c, npos, gw_dev, c->stream);
+    if (rc) return rc;
+    mark("lists enqueued");
+    SimOrder ord;
+    if (c->order_ready) {
+        ord = c->order;  // built by msa_trim while the pair pass ran
     } else {
-        {
-            ProfScope ps(c, "encode");
-            msak::launch_sim_encode32(c->stream, c->raw, m, n, c->ld, c->lut.p, npos, gw_dev, c->simcodes.p, c->errkey.p,
-                                      tcols);
-        }
-        HIPCHK(c, hipGetLastError());
-        ProfScope ps(c, "sim");
-        const int e = msak::launch_similarity_pc(c->stream, c->simcodes.p, m, n, c->ld, c->wmat.p, c->ldw, c->tab.p, npos,
-                                                 gw_dev, c->mdk.p + n, c->mdk.p, tcols);
-        if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
+        rc = build_sim_order(c, gaps_windowed, &ord);
+        if (rc) return rc;
     }
-    HIPCHK(c, hipGetLastError());
-    return fetch_similarity(c, n, mdk_out, q_out, detail);
+    c->order_ready = false;
+    mark("columns sorted");
+    rc = sim_order_enqueue(c, ord, c->stream);
+    if (rc) return rc;
+    rc = sim_kernel_enqueue(c, npos, ord, gw_dev, nullptr);
+    if (rc) return rc;
+    mark("kernel enqueued");
+    rc = fetch_similarity(c, n, mdk_out, q_out, detail);
+    mark("results fetched");
+    return rc;
 }
 
 int overlap(msa_ctx *c, float residue_overlap, float *out) {
@@ -856,17 +723,8 @@ int stage_row_totals(msa_ctx *c, hipStream_t st = nullptr) {
     const int m = c->m, n = c->n;
     HIPCHK(c, c->row_cnt.reserve((size_t)m + 64));
     HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
-    // (no mask: every column counts.  On the context's stream this pass also collects the byte values for the pair
-    // pass's dense codes if nothing has yet: a trim that needs no gap counts then runs no gap_counts for them)
-    bool collect = false;
-    if (!side && msak::pair_dense(m) && !c->byteset_ready) {
-        int rc = ensure_state(c);
-        if (rc) return rc;
-        collect = true;
-    }
-    msak::launch_row_nongap(st, c->raw, m, n, c->ld, nullptr, c->row_cnt.p,
-                            collect ? reinterpret_cast<uint32_t *>(c->state.p + ST_USED_SLOTS) : nullptr);
-    c->byteset_ready |= collect;
+    // (no mask: every column counts)
+    msak::launch_row_nongap(st, c->raw, m, n, c->ld, nullptr, c->row_cnt.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_rowtot.p, c->row_cnt.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
     if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));
@@ -1190,8 +1048,7 @@ int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of th
 // the device (identity_final_kernel), so that the similarity kernel can sit in the queue behind the statistics
 // without a round trip to the host; the host takes the same decision from the same two floats after the wait.
 bool sim_pipeline_applies(const msa_ctx *c, const msa_trim_params *p, int sim_hw) {
-    return p->vhash && p->dist && p->npos >= 1 && p->npos <= 28 && (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel == 4) &&
-           c->tuning.lg_regs == 0 && c->m < 32000 && c->m >= 2 && sim_hw <= c->n / 4 && c->tuning.pipeline != 0;
+    return p->vhash && p->dist && p->npos >= 1 && p->npos <= 28 && c->m >= 2 && sim_hw <= c->n / 4 && c->tuning.pipeline != 0;
 }
 
 int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool gated, std::vector<int32_t> &gaps_w) {
@@ -1234,7 +1091,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
         if ((rc = sim_lists_enqueue(c, p->npos, gw_dev, side))) return rc;
     }
     SimOrder ord;
-    if ((rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, false, &ord))) return rc;
+    if ((rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, &ord))) return rc;
     if ((rc = sim_order_enqueue(c, ord, side))) return rc;
     if (forked) HIPCHK(c, hipEventRecord(c->ev_join, side));
     int *gate = nullptr;
@@ -1248,7 +1105,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
     HIPCHK(c, hipGetLastError());
     if (forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (c->rowtot_staged == 3) c->rowtot_staged = 1;  // (joined: a wait on the context's stream now covers the copy)
-    if ((rc = sim_kernel_enqueue(c, p->npos, ord, false, gw_dev, gate))) return rc;
+    if ((rc = sim_kernel_enqueue(c, p->npos, ord, gw_dev, gate))) return rc;
     if ((rc = fetch_similarity_enqueue(c, n))) return rc;
     c->pipe_active = true;
     c->pipe_gated = gated;
@@ -1314,8 +1171,8 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->u_off.release(); c->u_tt.release(); c->u_ee.release(); c->u_n.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
-    c->simcodes.release(); c->pairmasks.release(); c->gaps_w.release();
+    c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->gaps_w.release();
     c->mdk.release(); c->simnum.release(); c->simden.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
@@ -1469,6 +1326,23 @@ int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
 
 extern "C" {
 
+// Host rows -> the device's pitched layout, by where the rows live (measured on an MI355X, 2000 x 10000:
+// tools/ubench_register.hip, tools/upload_sweep.sh -> profiles/r03_upload.txt):
+//   * page-locked memory (hipHostMalloc, or registered by the caller: msa_host_register): ONE pitched copy straight from the
+//     caller's rows, no staging, no packing -- 0.37 ms, 54 GB/s, the link's rate;
+//   * pageable rows of a multiple of 16 bytes at a 16-byte aligned address: the runtime's own pitched copy (it stages
+//     internally): 0.52 ms;
+//   * anything else: packed into pinned staging piece by piece by the calling thread and PackPool's helpers, each piece
+//     sent as soon as it is packed: 0.61 - 0.69 ms (a pitched copy of odd-sized pageable rows degenerates into one
+//     transfer per row: 1.5 ms for 209 x 1227).
+static int zero_padding_for_shape(msa_ctx *c, int m, int n) {
+    const uint64_t pad_tag = ((uint64_t)(uint32_t)m << 32) | (uint32_t)n | (1ull << 63);
+    if (c->raw_own.tag != pad_tag) {
+        HIPCHK(c, hipMemsetAsync(c->raw_own.p, 0, (size_t)m * c->ld, c->stream));
+        c->raw_own.tag = pad_tag;
+    }
+    return MSA_OK;
+}
 static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet, bool wait) {
     if (!c || (!rowmajor && m > 0 && n > 0) || ld < n) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1478,15 +1352,42 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {
+        bool locked = false;
+        if (c->tuning.upload_direct) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, rowmajor) == hipSuccess) locked = at.type == hipMemoryTypeHost;
+            else (void)hipGetLastError();  // (ordinary memory: "invalid value", not an error of ours)
+        }
+        const bool aligned16 = ld % 16 == 0 && reinterpret_cast<uintptr_t>(rowmajor) % 16 == 0;
         if (ld == c->ld) {  // already pitched: one linear copy
+            c->raw_own.tag = 0;
             HIPCHK(c, hipMemcpyAsync(c->raw_own.p, rowmajor, (size_t)m * c->ld, hipMemcpyHostToDevice, c->stream));
+        } else if ((locked && ld % 8 == 0) || (aligned16 && c->tuning.upload_direct)) {
+            // (page-locked rows of an odd size degenerate as well: 209 x 1227 took 1.5 ms; 5000-byte rows are fine)
+            // The copy writes n bytes per row; the padding columns n .. ld must read as zero (what the staged path
+            // writes).  They are zeroed when the buffer is new or was last used for another shape, and stay zero under
+            // pitched copies of the same shape.
+            if ((rc = zero_padding_for_shape(c, m, n))) return rc;
+            HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor, (size_t)ld, (size_t)n, (size_t)m, hipMemcpyHostToDevice,
+                                       c->stream));
         } else {
+            c->raw_own.tag = 0;
             rc = upload_rows_pitched(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
             if (rc) return rc;
         }
     }
     if (wait) SYNC(c);  // the caller may free `rowmajor` on return
     return MSA_OK;
+}
+
+int msa_host_register(const void *rows, size_t bytes) {
+    if (!rows || bytes == 0) return MSA_E_INVALID;
+    return hipHostRegister(const_cast<void *>(rows), bytes, hipHostRegisterDefault) == hipSuccess ? MSA_OK : MSA_E_HIP;
+}
+
+int msa_host_unregister(const void *rows) {
+    if (!rows) return MSA_E_INVALID;
+    return hipHostUnregister(const_cast<void *>(rows)) == hipSuccess ? MSA_OK : MSA_E_HIP;
 }
 
 int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
@@ -1502,6 +1403,7 @@ int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {  // (straight from the row pointers into the pinned pieces: no packed copy in between)
+        c->raw_own.tag = 0;
         rc = upload_rows_pitched(c, m, n, [&](int i) { return rows[i]; });
         if (rc) return rc;
     }
@@ -1522,6 +1424,7 @@ int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n
     } else {  // re-pitch into an owned buffer (device-to-device)
         c->ld = round_up(std::max(n, 1), 64);
         HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
+        if ((rc = zero_padding_for_shape(c, m, n))) return rc;
         HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor_dev, (size_t)ld, (size_t)n, (size_t)m,
                                    hipMemcpyDeviceToDevice, c->stream));
         c->raw = c->raw_own.p;
@@ -1770,12 +1673,10 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
             if ((rc = need_gaps())) return rc;  // (waits for the staged copy only)
             info->gap_cut = msah::GapHistogram(c->h_gaps.data(), m, n).cut_point_2nd_slope();
             have_gap_cut = true;
-            if (p->vhash && p->dist && (c->tuning.sim_kernel == 0 || c->tuning.sim_kernel >= 3) && m < 32000) {
-                const bool pairs2 = c->tuning.sim_kernel == 5 && msak::lg2_fits(p->npos);
-                rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, pairs2, &c->order);
+            if (p->vhash && p->dist) {
+                rc = build_sim_order(c, gap_hw > 0 ? gaps_w.data() : nullptr, &c->order);
                 if (rc) return rc;
                 c->order_ready = true;
-                c->order_pairs2 = pairs2;
             }
             trace.mark("gap cut + column order");
             rc = identity_stats(c, &info->avg_seq, &info->max_seq);
@@ -1851,7 +1752,7 @@ int msa_trim_only_gaps_rows(msa_ctx *c, int32_t *rows, int32_t cap) {
 
 int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
     if (!c || !kernel) return MSA_E_INVALID;
-    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "simnum", "simden", "overlap", "cluster"};
+    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster"};
     bool known = false;
     for (const char *nm : names) known |= (std::strcmp(nm, kernel) == 0);
     if (!known) return MSA_E_INVALID;

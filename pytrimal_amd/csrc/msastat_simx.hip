@@ -17,19 +17,21 @@
 //   (sum < 2B, grids as assumed), so speculation can only cost time, never exactness.
 //
 // What is in this file, in order:
-//   * helpers (scans, exact_row: one row in the reference's order) and `similarity_bx`, the first kernel of the
-//     family: ONE grid per chain and round, a second pair of accumulators for predicted crossings, rounds cut short
-//     for the others, the lane's table column in 32 VGPRs (MSA_SIM_KERNEL=bx; section 5.7 of DESIGN.md);
-//   * `similarity_lg` (the default): every lane on the grid of its own predicted sum, one loop version, the table
-//     column in a per-wave LDS table read by ds_read_addtid_b32, W rows by hand-issued global loads.  Work mapping:
-//     one wave = one column (the columns the ">= 80 % gaps" rule zeroes never get a wave), lane = one of 64
+//   * helpers (scans, exact_row: one row in the reference's order);
+//   * `similarity_lg`, THE similarity kernel: every lane on the grid of its own predicted sum, one loop version, the
+//     lane's table column in a per-wave LDS table read by ds_read_addtid_b32, W rows by hand-issued global loads.  Work
+//     mapping: one wave = one column (the columns the ">= 80 % gaps" rule zeroes never get a wave), lane = one of 64
 //     consecutive rows j of the round, one step per VALID partner row k behind the round's first row (compacted
 //     list): 3 VALU + 1 LDS + 1 VMEM instruction per 64 terms.  Bound by the vector L1's bandwidth (the W stream:
-//     texture addresser 92 % busy), not by VALU issue or add latency;
-//   * `similarity_lg2` (MSA_SIM_KERNEL=q2): two columns per wave sharing the W loads -- measured, not faster;
+//     texture addresser 92 % busy), not by VALU issue or add latency.  Two instantiations: 32-bit byte offsets of the
+//     W rows in the lists (m <= 32768), or row indices multiplied out on the scalar unit (any m);
+//   * `similarity_seq` (MSA_SIM_KERNEL=seq): the statistic as the reference writes it -- one lane per column, two
+//     nested loops, one add after the other.  Slow by construction; the cross-check of the kernel above at sizes the
+//     CPU oracle cannot reach;
 //   * the identity row statistics (sequential float32 sums through the same chunk test);
-//   * the layout kernels (column-major codes, compacted lists, union lists) and the launchers.
-// Limits: m < 32000 (16-bit row indices, 32-bit W offsets); above that the chain kernels of msastat_kernels.hip run.
+//   * the layout kernels (column-major codes, compacted lists) and the launchers.
+// History: the round-1 chain kernels, the one-grid-per-round `bx` kernel, the table-in-registers
+// and two-columns-per-wave (`q2`) variants were measured against this kernel in round 2 and removed in round 3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -43,10 +45,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) uint32_t *cu32p;  // constant address space: wave-uniform loads go through the scalar cache
 
 constexpr uint32_t BX_SKIP = 224;  // code (8 x table row) of a residue that takes no part: row / column 28 of the table is zero
-constexpr int BX_R0 = 8;           // rows evaluated in the reference's order before the first round
-constexpr int BX_WAVES = 4;        // waves per workgroup (they only share the table in LDS)
-constexpr int BX_Q = 1;            // columns per wave, advanced in turn.  2 (the host then pairs a heavy column with a
-                                   // light one, all waves resident from the start) measured 6.2 instead of 5.1 ms at C3
 
 // explicit address spaces: global loads (not flat) everywhere, scalar loads for wave-uniform addresses
 typedef const __attribute__((address_space(1))) float *gf32p;
@@ -124,9 +122,8 @@ struct ColView {
     int nvalid;
     gu8p colcode;                                            // the column's codes by row (codeT), BX_SKIP for a row that takes no part
     int ldw;
-    int compact;  // lanes of a round are consecutive entries of the compacted list (else consecutive rows)
     int lastpad;  // the last entry of the lists (padding)
-    int nr;       // 0: `tab` is the {distance, valid} table [32][32]; > 0: the replicated float table [nr][nr][32 copies]
+    int big;      // `off` holds row INDICES (any m) instead of byte offsets, and `row` (16 bits) is not used
 };
 
 // Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
@@ -159,7 +156,6 @@ __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
 
 __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int tfirst, int which, f2 s) {
     const int lane = threadIdx.x & 63;
-    if (cv.compact) j = uni((int)cv.row[j]);  // (a round's rows are list entries there)
     const uint32_t cj = cv.colcode[j];
     if (uni((int)cj) == (int)BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
@@ -169,24 +165,15 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = min(t + 64 * i + lane, cv.lastpad);
-            k[i] = cv.row[e];
+            k[i] = cv.big ? cv.off[e] : (uint32_t)cv.row[e];
             c[i] = cv.code[e];
         }
     };
-    // (replicated table: entry (a, b) has 32 copies, lane l reads copy l % 32 -- no bank conflict whatever the codes)
-    const uint32_t rrow = cv.nr ? (((cj == BX_SKIP ? (uint32_t)cv.nr - 1u : cj >> 3) * (uint32_t)cv.nr) << 7) + ((uint32_t)(lane & 31) << 2) : 0u;
     auto values = [&](const uint32_t(&k)[4], const uint32_t(&c)[4], float(&w)[4], f2(&de)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             w[i] = wr[k[i]];  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
-            if (cv.nr) {
-                const bool skip = c[i] == BX_SKIP;
-                const uint32_t b = skip ? (uint32_t)cv.nr - 1u : c[i] >> 3;
-                de[i].x = *reinterpret_cast<const __attribute__((address_space(3))) float *>(tab + (rrow + (b << 7)));
-                de[i].y = skip ? 0.0f : 1.0f;
-            } else {
-                de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
-            }
+            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
         }
     };
     // (list entries a chunk ahead; the W gather and the table gather of a chunk are issued together.  A deeper
@@ -212,476 +199,24 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
     return f2{s0, s1};
 }
 
-// Stitch the rows [lo, hi) of a round: s before row lo, per-lane increments for an even / odd sum on the grid
-// whose binade ends at `top`.  Returns the sum after each row (valid for the lanes before `cross`) and the
-// first row whose sum would reach `top` (hi if none).
-__device__ __forceinline__ float scan_rows(float s, float top, float ie, float io, int lo, int hi, int lane, int &cross) {
-    const bool in = lane >= lo && lane < hi;
-    const float a = in ? ie : 0.0f;
-    const float P = wave_prefix(a);
-    unsigned long long ties = __ballot(in && ie != io);
-    float corr = 0.0f;
-    while (ties) {
-        const int t = __builtin_ctzll(ties);
-        ties &= ties - 1;
-        const float at = rl(a, t);
-        const float st = s + ((rl(P, t) - at) + rl(corr, t));
-        if (!(st < top)) break;
-        const float chosen = (__float_as_uint(st) & 1u) ? rl(io, t) : at;
-        const float delta = chosen - at;
-        if (lane >= t) corr += delta;
-    }
-    const float sp = s + (P + corr);
-    const unsigned long long x = __ballot(in && !(sp < top));
-    cross = x ? __builtin_ctzll(x) : hi;
-    return sp;
-}
-
-// One chain (numerator or denominator of the column) at the end of a round of `limit` rows starting at row j0
-// (tbase valid rows lie before j0; vmask: the valid rows of the round).  Returns {the sum after every row (per lane), the new limit}: the limit shrinks when the rows behind
-// some point cannot be committed.
-struct Resolved {
-    float sp;
-    int limit;
-};
-__device__ __noinline__ Resolved resolve_chain(ColView cv, gf32p wup, ldsp tab, int j0, int tbase, unsigned long long vmask,
-                                               int kind, float s, float ie, float io, float ie2, float io2, int limit,
-                                               bool dual) {
-    // (row j0 + x of the round; its partners start at entry tbase + (valid rows of the round up to and including x))
-    auto tfirst = [&](int x) { return tbase + __builtin_popcountll(vmask & ((2ull << x) - 1ull)); };
-    const int lane = threadIdx.x & 63;
-    float B, u;
-    if (!grid_of(s, B, u)) {
-        // no binade yet (sum still zero): the accumulators are plain sums; the first row that contributes is
-        // evaluated in order and ends the round
-        const unsigned long long nz = __ballot(lane < limit && ie != 0.0f);
-        if (!nz) return Resolved{s, limit};
-        const int x = __builtin_ctzll(nz);
-        const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{s, s});
-        const float sx = kind ? r.y : r.x;
-        return Resolved{lane < x ? s : sx, x + 1};
-    }
-    int x;
-    const float sp = scan_rows(s, 2.0f * B, ie, io, 0, limit, lane, x);
-    if (x >= limit) return Resolved{sp, limit};
-    // row x would leave the binade: evaluate it in order
-    const float before = x > 0 ? rl(sp, x - 1) : s;
-    const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{before, before});
-    const float sx = kind ? r.y : r.x;
-    const float B2 = 2.0f * B;
-    // without the second grid (the round did not expect this chain to cross), or after a row that spans two
-    // binades, the round ends behind row x
-    if (!dual || !(sx >= B2 && sx < 2.0f * B2)) return Resolved{lane < x ? sp : sx, x + 1};
-    // the rows behind it were also accumulated on the next grid
-    int y;
-    const float sp2 = scan_rows(sx, 2.0f * B2, ie2, io2, x + 1, limit, lane, y);
-    // (y < limit: a second crossing in the same round; the next round starts at that row)
-    return Resolved{lane < x ? sp : (lane == x ? sx : sp2), y};
-}
-
 // cycle stamps of MSA_SIM_MODE=64 (diagnostics): [0] prologue, [1] round loops, [2] stitching, [3] waves, [4] rounds,
-// [5] rounds x chains that carried the second grid, [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles),
-// [8] most rounds of a wave, [9] shortened rounds
+// [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles), [8] most rounds of a wave, [10] ordered rows,
+// [11] their cycles
 __device__ unsigned long long g_bx_stamps[16];
 __device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): column, cycles / 64 of the three phases, rounds, shortened rounds
 
-// The partner loop of one round: entries tstart .. tend-1 of the compacted list (valid rows only), one step per
-// partner row k:
-//   W[k][j(lane)]  one coalesced buffer load (SGPR row offset straight from the list + per-lane column offset);
-//   D[a_k][a_j]    from the lane's own copy of its table column, T[a] = D[a][a_j(lane)], held in 32 VGPRs and
-//                  indexed by the wave-uniform a_k (relative VGPR addressing: no LDS access in the loop, so the
-//                  scalar prefetch of the list is the only thing on the LGKM counter);
-//   one packed multiply {W, W} x {D, e} (e = 1 for a lane whose row takes part) and two packed adds per grid.
-// DN / DD: the numerator / denominator chain also accumulates on the next grid.
-typedef float v32f __attribute__((ext_vector_type(32)));
-
-template <bool DN, bool DD>
-__device__ __forceinline__ void round_loop(__amdgpu_buffer_rsrc_t wrsrc, ColView cv, int tstart, int tend, uint32_t joff,
-                                           const v32f &T, float e, f2 &an, f2 &an2, f2 &ad, f2 &ad2) {
-    typedef const __attribute__((address_space(4))) uint32_t *c32;
-    // the list entries of the group after next arrive by scalar loads while two groups of W rows are in flight
-    struct Entries {
-        uint32_t o[8];  // row offsets in W
-        uint2 codes;    // 8 codes
-    };
-    auto sload = [&](Entries &en, int t) {  // 8 entries = 32 + 8 bytes (t % 8 == 0)
-        c32 po = (c32)(uint64_t)(cv.off + t);
-        c32 pc = (c32)(uint64_t)(cv.code + t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) en.o[i] = po[i];
-        en.codes = make_uint2(pc[0], pc[1]);
-    };
-    auto bload = [&](float(&w)[8], const Entries &en) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
-    };
-    // consume the 8 rows of a group and, row by row, put the group after next into the registers just freed:
-    // every W row is requested 16 steps before its use with 16 registers in all
-    auto consume_reload = [&](float(&w)[8], const uint2 &codes, const Entries &next) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t word = i < 4 ? codes.x : codes.y;
-            const uint32_t ak = (word >> (8 * (i & 3) + 3)) & 0x1Fu;  // code = 8 x table row
-            const f2 x = f2{T[ak], e} * w[i];
-            w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[i], 0));
-            const f2 xn = {x.x, x.x}, xd = {x.y, x.y};
-            an += xn;
-            ad += xd;
-            if (DN) an2 += xn;
-            if (DD) ad2 += xd;
-        }
-    };
-    float wA[8], wB[8];
-    Entries eA, eB;
-    uint2 cA, cB;
-    sload(eA, tstart);
-    sload(eB, tstart + 8);
-    bload(wA, eA);
-    cA = eA.codes;
-    bload(wB, eB);
-    cB = eB.codes;
-    sload(eA, tstart + 16);
-    sload(eB, tstart + 24);
-#pragma unroll 1
-    for (int t = tstart; t < tend; t += 16) {  // (the lists are padded: zero row, skipped codes)
-        consume_reload(wA, cA, eA);
-        cA = eA.codes;
-        sload(eA, t + 32);
-        consume_reload(wB, cB, eB);
-        cB = eB.codes;
-        sload(eB, t + 40);
-    }
-}
-
-// ---- the same loop with the table read folded into the multiply --------------------------------------------
-// The compiler turns T[a_k] into s_set_gpr_idx_on / v_mov_b32 (relative source) / s_set_gpr_idx_off in front of the
-// packed multiply: four VALU instructions per step.  Here the lane's table column is a 32-register value pinned to
-// v[64:95] (physical-register constraints on every asm statement that touches it, so the compiler itself keeps it
-// there and out of everybody's way), the multiply reads v[64 + a_k] through the relative-source mode, four steps
-// under one s_set_gpr_idx_on, and EXEC holds only the lanes whose row takes part, so that the denominator term is
-// W itself: v_mul_f32 + two packed adds = three VALU instructions per step.  EXPERIMENTAL (MSA_BX_ASM=1, parity-tested):
-// per wave it is 18 % faster, but the pinned table fragments the register file -- at the 96 registers that five
-// waves per SIMD allow the allocator spills inside one of the loop versions, at 117 registers the occupancy drops
-// to four waves; either way the kernel as a whole does not gain (4.98 vs 5.27 ms at best, 6.5 ms at worst).
-
-// the lane's table column D[0..28][a_j] (stride 256 B in the LDS table); entries 29..31 are zero
-__device__ __forceinline__ v32f fill_table_regs(uint32_t lds_addr) {
-    v32f T;
-    asm volatile(
-        "ds_read_b32 v64, %1 offset:0\n\tds_read_b32 v65, %1 offset:256\n\tds_read_b32 v66, %1 offset:512\n\t"
-        "ds_read_b32 v67, %1 offset:768\n\tds_read_b32 v68, %1 offset:1024\n\tds_read_b32 v69, %1 offset:1280\n\t"
-        "ds_read_b32 v70, %1 offset:1536\n\tds_read_b32 v71, %1 offset:1792\n\tds_read_b32 v72, %1 offset:2048\n\t"
-        "ds_read_b32 v73, %1 offset:2304\n\tds_read_b32 v74, %1 offset:2560\n\tds_read_b32 v75, %1 offset:2816\n\t"
-        "ds_read_b32 v76, %1 offset:3072\n\tds_read_b32 v77, %1 offset:3328\n\tds_read_b32 v78, %1 offset:3584\n\t"
-        "ds_read_b32 v79, %1 offset:3840\n\tds_read_b32 v80, %1 offset:4096\n\tds_read_b32 v81, %1 offset:4352\n\t"
-        "ds_read_b32 v82, %1 offset:4608\n\tds_read_b32 v83, %1 offset:4864\n\tds_read_b32 v84, %1 offset:5120\n\t"
-        "ds_read_b32 v85, %1 offset:5376\n\tds_read_b32 v86, %1 offset:5632\n\tds_read_b32 v87, %1 offset:5888\n\t"
-        "ds_read_b32 v88, %1 offset:6144\n\tds_read_b32 v89, %1 offset:6400\n\tds_read_b32 v90, %1 offset:6656\n\t"
-        "ds_read_b32 v91, %1 offset:6912\n\tds_read_b32 v92, %1 offset:7168\n\t"
-        "v_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\ts_waitcnt lgkmcnt(0)"
-        : "={v[64:95]}"(T)
-        : "v"(lds_addr)
-        : "memory");
-    return T;
-}
-
-template <bool DN, bool DD>
-__device__ __forceinline__ void round_loop_asm(__amdgpu_buffer_rsrc_t wrsrc, ColView cv, int tstart, int tend, uint32_t joff,
-                                               const v32f &T, f2 &an, f2 &an2, f2 &ad, f2 &ad2) {
-    typedef const __attribute__((address_space(4))) uint32_t *c32;
-    struct Entries {
-        uint32_t o[8];  // row offsets in W
-        uint2 codes;    // 8 codes
-    };
-    auto sload = [&](Entries &en, int t) {
-        c32 po = (c32)(uint64_t)(cv.off + t);
-        c32 pc = (c32)(uint64_t)(cv.code + t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) en.o[i] = po[i];
-        en.codes = make_uint2(pc[0], pc[1]);
-    };
-    auto bload = [&](float(&w)[8], const Entries &en) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, en.o[i], 0));
-    };
-    auto consume_reload = [&](float(&w)[8], const uint2 &codes, const Entries &next) {
-#pragma unroll
-        for (int h = 0; h < 8; h += 4) {
-            const uint32_t word = h ? codes.y : codes.x;
-            const uint32_t k0 = (word >> 3) & 0x1Fu, k1 = (word >> 11) & 0x1Fu, k2 = (word >> 19) & 0x1Fu, k3 = word >> 27;
-            float x0, x1, x2, x3;
-            asm volatile(
-                "s_set_gpr_idx_on %[k0], gpr_idx(SRC1)\n\tv_mul_f32 %[x0], %[w0], v64\n\t"
-                "s_set_gpr_idx_idx %[k1]\n\tv_mul_f32 %[x1], %[w1], v64\n\t"
-                "s_set_gpr_idx_idx %[k2]\n\tv_mul_f32 %[x2], %[w2], v64\n\t"
-                "s_set_gpr_idx_idx %[k3]\n\tv_mul_f32 %[x3], %[w3], v64\n\t"
-                "s_set_gpr_idx_off"
-                : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3)
-                : [w0] "v"(w[h]), [w1] "v"(w[h + 1]), [w2] "v"(w[h + 2]), [w3] "v"(w[h + 3]), [k0] "s"(k0), [k1] "s"(k1),
-                  [k2] "s"(k2), [k3] "s"(k3), "{v[64:95]}"(T)
-                : "m0");
-            const float xs[4] = {x0, x1, x2, x3};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f2 xn = {xs[i], xs[i]}, xd = {w[h + i], w[h + i]};
-                w[h + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next.o[h + i], 0));
-                an += xn;
-                ad += xd;
-                if (DN) an2 += xn;
-                if (DD) ad2 += xd;
-            }
-        }
-    };
-    // one group of 8 W rows in flight (8 steps of prefetch: more does not pay here and the registers are needed)
-    float w[8];
-    Entries e0, e1;
-    uint2 codes;
-    sload(e0, tstart);
-    sload(e1, tstart + 8);
-    bload(w, e0);
-    codes = e0.codes;
-#pragma unroll 1
-    for (int t = tstart; t < tend; t += 16) {
-        consume_reload(w, codes, e1);
-        codes = e1.codes;
-        sload(e0, t + 16);
-        consume_reload(w, codes, e0);
-        codes = e0.codes;
-        sload(e1, t + 24);
-    }
-}
-
-template <bool STAMP, bool ASM>
-__device__ __forceinline__ void similarity_bx_body(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_,
-                                                                       const uint8_t *__restrict__ vcode_,
-                                                                       const int32_t *__restrict__ nvalid,
-                                                                       const uint8_t *__restrict__ codeT_, int64_t ldk, int m_,
-                                                                       int n, const int32_t *__restrict__ cols, int ncols,
-                                                                       const float *__restrict__ wlow_, uint32_t wbytes,
-                                                                       const float *__restrict__ wup_, int ldw_, int r0_, int compact_,
-                                                                       const float *__restrict__ tab_g,
-                                                                       float *__restrict__ num_out,
-                                                                       float *__restrict__ den_out) {
-    const gf32p wup = (gf32p)(uint64_t)wup_;
-    __shared__ f2 tab[32 * 32];                    // {distance, both valid}[row code][column code], rows 28.. zero
-    __shared__ float spbuf[BX_WAVES][2][64];       // per chain: the sum after every row of the round
-    for (int i = threadIdx.x; i < 32 * 32; i += 64 * BX_WAVES) {
-        f2 v = {0.0f, 0.0f};
-        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
-        tab[i] = v;
-    }
-    __syncthreads();
-    const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
-    const int lane = threadIdx.x & 63;
-    const int wave = uni(threadIdx.x >> 6);
-    const int ci = blockIdx.x * BX_WAVES + wave;  // the wave's group of BX_Q columns in the list
-    if (ci * BX_Q >= ncols) return;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
-    // A wave owns BX_Q columns and advances them in turn, one round each (BX_Q = 1 in production).
-    ColView cv[BX_Q];
-    int colid[BX_Q], mrows[BX_Q], j0[BX_Q], tbase[BX_Q];
-#pragma unroll
-    for (int q = 0; q < BX_Q; ++q) {
-        const int col = uni(cols[ci * BX_Q + q]);  // (the list is padded with column n: an all-skipped column)
-        colid[q] = col;
-        cv[q].off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
-        cv[q].row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
-        cv[q].code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
-        cv[q].nvalid = uni(nvalid[col]);
-        cv[q].colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
-        cv[q].ldw = ldw_;
-        cv[q].compact = compact_;
-        cv[q].lastpad = (int)ldk - 1;
-        cv[q].nr = 0;
-        // Lanes are CONSECUTIVE rows (one coalesced 256-byte load per partner row; a row that takes no part idles
-        // its lane), partners come from the compacted list (only valid rows cost a step).  In compact mode the lanes
-        // are consecutive ENTRIES of the list as well (no idle lanes, the W load becomes a 64-lane gather over ~90
-        // consecutive floats): "row" j then means list entry j, m the number of valid rows, every row is valid.
-        mrows[q] = compact_ ? cv[q].nvalid : m_;
-        j0[q] = min(r0_, max(mrows[q] - 1, 0));
-        tbase[q] = 0;  // valid rows before j0
-    }
-
-    // lanes 2q / 2q+1 hold the running numerator / denominator sum of column q and the increment their last full
-    // round brought (the estimate behind the second-grid decision; < 0: unknown)
-    float sall = 0.0f, pinc = -1.0f;
-    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_dual = 0, n_short = 0, t0c = 0, rt0 = 0;
-    if (STAMP) {
-        t0c = __builtin_readcyclecounter();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-#pragma unroll
-    for (int q = 0; q < BX_Q; ++q) {
-        f2 s2 = {0.0f, 0.0f};
-        for (int j = 0; j < j0[q]; ++j) {
-            tbase[q] += compact_ ? 1 : (uni((int)cv[q].colcode[j]) != (int)BX_SKIP);
-            s2 = exact_row(cv[q], wup, tabp, j, tbase[q], 3, s2);
-        }
-        if (lane == 2 * q) sall = s2.x;
-        if (lane == 2 * q + 1) sall = s2.y;
-    }
-    if (STAMP) {
-        const unsigned long long t1 = __builtin_readcyclecounter();
-        t_pro = t1 - t0c;
-        t0c = t1;
-    }
-    int guard = 0;  // every round commits at least one row; a round that does not would loop forever
-    bool more = true;
-    while (more) {
-        more = false;
-        if (++guard > m_ + 64) {
-            sall = __uint_as_float(0x7FC00000u);  // (never reached; NaN results fail every parity test)
-            break;
-        }
-#pragma unroll
-        for (int q = 0; q < BX_Q; ++q) {
-            const int nv = cv[q].nvalid, m = mrows[q];
-            if (!(j0[q] < m - 1 && tbase[q] < nv)) continue;
-            more = true;
-            const int nrows = min(64 - ((j0[q] - r0_) & 63), m - 1 - j0[q]);
-            // Which chains may leave their binade in this round?  They also accumulate on the next grid.  A wrong
-            // "no" only shortens the round (resolve_chain), never the result.
-            float Bl, ul;
-            const bool grid = grid_of(sall, Bl, ul);
-            const bool risky = !grid || pinc < 0.0f || !(sall + 1.3f * pinc * ((float)nrows * (1.0f / 64.0f)) < 2.0f * Bl);
-            const uint32_t rb = (uint32_t)(__ballot(risky) >> (2 * q)) & 3u;
-            const float Bn = rl(Bl, 2 * q), un = rl(ul, 2 * q), Bd = rl(Bl, 2 * q + 1), ud = rl(ul, 2 * q + 1);
-            f2 an = {Bn, Bn + un}, an2 = {2.0f * Bn, 2.0f * Bn + 2.0f * un};
-            f2 ad = {Bd, Bd + ud}, ad2 = {2.0f * Bd, 2.0f * Bd + 2.0f * ud};
-            const uint32_t joff = 4u * (compact_ ? (uint32_t)cv[q].row[j0[q] + lane] : (uint32_t)(j0[q] + lane));
-            const uint32_t cj8 =
-                lane < nrows ? (uint32_t)(compact_ ? cv[q].code[j0[q] + lane] : cv[q].colcode[j0[q] + lane]) : BX_SKIP;
-            const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
-            // partners: the valid rows behind j0 (entries at or before a lane's own row read zeros: W is lower
-            // triangular here); the group of 8 that holds the first of them
-            const int tstart = tbase[q] & ~7, tend = (nv + 7) & ~7;
-            if (ASM) {
-                // EXEC = the lanes whose row takes part (the others keep their accumulators: increment 0)
-                const v32f T = fill_table_regs((uint32_t)(uintptr_t)tabp + cj8);
-                if (cj8 != BX_SKIP) {
-                    switch (rb) {
-                        case 0: round_loop_asm<false, false>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
-                        case 1: round_loop_asm<true, false>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
-                        case 2: round_loop_asm<false, true>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
-                        default: round_loop_asm<true, true>(wrsrc, cv[q], tstart, tend, joff, T, an, an2, ad, ad2); break;
-                    }
-                }
-            } else {
-                v32f T;  // the lane's table column (zeros for a row that takes no part: column 28 of the table)
-#pragma unroll
-                for (int a = 0; a < 32; ++a)
-                    T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
-                const float e = cj8 != BX_SKIP ? 1.0f : 0.0f;
-                switch (rb) {
-                    case 0: round_loop<false, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                    case 1: round_loop<true, false>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                    case 2: round_loop<false, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                    default: round_loop<true, true>(wrsrc, cv[q], tstart, tend, joff, T, e, an, an2, ad, ad2); break;
-                }
-            }
-            if (STAMP) {
-                const unsigned long long t1 = __builtin_readcyclecounter();
-                t_loop += t1 - t0c;
-                t0c = t1;
-                ++n_rounds;
-                n_dual += __builtin_popcount(rb);
-            }
-            int limit = nrows;
-            {
-                const Resolved r = resolve_chain(cv[q], wup, tabp, j0[q], tbase[q], vmask, 0, rl(sall, 2 * q), an.x - Bn,
-                                                 an.y - (Bn + un), an2.x - 2.0f * Bn, an2.y - (2.0f * Bn + 2.0f * un), limit,
-                                                 (rb & 1u) != 0);
-                spbuf[wave][0][lane] = r.sp;
-                limit = uni(r.limit);
-            }
-            {
-                const Resolved r = resolve_chain(cv[q], wup, tabp, j0[q], tbase[q], vmask, 1, rl(sall, 2 * q + 1), ad.x - Bd,
-                                                 ad.y - (Bd + ud), ad2.x - 2.0f * Bd, ad2.y - (2.0f * Bd + 2.0f * ud), limit,
-                                                 (rb & 2u) != 0);
-                spbuf[wave][1][lane] = r.sp;
-                limit = uni(r.limit);
-            }
-            limit = max(limit, 1);
-            if ((lane >> 1) == q) {
-                const float snew = spbuf[wave][lane & 1][limit - 1];  // (limit >= 1: every chain commits at least one row)
-                // (a short round is a poor sample of the increment per row: keep the previous estimate)
-                if (!grid) pinc = -1.0f;
-                else if (limit >= 16) pinc = (snew - sall) * (64.0f / (float)limit);
-                sall = snew;
-            }
-            if (STAMP) n_short += limit < nrows;
-            tbase[q] += __builtin_popcountll(vmask & ((limit >= 64 ? 0ull : (1ull << limit)) - 1ull));
-            j0[q] += limit;
-            if (STAMP) {
-                const unsigned long long t1 = __builtin_readcyclecounter();
-                t_res += t1 - t0c;
-                t0c = t1;
-            }
-        }
-    }
-    if (STAMP && lane == 0) {
-        atomicAdd(&g_bx_stamps[0], t_pro);
-        atomicAdd(&g_bx_stamps[1], t_loop);
-        atomicAdd(&g_bx_stamps[2], t_res);
-        atomicAdd(&g_bx_stamps[3], 1ull);
-        atomicAdd(&g_bx_stamps[4], n_rounds);
-        atomicAdd(&g_bx_stamps[5], n_dual);
-        atomicAdd(&g_bx_stamps[6], __builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
-        atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
-        atomicMax(&g_bx_stamps[8], n_rounds);
-        atomicAdd(&g_bx_stamps[9], n_short);
-        if (ci < 16384) {
-            unsigned int *r = g_bx_rec + 8 * ci;
-            r[0] = (unsigned)colid[0];
-            r[1] = (unsigned)(t_pro >> 6);
-            r[2] = (unsigned)(t_loop >> 6);
-            r[3] = (unsigned)(t_res >> 6);
-            r[4] = (unsigned)n_rounds;
-            r[5] = (unsigned)n_short;
-            r[6] = (unsigned)n_dual;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < BX_Q; ++q) {
-        if (colid[q] < n) {
-            const float sn = rl(sall, 2 * q), sd = rl(sall, 2 * q + 1);
-            if (lane == 0) {
-                num_out[colid[q]] = sn;
-                den_out[colid[q]] = sd;
-            }
-        }
-    }
-}
-
-// Two entry points over the same body: the loop with the folded table read needs 96 VGPRs to keep five waves per
-// SIMD and is compiled under that limit; the compiler-built loop must not be squeezed (its indexed table would spill).
-template <bool STAMP>
-__global__ __launch_bounds__(64 * BX_WAVES) void similarity_bx_kernel(const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
-                 const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m_, int n,
-                 const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
-                 const float *__restrict__ wup_, int ldw_, int r0_, int compact_, const float *__restrict__ tab_g,
-                 float *__restrict__ num_out, float *__restrict__ den_out) {
-    similarity_bx_body<STAMP, false>(voff_, vrow_, vcode_, nvalid, codeT_, ldk, m_, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, compact_, tab_g, num_out, den_out);
-}
-template <bool STAMP>
-__global__ __launch_bounds__(64 * BX_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_bx_asm_kernel(
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
-                 const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m_, int n,
-                 const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_, uint32_t wbytes,
-                 const float *__restrict__ wup_, int ldw_, int r0_, int compact_, const float *__restrict__ tab_g,
-                 float *__restrict__ num_out, float *__restrict__ den_out) {
-    similarity_bx_body<STAMP, true>(voff_, vrow_, vcode_, nvalid, codeT_, ldk, m_, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, compact_, tab_g, num_out, den_out);
-}
-
 // ---- per-lane grids ------------------------------------------------------------------------------------------
-// The kernel above fixes ONE grid per chain and round (the binade of the sum at the round's first row) and pays for
-// every binade crossing: a second pair of accumulators for predicted crossings, a round cut short for the others
-// (the early rounds, where the sum doubles every few rows, are walked three to four times).  Nothing in the scheme
-// needs the lanes of a round to agree on a grid: a lane's accumulators only have to start on the grid of the sum
+// A kernel that fixes ONE grid per chain and round (the binade of the sum at the round's first row: round 2's `bx`)
+// pays for every binade crossing: a second pair of accumulators for predicted crossings, a round cut short for the
+// others (the early rounds, where the sum doubles every few rows, are walked three to four times).  Nothing in the
+// scheme needs the lanes of a round to agree on a grid: a lane's accumulators only have to start on the grid of the sum
 // IN FRONT OF ITS OWN ROW.  That sum is not known before the round, but it is predictable to a fraction of a row:
-//     increment of row j  ~  c * (valid rows behind j) * G[a_j],   G[a] = sum_b h_b D[b][a]
-// (h = the column's residue frequencies; G = 1 for the denominator; c = the ratio measured on the previous round,
-// on the ordered first row for the first round).  Every lane starts on the grid of its predicted sum, the round
+//     increment of row j  ~  c * (valid rows behind j) * wbar_j * G[a_j],   G[a] = sum_b h_b D[b][a]
+// (h = the column's residue frequencies; G = 1 for the denominator; wbar_j = the mean of W[j][k > j], one number per
+// sequence computed behind the pair pass -- on alignments with families of close sequences the rows differ by a factor of
+// several in what they add, and a predictor blind to that misjudges the binade of every row near a crossing: 52.9
+// instead of 19.1 ordered rows per column on the ENOG-like alignment of tools/sim_by_data.py; c = the ratio measured
+// on the previous round, on the ordered first row for the first round).  Every lane starts on the grid of its predicted sum, the round
 // loop has a single version (two packed adds per step, no second grid), every round covers its 64 rows, and the
 // stitching commits segment by segment: lanes whose grid is the binade the sum really is in are scanned as before;
 // a row whose sum leaves the binade (the crossing row, ~9 per chain at m = 2000) or whose prediction was wrong
@@ -829,19 +364,16 @@ __device__ __forceinline__ void lg_wait_rows(LgD &D) {
                  : "memory");
 }
 
-// W rows by global_load_dword with a 64-bit per-lane address instead of buffer_load_dword (SGPR row offset + per-lane
-// offset, range-checked): tools/ubench_wstream.hip measures 5.3 instead of 8.6 CU-cycles per 256-byte wave-load for
-// the same rows (30 against 18 TB/s chip-wide) -- the buffer path costs the texture addresser more per instruction.
-// One more VALU instruction per step (the address).
-// MODE 3: (production) global loads with the row address in an SGPR pair and the lane offset in a VGPR (s_add_u32 /
-//         s_addc_u32: two SALU, no VALU); hand-issued, so the loop counts VMCNT itself: 16 loads are in flight at
-//         every step and nothing else of the loop is a vector-memory instruction
-//      0: global loads, 64-bit per-lane address left to the compiler (v_lshl_add_u64: one VALU + one SALU per step;
-//         diagnostics, MSA_LG_DBG & 128: 3.38 instead of 3.13 ms at C3)
-//      1: buffer loads (diagnostics, MSA_LG_DBG & 64: 4.03 ms)
-//      2: no W reloads at all (diagnostics, MSA_LG_DBG & 1: what the W stream costs; results are wrong)
-template <int MODE>
-__device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, const float *wlow_g,
+// W rows by global_load_dword with the row address in an SGPR pair and the lane offset in a VGPR (s_add_u32 /
+// s_addc_u32: two SALU, no VALU), hand-issued, so the loop counts VMCNT itself: 16 loads are in flight at every step
+// and nothing else of the loop is a vector-memory instruction.  (Measured against it in round 2, tools/ubench_wstream.hip:
+// buffer_load_dword with the list offset as SGPR offset costs the texture addresser 8.6 instead of 5.3 CU-cycles per
+// 256-byte wave-load -- 4.03 instead of 3.13 ms at C3; a 64-bit per-lane address left to the compiler one more VALU
+// per step -- 3.38 ms.)
+// BIG: the list holds row indices instead of byte offsets (any number of rows: 32-bit offsets end at m = 32768); the
+// row address is multiplied out on the scalar unit, two more SALU instructions per step.
+template <bool BIG>
+__device__ __forceinline__ void round_loop_lds(const float *wlow_g, uint32_t rowbytes,
                                                const __attribute__((address_space(1))) uint32_t *off,
                                                const __attribute__((address_space(1))) uint16_t *trow, int tstart, int tend,
                                                uint32_t joff, uint32_t base, f2 &an, f2 &ad) {
@@ -855,14 +387,10 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
         for (int i = 0; i < 8; ++i) en.c[i] = pc[i];
     };
     // (every list offset + lane offset lies inside wlow: rows 0 .. m, columns below ldw)
-    const __attribute__((address_space(1))) char *wlane = (const __attribute__((address_space(1))) char *)(uint64_t)wlow_g + joff;
     const uint64_t wuni = (uint64_t)uniform_ptr((const __attribute__((address_space(1))) char *)(uint64_t)wlow_g);
     auto wrow = [&](float &dst, uint32_t o) {
-        if (MODE == 1) dst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, o, 0));
-        else if (MODE == 3) {
-            const uint64_t row = wuni + o;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(joff), "s"(row) : "memory");
-        } else dst = *reinterpret_cast<const __attribute__((address_space(1))) float *>(wlane + o);
+        const uint64_t row = BIG ? wuni + (uint64_t)o * (uint64_t)rowbytes : wuni + o;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(joff), "s"(row) : "memory");
     };
     auto bload = [&](float(&w)[16], const LgEntries &en) {
 #pragma unroll
@@ -872,11 +400,11 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
     auto consume_reload = [&](float(&w)[16], const LgD &D, const LgEntries &next) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (MODE == 3) asm volatile("s_waitcnt vmcnt(15)" : "+v"(w[i])::"memory");  // the oldest of the 16 loads in flight
+            asm volatile("s_waitcnt vmcnt(15)" : "+v"(w[i])::"memory");  // the oldest of the 16 loads in flight
             const float wi = w[i];
             const float x = wi * D.d[i];
             const f2 xn = {x, x}, xd = {wi, wi};
-            if (MODE != 2) wrow(w[i], next.o[i]);
+            wrow(w[i], next.o[i]);
             an += xn;
             ad += xd;
         }
@@ -902,25 +430,25 @@ __device__ __forceinline__ void round_loop_lds(__amdgpu_buffer_rsrc_t wrsrc, con
         consume_reload(w, dB, eA);
     }
     lg_wait_rows(dA);  // (nothing may stay in flight into the caller's LDS traffic)
-    if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 constexpr int LG_WAVES_MAX = 8;  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
 
-// LDST: the lane's table column lives in LDS (round_loop_lds; `nr` rows per wave behind the static arrays, within
-// the first 64 KB: M0 holds 16 bits) instead of 32 registers (round_loop).
-template <bool STAMP, bool LDST>
+// The lane's table column lives in LDS (round_loop_lds; `nr` rows per wave behind the static arrays, within the first
+// 64 KB: M0 holds 16 bits).
+template <bool STAMP, bool BIG>
 __device__ __forceinline__ void similarity_lg_body(
     const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
     const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_,
     int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,
-    uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
-    float *__restrict__ num_out, float *__restrict__ den_out) {
+    const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
+    float *__restrict__ num_out, float *__restrict__ den_out, const float *__restrict__ wbar) {
     const gf32p wup = (gf32p)(uint64_t)wup_;
     __shared__ f2 tab[32 * 32];                  // {distance, both valid}[row code][column code], rows 28.. zero
     __shared__ uint32_t hist[LG_WAVES_MAX][32];  // residue counts of the wave's column
     __shared__ float gtab[LG_WAVES_MAX][32];     // G[a] = mean over the column's valid rows of D[.][a]
-    extern __shared__ float ltab[];              // LDST: [wave][nr][64 lanes]
+    extern __shared__ float ltab[];              // [wave][nr][64 lanes]
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
         f2 v = {0.0f, 0.0f};
         if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
@@ -933,7 +461,6 @@ __device__ __forceinline__ void similarity_lg_body(
     const int wave = uni(threadIdx.x >> 6);
     const int ci = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (ci >= ncols) return;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
     const int col = uni(cols[ci]);
     ColView cv;
     cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
@@ -942,9 +469,8 @@ __device__ __forceinline__ void similarity_lg_body(
     cv.nvalid = uni(nvalid[col]);
     cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
     cv.ldw = ldw_;
-    cv.compact = 0;
     cv.lastpad = (int)ldk - 1;
-    cv.nr = 0;
+    cv.big = BIG ? 1 : 0;
     const __attribute__((address_space(1))) uint16_t *vtrow =
         uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
     const int nv = cv.nvalid;
@@ -975,7 +501,7 @@ __device__ __forceinline__ void similarity_lg_body(
             if (cj != BX_SKIP) {
                 ++tb;
                 seen = true;
-                const float rem = (float)(nv - tb);
+                const float rem = (float)(nv - tb) * unif(wbar[jstart]);
                 qd0 += rem;
                 qn0 += rem * gtab[wave][cj >> 3];
                 s2 = exact_row(cv, wup, tabp, jstart, tb, 3, s2);
@@ -1013,8 +539,9 @@ __device__ __forceinline__ void similarity_lg_body(
         // predicted sum in front of every row -> the lane's grid
         const int behind = nv - (tbase + __builtin_popcountll(vall & ((2ull << lane) - 1ull)));
         const bool takes = cj8 != BX_SKIP;
-        const float qd = takes ? (float)behind : 0.0f;
-        const float qn = takes ? (float)behind * gtab[wave][cj8 >> 3] : 0.0f;
+        // (the row's mean weight over its partners, a property of the alignment: rows of a tight family add less)
+        const float qd = takes ? (float)behind * wbar[j0 + lane] : 0.0f;
+        const float qn = takes ? qd * gtab[wave][cj8 >> 3] : 0.0f;
         float Bn, Bd, Qn, Qd;
         {
             const float Pd = wave_prefix(qd), Pn = wave_prefix(qn);
@@ -1025,31 +552,15 @@ __device__ __forceinline__ void similarity_lg_body(
             Qd = rl(Pd, 63);
         }
         // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
-        f2 an = {Bn, Bn + Bn * 0x1p-23f}, ad = {Bd, Bd + Bd * 0x1p-23f}, an2 = {0.0f, 0.0f}, ad2 = {0.0f, 0.0f};
+        f2 an = {Bn, Bn + Bn * 0x1p-23f}, ad = {Bd, Bd + Bd * 0x1p-23f};
         const uint32_t joff = 4u * (uint32_t)(j0 + lane);
-        if (LDST) {
+        {
             // the lane's table column into the wave's [row][lane] table (zeros for a row that takes no part: column 28)
             float *lt = ltab + (size_t)wave * nr * 64 + lane;
             for (int a = 0; a < nr; ++a)
                 lt[a * 64] = (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x;
             const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(ltab + (size_t)wave * nr * 64);
-            // (the diagnostic loop versions exist in the stamped kernel only)
-            if (STAMP && (r0_ & 0x10000))
-                round_loop_lds<2>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
-            else if (STAMP && (r0_ & 0x40000))
-                round_loop_lds<1>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
-            else if (STAMP && (r0_ & 0x80000))
-                round_loop_lds<0>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
-            else
-                round_loop_lds<3>(wrsrc, wlow_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
-        } else {
-            const int tstart = tbase & ~7, tend = (nv + 7) & ~7;
-            v32f T;  // the lane's table column
-#pragma unroll
-            for (int a = 0; a < 32; ++a)
-                T[a] = a < 29 ? (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x : 0.0f;
-            const float e = takes ? 1.0f : 0.0f;
-            round_loop<false, false>(wrsrc, cv, tstart, tend, joff, T, e, an, an2, ad, ad2);
+            round_loop_lds<BIG>(wlow_, 4u * (uint32_t)ldw_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
         }
         if (STAMP) {
             const unsigned long long t1 = __builtin_readcyclecounter();
@@ -1107,356 +618,75 @@ __device__ __forceinline__ void similarity_lg_body(
     }
 }
 
-// Two entry points over the same body: with the table in LDS the kernel is compiled for six waves per SIMD (80
-// registers; the LDS allocation admits 24 waves per CU for a 20-letter alphabet); the register-table version must
-// not be squeezed (its indexed table would go to scratch memory).
+// Compiled for five waves per SIMD (the LDS allocation admits 20 waves per CU for a 20-letter alphabet).  Two
+// instantiations: 32-bit byte offsets in the lists, or row indices (BIG, m > 32768).
 #define LG_PARAMS                                                                                                      \
     const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,      \
         const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, \
         int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
-        uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
-        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate
-#define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wbytes, wup_, ldw_, r0_, tab_g, num_out, den_out
-template <bool STAMP>
+        const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
+        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate, const float *__restrict__ wbar
+#define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar
+template <bool STAMP, bool BIG>
 __global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
     // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
     // kernel that computes them raises the gate when the similarity values will not be used)
     if (gate && *gate) return;
-    similarity_lg_body<STAMP, true>(LG_ARGS);
-}
-template <bool STAMP>
-__global__ __launch_bounds__(64 * LG_WAVES_MAX) void similarity_lg_regs_kernel(LG_PARAMS) {
-    if (gate && *gate) return;
-    similarity_lg_body<STAMP, false>(LG_ARGS);
+    similarity_lg_body<STAMP, BIG>(LG_ARGS);
 }
 #undef LG_PARAMS
 #undef LG_ARGS
 
-// ---- two columns per wave ------------------------------------------------------------------------------------
-// The kernel above is bound by the vector-memory pipeline: one 256-byte buffer load of a W row per 64 terms costs
-// the CU ~8.5 cycles whatever the occupancy (tools/ubench_wstream.hip: 18 TB/s chip-wide for this pattern, all
-// L2 hits), and 2.2e8 of them are 3.6 of its 4.0 ms at 2000 x 10000.  Here a wave owns TWO columns (neighbours in
-// the order by valid rows) and walks the UNION of their valid rows once: every W row loaded serves both columns.
-//   * the lane's table lookup D[a_k][a_j] comes from ONE table per workgroup instead of one per wave and round:
-//     every entry replicated 32 times ([a_k][a_j][copy], lane l reads copy l % 32: no bank conflict), address =
-//     (a_k * nr * 128, from the list, SGPR) + (a_j * 128 + 4 (l % 32), per lane and round): one v_add + ds_read_b32;
-//   * a row that takes part in only one of the two columns: the other column reads the table's zero row
-//     (numerator term 0) and adds W * 0 to its denominator -- v_pk_fma_f32 with the 1/0 flag of the list as the
-//     scalar operand; W * 1 is exact, so fl(W * 1 + s) is the reference's fl(s + W);
-//   * no per-wave LDS, 5 waves per SIMD, all the waves of 10 000 columns resident at once.
-struct PairView {  // the union of two columns' valid rows, in row order (lg2_union_kernel)
-    const __attribute__((address_space(1))) uint32_t *off;  // W row offset; padding: the zero row
-    const __attribute__((address_space(1))) uint32_t *tt;   // table-row offsets a_k * nr * 128 of the two columns, 16 bits each; padding: zero rows
-    const __attribute__((address_space(1))) float *ee;      // {takes part in column 1, in column 2} as 1.0 / 0.0
-    int n;
-};
-
-__device__ __forceinline__ void round_loop_q2(__amdgpu_buffer_rsrc_t wrsrc, PairView pv, int tstart, int tend, uint32_t joff,
-                                              ldsp rtab, uint32_t vb1, uint32_t vb2, f2 &an1, f2 &ad1, f2 &an2, f2 &ad2) {
-    typedef const __attribute__((address_space(4))) uint32_t *c32;
-    typedef const __attribute__((address_space(4))) float *cf32;
-    auto lo = [&](uint32_t(&o)[8], int t) {
-        c32 p = (c32)(uint64_t)(pv.off + t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = p[i];
-    };
-    auto lt = [&](uint32_t(&x)[8], int t) {
-        c32 p = (c32)(uint64_t)(pv.tt + t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = p[i];
-    };
-    auto le = [&](float(&e)[16], int t) {
-        cf32 p = (cf32)(uint64_t)(pv.ee + 2 * t);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = p[i];
-    };
-    auto bload = [&](float(&w)[8], const uint32_t(&o)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, o[i], 0));
-    };
-    auto dissue = [&](float(&d1)[8], float(&d2)[8], const uint32_t(&x)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            d1[i] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(rtab + (vb1 + (x[i] & 0xFFFFu)));
-            d2[i] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(rtab + (vb2 + (x[i] >> 16)));
-        }
-    };
-    auto consume_reload = [&](float(&w)[8], const float(&d1)[8], const float(&d2)[8], const float(&e)[16], const uint32_t(&next)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float wi = w[i];
-            const float x1 = wi * d1[i], x2 = wi * d2[i];
-            w[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, joff, next[i], 0));
-            an1 += f2{x1, x1};
-            an2 += f2{x2, x2};
-            ad1 = __builtin_elementwise_fma(f2{wi, wi}, f2{e[2 * i], e[2 * i]}, ad1);
-            ad2 = __builtin_elementwise_fma(f2{wi, wi}, f2{e[2 * i + 1], e[2 * i + 1]}, ad2);
-        }
-    };
-    // Groups of 8 union entries, A and B in turn.  In front of a group: its table values and flags and the W row
-    // offsets of the group after next have arrived (one lgkmcnt(0), everything outstanding is a group old); then
-    // the table reads of the next group and the scalar loads of later groups are issued, then 8 steps of VALU work
-    // whose W rows were requested two groups ago.
-    uint32_t oA[8], oB[8], tA[8], tB[8];
-    float eA[16], eB[16], wA[8], wB[8], d1A[8], d2A[8], d1B[8], d2B[8];
-    lo(oA, tstart);
-    lo(oB, tstart + 8);
-    lt(tA, tstart);
-    le(eA, tstart);
-    bload(wA, oA);
-    bload(wB, oB);
-    dissue(d1A, d2A, tA);
-    lt(tB, tstart + 8);
-    lo(oA, tstart + 16);
-#pragma unroll 1
-    for (int t = tstart; t < tend; t += 16) {  // (the lists are padded: zero row of W, zero rows of the table, flags 0)
-        dissue(d1B, d2B, tB);
-        lt(tA, t + 16);
-        le(eB, t + 8);
-        lo(oB, t + 24);
-        __builtin_amdgcn_sched_barrier(0);  // (the scalar loads must not sink towards their use: the next wait would stall on them)
-        consume_reload(wA, d1A, d2A, eA, oA);
-        dissue(d1A, d2A, tA);
-        lt(tB, t + 24);
-        le(eA, t + 16);
-        lo(oA, t + 32);
-        __builtin_amdgcn_sched_barrier(0);
-        consume_reload(wB, d1B, d2B, eB, oB);
-    }
-}
-
-constexpr int LG2_WAVES = 12;  // waves per workgroup (a multiple of 4: a workgroup fills the SIMDs evenly): two workgroups share a CU (the 56 KB table each), 6 waves per SIMD
-
-template <bool STAMP>
-__global__ __launch_bounds__(64 * LG2_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void similarity_lg2_kernel(
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
-    const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, int64_t ldk, int m, int n,
-    const int32_t *__restrict__ cols, int npairs, const uint32_t *__restrict__ uoff_, const uint32_t *__restrict__ utt_,
-    const float *__restrict__ uee_, const int32_t *__restrict__ nunion, int nr, const float *__restrict__ wlow_,
-    uint32_t wbytes, const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
-    float *__restrict__ num_out, float *__restrict__ den_out) {
-    const gf32p wup = (gf32p)(uint64_t)wup_;
-    __shared__ uint32_t hist[LG2_WAVES][2][32];  // residue counts of the wave's columns
-    __shared__ float gtab[LG2_WAVES][2][32];     // G[a] = mean over the column's valid rows of D[.][a]
-    extern __shared__ float rtab_[];             // [nr][nr][32]: D[a][b] (zero where a or b is the row behind the alphabet), 32 copies
-    for (int i = threadIdx.x; i < nr * nr * 32; i += blockDim.x) {
-        const int a = (i >> 5) / nr, b = (i >> 5) % nr;
-        rtab_[i] = (a < nr - 1 && b < nr - 1) ? tab_g[(a * 32 + b) * 2] : 0.0f;
-    }
-    for (int i = threadIdx.x; i < LG2_WAVES * 2 * 32; i += blockDim.x) (&hist[0][0][0])[i] = 0u;
+// ---- the statistic as the reference writes it ------------------------------------------------------------------------
+// Similarity::calculateVectors (statistics.pxd:55): for every column, rows j ascending, partners
+// k > j ascending, both valid:  num += W[j][k] * D[a_j][a_k];  den += W[j][k]  -- float32, one add after the other, the
+// product rounded before the add (-ffp-contract=off).  One lane per column, no cleverness: m^2 / 2 dependent adds per
+// lane.  The cross-check of similarity_lg where the CPU oracle is out of reach (MSA_SIM_KERNEL=seq; tests only).
+__global__ __launch_bounds__(64) void similarity_seq_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int n,
+                                                            const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wup,
+                                                            int ldw, const float *__restrict__ tab_g, float *__restrict__ num_out,
+                                                            float *__restrict__ den_out) {
+    __shared__ float dtab[29 * 32];
+    for (int i = threadIdx.x; i < 29 * 32; i += 64) dtab[i] = tab_g[2 * i];
     __syncthreads();
-    const ldsp rtab = (ldsp)(const __attribute__((address_space(3))) void *)rtab_;
-    const int lane = threadIdx.x & 63;
-    const int wave = uni(threadIdx.x >> 6);
-    const int pi = blockIdx.x * (int)(blockDim.x >> 6) + wave;
-    if (pi >= npairs) return;
-    // Every wave is resident from the start and the kernel ends with the heaviest pair: the host deals the pairs so
-    // that wave 0 of a workgroup holds the heaviest and the last wave the lightest -- the heavy ones issue first.
-    if (!(r0_ & 0x20000)) {
-        const int nw = (int)(blockDim.x >> 6);
-        const int band = nw > 1 ? (wave * 4) / nw : 0;  // 0 (heaviest quarter) .. 3
-        if (band == 0) __builtin_amdgcn_s_setprio(3);
-        else if (band == 1) __builtin_amdgcn_s_setprio(2);
-        else if (band == 2) __builtin_amdgcn_s_setprio(1);
-    }
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wlow_, 0, (int)wbytes, 0x00027000);
-    PairView pv;
-    pv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)uoff_ + (size_t)pi * ldk);
-    pv.tt = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)utt_ + (size_t)pi * ldk);
-    pv.ee = uniform_ptr((const __attribute__((address_space(1))) float *)(uint64_t)uee_ + (size_t)pi * ldk * 2);
-    pv.n = uni(nunion[pi]);
-    ColView cv[2];
-    int col[2], nv[2], jstart[2], tb[2];
-    float sn[2], sd[2], cn[2], cd[2];
-    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0;
-    if (STAMP) {
-        t0c = __builtin_readcyclecounter();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        col[q] = uni(cols[2 * pi + q]);  // (the list is padded with column n: an all-skipped column)
-        const int c = col[q];
-        cv[q].off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)c * ldk);
-        cv[q].row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)c * ldk);
-        cv[q].code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)c * ldk);
-        cv[q].nvalid = uni(nvalid[c]);
-        cv[q].colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)c * ldk);
-        cv[q].ldw = ldw_;
-        cv[q].compact = 0;
-        cv[q].lastpad = (int)ldk - 1;
-        cv[q].nr = nr;
-        nv[q] = cv[q].nvalid;
-        // the column's residue frequencies -> G
-        for (int t = lane; t < nv[q]; t += 64) atomicAdd(&hist[wave][q][cv[q].code[t] >> 3], 1u);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (lane < 32) {
-            float g = 0.0f;
-            if (lane < nr - 1)
-                for (int b = 0; b < nr - 1; ++b) g += (float)hist[wave][q][b] * rtab_[(b * nr + lane) * 32];
-            gtab[wave][q][lane] = nv[q] > 0 ? g / (float)nv[q] : 0.0f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        // the first rows in the reference's order: at least up to the first row that takes part
-        f2 s2 = {0.0f, 0.0f};
-        float qn0 = 0.0f, qd0 = 0.0f;
-        jstart[q] = 0;
-        tb[q] = 0;
-        bool seen = false;
-        while (jstart[q] < m - 1 && tb[q] < nv[q] && (jstart[q] < (r0_ & 0xFFFF) || !seen)) {
-            const uint32_t cj = (uint32_t)uni((int)cv[q].colcode[jstart[q]]);
-            if (cj != BX_SKIP) {
-                ++tb[q];
-                seen = true;
-                const float rem = (float)(nv[q] - tb[q]);
-                qd0 += rem;
-                qn0 += rem * gtab[wave][q][cj >> 3];
-                s2 = exact_row(cv[q], wup, rtab, jstart[q], tb[q], 3, s2);
-            }
-            ++jstart[q];
-        }
-        if (tb[q] >= nv[q]) jstart[q] = m;  // nothing behind the ordered rows: the column is done
-        sn[q] = unif(s2.x);
-        sd[q] = unif(s2.y);
-        qn0 = unif(qn0);
-        qd0 = unif(qd0);
-        cn[q] = unif((sn[q] > 0.0f && qn0 > 0.0f) ? sn[q] / qn0 : 0.8f);
-        cd[q] = unif((sd[q] > 0.0f && qd0 > 0.0f) ? sd[q] / qd0 : 0.8f);
-    }
-    if (STAMP) {
-        const unsigned long long t1 = __builtin_readcyclecounter();
-        t_pro = t1 - t0c;
-        t0c = t1;
-    }
-    int j0 = min(jstart[0], jstart[1]) & ~63;
-    // valid rows of either column / of their union before j0
-    int tbase[2] = {0, 0}, tbaseU = 0;
-    for (int r = lane; r < j0; r += 64) {  // (j0 > 0 only when both columns begin with 64 or more rows that take no part)
-        const bool v0 = cv[0].colcode[r] != BX_SKIP, v1 = cv[1].colcode[r] != BX_SKIP;
-        tbase[0] += __builtin_popcountll(__ballot(v0));
-        tbase[1] += __builtin_popcountll(__ballot(v1));
-        tbaseU += __builtin_popcountll(__ballot(v0 || v1));
-    }
-    tbase[0] = uni(tbase[0]);
-    tbase[1] = uni(tbase[1]);
-    tbaseU = uni(tbaseU);
-    for (; j0 < m - 1 && (tbase[0] < nv[0] || tbase[1] < nv[1]); j0 += 64) {
-        const int nrows = min(64, m - 1 - j0);
-        unsigned long long vall[2], vmask[2];
-        uint32_t vb[2];
-        float Bn[2], Bd[2], Qn[2], Qd[2];
-        bool takes[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t craw = lane < nrows ? (uint32_t)cv[q].colcode[j0 + lane] : BX_SKIP;
-            vall[q] = __ballot(craw != BX_SKIP);
-            const uint32_t cj8 = j0 + lane >= jstart[q] ? craw : BX_SKIP;  // (rows before jstart were evaluated in order)
-            vmask[q] = __ballot(cj8 != BX_SKIP);
-            takes[q] = cj8 != BX_SKIP;
-            const uint32_t aj = takes[q] ? cj8 >> 3 : (uint32_t)nr - 1u;
-            vb[q] = (aj << 7) + ((uint32_t)(lane & 31) << 2);
-            // predicted sum in front of every row -> the lane's grid
-            const int behind = nv[q] - (tbase[q] + __builtin_popcountll(vall[q] & ((2ull << lane) - 1ull)));
-            const float qd = takes[q] ? (float)behind : 0.0f;
-            const float qn = takes[q] ? (float)behind * gtab[wave][q][cj8 >> 3] : 0.0f;
-            const float Pd = wave_prefix(qd), Pn = wave_prefix(qn);
-            float un, ud;
-            grid_of(sn[q] + cn[q] * (Pn - qn), Bn[q], un);
-            grid_of(sd[q] + cd[q] * (Pd - qd), Bd[q], ud);
-            Qn[q] = rl(Pn, 63);
-            Qd[q] = rl(Pd, 63);
-        }
-        // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
-        f2 an0 = {Bn[0], Bn[0] + Bn[0] * 0x1p-23f}, ad0 = {Bd[0], Bd[0] + Bd[0] * 0x1p-23f};
-        f2 an1 = {Bn[1], Bn[1] + Bn[1] * 0x1p-23f}, ad1 = {Bd[1], Bd[1] + Bd[1] * 0x1p-23f};
-        round_loop_q2(wrsrc, pv, tbaseU & ~7, pv.n, 4u * (uint32_t)(j0 + lane), rtab, vb[0], vb[1], an0, ad0, an1, ad1);
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_loop += t1 - t0c;
-            t0c = t1;
-            ++n_rounds;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const f2 an = q ? an1 : an0, ad = q ? ad1 : ad0;
-            // (a lane whose row takes no part added W x flag to its denominator accumulators: ignored)
-            const ResolvedLg rn = resolve_lg<STAMP>(cv[q], wup, rtab, j0, tbase[q], vall[q], vmask[q], 0, sn[q], Bn[q], an.x - Bn[q],
-                                                    an.y - (Bn[q] + Bn[q] * 0x1p-23f));
-            const ResolvedLg rd = resolve_lg<STAMP>(cv[q], wup, rtab, j0, tbase[q], vall[q], vmask[q], 1, sd[q], Bd[q],
-                                                    takes[q] ? ad.x - Bd[q] : 0.0f, takes[q] ? ad.y - (Bd[q] + Bd[q] * 0x1p-23f) : 0.0f);
-            const float sn1 = unif(rn.s), sd1 = unif(rd.s);
-            if (sn1 > sn[q] && Qn[q] > 0.0f) cn[q] = unif((sn1 - sn[q]) / Qn[q]);
-            if (sd1 > sd[q] && Qd[q] > 0.0f) cd[q] = unif((sd1 - sd[q]) / Qd[q]);
-            sn[q] = sn1;
-            sd[q] = sd1;
-            tbase[q] += __builtin_popcountll(vall[q]);
-            if (STAMP) {
-                n_ordered += (unsigned)(rn.ordered + rd.ordered);
-                t_ord += rn.t_ordered + rd.t_ordered;
-            }
-        }
-        tbaseU += __builtin_popcountll(vall[0] | vall[1]);
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_res += t1 - t0c;
-            t0c = t1;
+    const int ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= ncols) return;
+    const int col = cols[ci];
+    if (col >= n) return;
+    const uint8_t *code = codeT + (size_t)col * ldk;
+    float num = 0.0f, den = 0.0f;
+    for (int j = 0; j + 1 < m; ++j) {
+        const uint32_t cj = code[j];
+        if (cj == BX_SKIP) continue;
+        const float *wr = wup + (size_t)j * ldw;
+        const float *drow = dtab + (cj >> 3) * 32;
+        for (int k = j + 1; k < m; ++k) {
+            const uint32_t ck = code[k];
+            if (ck == BX_SKIP) continue;
+            const float w = wr[k];
+            const float x = w * drow[ck >> 3];
+            num = num + x;
+            den = den + w;
         }
     }
-    if (STAMP && lane == 0) {
-        atomicAdd(&g_bx_stamps[0], t_pro);
-        atomicAdd(&g_bx_stamps[1], t_loop);
-        atomicAdd(&g_bx_stamps[2], t_res);
-        atomicAdd(&g_bx_stamps[3], 1ull);
-        atomicAdd(&g_bx_stamps[4], n_rounds);
-        atomicAdd(&g_bx_stamps[6], __builtin_amdgcn_s_memrealtime() - rt0);  // 100 MHz ticks
-        atomicMax(&g_bx_stamps[7], t_pro + t_loop + t_res);
-        atomicMax(&g_bx_stamps[8], n_rounds);
-        atomicAdd(&g_bx_stamps[10], n_ordered);
-        atomicAdd(&g_bx_stamps[11], t_ord);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (col[q] < n) {
-                num_out[col[q]] = sn[q];
-                den_out[col[q]] = sd[q];
-            }
-    }
+    num_out[col] = num;
+    den_out[col] = den;
 }
 
-// The union lists of the column pairs (one wave per pair): for every row that takes part in either column, in row
-// order: W row offset, the two table-row offsets (row behind the alphabet = zero row where the row takes no part),
-// the two 1/0 flags; padded behind the last entry like the single-column lists.
-__global__ __launch_bounds__(256) void lg2_union_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, const int32_t *__restrict__ cols,
-                                                        int npairs, uint32_t ldw4, int nr, uint32_t *__restrict__ uoff,
-                                                        uint32_t *__restrict__ utt, float *__restrict__ uee, int32_t *__restrict__ nunion) {
+// wbar[j] = mean of W[j][k] over k > j (the upper triangle of a row; 0 for the last row): the similarity kernel's
+// predictor scales its per-row estimates with it.  Any order of summation: it is an estimate, nothing exact hangs on it.
+__global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar) {
     const int lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pi >= npairs) return;
-    const uint8_t *s0 = codeT + (size_t)cols[2 * pi] * ldk, *s1 = codeT + (size_t)cols[2 * pi + 1] * ldk;
-    uint32_t *po = uoff + (size_t)pi * ldk, *pt = utt + (size_t)pi * ldk;
-    float2 *pe = reinterpret_cast<float2 *>(uee) + (size_t)pi * ldk;
-    const uint32_t stride = (uint32_t)nr * 128u, zrow = (uint32_t)(nr - 1) * stride;
-    int count = 0;
-    for (int kb = 0; kb < m; kb += 64) {
-        const int k = kb + lane;
-        const uint32_t c0 = k < m ? s0[k] : BX_SKIP, c1 = k < m ? s1[k] : BX_SKIP;
-        const bool v0 = c0 != BX_SKIP, v1 = c1 != BX_SKIP;
-        const unsigned long long mask = __ballot(v0 || v1);
-        if (v0 || v1) {
-            const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            po[pos] = (uint32_t)k * ldw4;
-            pt[pos] = (v0 ? (c0 >> 3) * stride : zrow) | ((v1 ? (c1 >> 3) * stride : zrow) << 16);
-            pe[pos] = make_float2(v0 ? 1.0f : 0.0f, v1 ? 1.0f : 0.0f);
-        }
-        count += __builtin_popcountll(mask);
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= m + 64) return;
+    float s = 0.0f;
+    if (j < m) {
+        const float *r = wup + (size_t)j * ldw;
+        for (int k = j + 1 + lane; k < m; k += 64) s += r[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     }
-    for (int64_t t = count + lane; t < ldk; t += 64) {
-        po[t] = (uint32_t)m * ldw4;  // row m of W: zeros
-        pt[t] = zrow | (zrow << 16);
-        pe[t] = make_float2(0.0f, 0.0f);
-    }
-    if (lane == 0) nunion[pi] = count;
+    if (lane == 0) wbar[j] = (j < m - 1) ? s / (float)(m - 1 - j) : 0.0f;  // (rows m .. m + 63: zeros, a round reads past the end)
 }
 
 // ---- identity row statistics (Cleaner::calculateSeqIdentity's consumers: selectMethod, getCutPointClusters) --------
@@ -1543,7 +773,7 @@ __global__ __launch_bounds__(128) void identity_final_kernel(const float *__rest
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
                                                          uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vrow,
                                                          uint8_t *__restrict__ vcode, uint16_t *__restrict__ vtrow, int skiprow,
-                                                         int32_t *__restrict__ nvalid) {
+                                                         int32_t *__restrict__ nvalid, int big) {
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= ncols_pad) return;
@@ -1559,7 +789,7 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
         const unsigned long long mask = __ballot(code != BX_SKIP);
         if (code != BX_SKIP) {
             const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            po[pos] = (uint32_t)k * ldw4;
+            po[pos] = big ? (uint32_t)k : (uint32_t)k * ldw4;  // (big: the row index; the kernel multiplies it out)
             pr[pos] = (uint16_t)k;
             pc[pos] = (uint8_t)code;
             pt[pos] = (uint16_t)((code >> 3) * 256u);
@@ -1567,8 +797,8 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
         count += __builtin_popcountll(mask);
     }
     for (int64_t t = count + lane; t < ldk; t += 64) {
-        po[t] = (uint32_t)m * ldw4;  // row m of W: zeros
-        pr[t] = (uint16_t)m;         // column m of W: zeros
+        po[t] = big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+        pr[t] = (uint16_t)m;                              // column m of W: zeros
         pc[t] = (uint8_t)BX_SKIP;
         pt[t] = (uint16_t)(skiprow * 256);  // the table's zero row
     }
@@ -1629,108 +859,59 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
     sim_encode_cm_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codeT, ldk, ncp, err_key);
 }
 
+// the lists hold 32-bit byte offsets of the W rows while those fit (row m included); beyond that, row indices
+bool lg_big(int m, int ldw) { return tuning().lg_big != 0 || ((uint64_t)m + 2) * (uint64_t)ldw * 4u > 0xFFFFFFFFull; }
+
 void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vrow,
                        uint8_t *vcode, uint16_t *vtrow, int32_t *nvalid) {
     const int ncp = bx_cols_pad(n);
-    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, vtrow, npos, nvalid);
+    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, vtrow, npos, nvalid,
+                                                    lg_big(m, ldw) ? 1 : 0);
 }
 
-int bx_cols_per_wave() { return BX_Q; }
-
-// cols: the columns to evaluate (device, ncols entries, a multiple of bx_cols_per_wave(): consecutive entries share a
-// wave; pad with the index n, the all-skipped column); the sums of every other column must have been zeroed by the
-// caller.  W (both triangles) must be smaller than 4 GB and m < 65535 (checked by the caller).
-int launch_similarity_bx(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode,
-                         const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wlow,
-                         const float *wup, int ldw, const void *tab, float *num_out, float *den_out) {
-    const int64_t ldk = bx_ldk(m);
-    const int r0 = tuning().bx_r0 >= 0 ? tuning().bx_r0 : BX_R0;
-    const int compact = tuning().bx_compact > 0 ? 1 : 0;
-    const unsigned grid = (unsigned)((ncols / BX_Q + BX_WAVES - 1) / BX_WAVES);  // ncols is a multiple of BX_Q
-    if (grid == 0) return 0;
-    const float *t = static_cast<const float *>(tab);
-    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
-    const bool stamp = (tuning().sim_mode & 64) != 0, use_asm = tuning().bx_asm != 0;
-#define BX_LAUNCH(KERNEL)                                                                                              \
-    KERNEL<<<grid, 64 * BX_WAVES, 0, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup, ldw, r0, \
-                                          compact, t, num_out, den_out)
-    if (stamp && use_asm) BX_LAUNCH(similarity_bx_asm_kernel<true>);
-    else if (stamp) BX_LAUNCH(similarity_bx_kernel<true>);
-    else if (use_asm) BX_LAUNCH(similarity_bx_asm_kernel<false>);
-    else BX_LAUNCH(similarity_bx_kernel<false>);
-#undef BX_LAUNCH
-    return 0;
-}
-
-// the same contract as launch_similarity_bx plus the 16-bit table-row list; the kernel with per-lane grids (the default)
+// cols: the columns to evaluate (device, ncols entries; pad with the index n, the all-skipped column); the sums of every
+// other column are left alone.  Any number of rows (see lg_big).
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
                          int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
-                         const int *gate) {
+                         const int *gate, const float *wbar) {
     const int64_t ldk = bx_ldk(m);
-    // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 1 -> no W loads, stamped kernel only)
-    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 1) << 16) | ((tuning().lg_dbg & 64) ? 0x40000 : 0) |
-                   ((tuning().lg_dbg & 128) ? 0x80000 : 0);
-    const bool ldst = tuning().lg_regs == 0;
+    const int r0 = tuning().lg_r0 >= 0 ? tuning().lg_r0 : LG_R0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
-    // eight waves per workgroup while their tables stay within the 64 KB M0 can address (static arrays: 10.5 KB)
     // four waves per workgroup: five workgroups (20 waves) per CU for a 20-letter alphabet, and a workgroup's slots
-    // are refilled as soon as its four columns are done (eight per workgroup, MSA_LG_DBG & 2: 4.0 instead of 3.8 ms at C3)
-    const int waves = ldst ? ((tuning().lg_dbg & 2) && (size_t)8 * nr * 256 + 10752 <= 65536 ? 8 : 4) : BX_WAVES;
-    const size_t dyn = ldst ? (size_t)waves * nr * 256 : 0;
+    // are refilled as soon as its four columns are done (eight per workgroup: 4.0 instead of 3.8 ms at C3)
+    const int waves = 4;
+    const size_t dyn = (size_t)waves * nr * 256;
     const unsigned grid = (unsigned)((ncols + waves - 1) / waves);
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
-    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
-    const bool stamp = (tuning().sim_mode & 64) != 0;
+    const bool stamp = (tuning().sim_mode & 64) != 0, big = lg_big(m, ldw);
 #define LG_LAUNCH(KERNEL)                                                                                              \
-    KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wbytes, wup, ldw, r0, \
-                                         t, num_out, den_out, gate)
-    if (ldst) {
-        const void *k = stamp ? (const void *)similarity_lg_kernel<true> : (const void *)similarity_lg_kernel<false>;
-        const int e = set_max_lds_once(k, (int)dyn);
-        if (e) return e;
-        if (stamp) LG_LAUNCH(similarity_lg_kernel<true>);
-        else LG_LAUNCH(similarity_lg_kernel<false>);
-    } else {
-        if (stamp) LG_LAUNCH(similarity_lg_regs_kernel<true>);
-        else LG_LAUNCH(similarity_lg_regs_kernel<false>);
-    }
+    do {                                                                                                               \
+        const int e = set_max_lds_once((const void *)KERNEL, (int)dyn);                                                \
+        if (e) return e;                                                                                               \
+        KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
+                                             t, num_out, den_out, gate, wbar);                                        \
+    } while (0)
+    if (stamp && big) LG_LAUNCH((similarity_lg_kernel<true, true>));
+    else if (stamp) LG_LAUNCH((similarity_lg_kernel<true, false>));
+    else if (big) LG_LAUNCH((similarity_lg_kernel<false, true>));
+    else LG_LAUNCH((similarity_lg_kernel<false, false>));
 #undef LG_LAUNCH
     return 0;
 }
 
-// Two columns per wave (consecutive entries of `cols`, ncols even, padded with the all-skipped column n; `waves`
-// consecutive pairs share a workgroup): the union lists are built here from the column order.  npos + 1 <= 23
-// (16-bit table-row offsets).
-bool lg2_fits(int npos) { return npos + 1 <= 23; }
-int lg2_max_waves() { return LG2_WAVES; }
-int launch_similarity_lg2(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, int npos,
-                          const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, int waves,
-                          uint32_t *uoff, uint32_t *utt, float *uee, int32_t *nunion, const float *wlow, const float *wup, int ldw,
+// mean weight of every row over its later partners (m + 64 floats): the similarity kernel's predictor reads it
+void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar) {
+    w_row_means_kernel<<<(m + 64 + 3) / 4, 256, 0, s>>>(wup, m, ldw, wbar);
+}
+
+// the plain sequential kernel (cross-check): same column list, same outputs
+int launch_similarity_seq(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wup, int ldw,
                           const void *tab, float *num_out, float *den_out) {
-    const int64_t ldk = bx_ldk(m);
-    // (diagnostics ride in the high bits of r0: MSA_LG_DBG & 16 -> no wave priorities)
-    const int r0 = (tuning().bx_r0 >= 0 ? tuning().bx_r0 : LG_R0) | ((tuning().lg_dbg & 16) ? 0x20000 : 0);
-    const int npairs = ncols / 2;
-    if (npairs == 0) return 0;
-    const int nr = npos + 1;
-    lg2_union_kernel<<<(npairs + 3) / 4, 256, 0, s>>>(codeT, ldk, m, cols, npairs, (uint32_t)ldw * 4u, nr, uoff, utt, uee, nunion);
-    const size_t dyn = (size_t)nr * nr * 128;
-    if (waves < 1 || waves > LG2_WAVES) return (int)hipErrorInvalidValue;
-    const unsigned grid = (unsigned)((npairs + waves - 1) / waves);
-    const float *t = static_cast<const float *>(tab);
-    const uint32_t wbytes = (uint32_t)(bx_wlow_rows(m) * (size_t)ldw * 4);
-    const bool stamp = (tuning().sim_mode & 64) != 0;
-    const void *k = stamp ? (const void *)similarity_lg2_kernel<true> : (const void *)similarity_lg2_kernel<false>;
-    const int e = set_max_lds_once(k, (int)dyn);
-    if (e) return e;
-    if (stamp)
-        similarity_lg2_kernel<true><<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, npairs, uoff, utt, uee,
-                                                                     nunion, nr, wlow, wbytes, wup, ldw, r0, t, num_out, den_out);
-    else
-        similarity_lg2_kernel<false><<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, nvalid, codeT, ldk, m, n, cols, npairs, uoff, utt, uee,
-                                                                      nunion, nr, wlow, wbytes, wup, ldw, r0, t, num_out, den_out);
+    if (ncols <= 0) return 0;
+    similarity_seq_kernel<<<(ncols + 63) / 64, 64, 0, s>>>(codeT, bx_ldk(m), m, n, cols, ncols, wup, ldw, static_cast<const float *>(tab),
+                                                           num_out, den_out);
     return 0;
 }
 

@@ -138,6 +138,12 @@ class BaseTrimmer:
                 "(platform=None / no visible device); construct the trimmer with platform='hip' on a GPU host")
         # a TrimmedAlignment is first materialised to its kept sequences / residues (_trimal.pyx:1324-1327)
         dense = alignment._dense()
+        if dense is alignment._matrix and dense.size:
+            # an alignment that is trimmed again (another trimmer, another setting): its rows are page-locked from the
+            # second trim on, for as long as the matrix lives -- every further upload is one DMA copy from where they lie
+            alignment._uploads = getattr(alignment, "_uploads", 0) + 1
+            if alignment._uploads == 2:
+                _lib.pin_array(dense)
         ty = alignment._alignment_type()
         indet = ord("X") if (ty & 4) else ord("N")
         if matrix is None:

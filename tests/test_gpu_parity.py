@@ -34,8 +34,7 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_SIM_TCOLS", "MSA_SIM_TP", "MSA_DEN_KERNEL", "MSA_BX_COMPACT", "MSA_BX_R0", "MSA_BX_ASM",
-                     "MSA_LG_REGS", "MSA_LG_DBG", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD", "MSA_PAIR_TI", "MSA_PAIR_DENSE"):
+        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -289,15 +288,13 @@ def test_c4_full_size_pair_counts(ctx):
     assert np.array_equal(bits(ov), bits(want))
 
 
-@pytest.mark.parametrize("pipe,tri,dense", [("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"), ("1", "1", "0"), ("2", "1", "0"), ("1", "1", "2")])
 @pytest.mark.parametrize("shape", [(2, 5), (9, 33), (65, 64), (130, 31), (513, 97), (700, 300), (1030, 70)])
-def test_pair_kernel_variants(ctx_with, pipe, tri, dense, shape):
-    """the software-pipelined pair-count loop and the triangle-only grid against the plain ones and the oracle
-    (odd and even chunk counts, rows that end inside a tile)"""
+def test_pair_kernel_shapes(ctx, shape):
+    """the software-pipelined pair-count loop on the triangle-only grid against the oracle (odd and even chunk counts,
+    rows that end inside a tile)"""
     m, n = shape
     a = synth_msa(m, n, 300 + m)
     ohit, odst = oracle.pair_counts(a, ord("X"))
-    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_XCD=tri, MSA_PAIR_DENSE=dense)
     ctx.upload(a, ord("X"))
     hit, dst = ctx.pair_counts()
     assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
@@ -306,12 +303,11 @@ def test_pair_kernel_variants(ctx_with, pipe, tri, dense, shape):
     assert np.array_equal(bits(w), bits(oracle.weights(ohit, odst)))
 
 
-@pytest.mark.parametrize("pipe,dense", [("0", "0"), ("1", "0"), ("2", "0"), ("1", "1"), ("1", "2")])
-def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe, dense):
-    """m large enough for two rows j per lane on the raw planes (TJ = 2): row slices against the oracle"""
+def test_pair_kernel_two_rows_per_lane(ctx):
+    """m large enough for the second regime of the pair pass (two rows j per lane, the plain loop): row slices against
+    the oracle"""
     m, n = 4300, 40
     a = synth_msa(m, n, 77)
-    ctx = ctx_with(MSA_PAIR_PIPE=pipe, MSA_PAIR_DENSE=dense)
     ctx.upload(a, ord("X"))
     hit, dst = ctx.pair_counts()
     assert np.array_equal(hit, hit.T) and np.array_equal(dst, dst.T)
@@ -321,10 +317,11 @@ def test_pair_kernel_variants_two_rows_per_lane(ctx_with, pipe, dense):
         assert np.array_equal(dst[np.ix_(rows, rows)], odst)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (3, 31), (65, 64), (209, 1227), (700, 5000), (2100, 4100)])
-def test_upload_paths_agree(ctx, shape):
-    """packed matrix (re-pitched in pieces), array of row pointers, already pitched matrix: the same residues on the
-    device (gap counts and a strict trim's similarity values as the witnesses)"""
+@pytest.mark.parametrize("shape", [(1, 1), (3, 31), (65, 64), (209, 1227), (700, 5000), (2100, 4100), (300, 1000), (64, 4000)])
+def test_upload_paths_agree(ctx, ctx_with, shape):
+    """packed matrix (the runtime's pitched copy, or re-pitched in pinned pieces), array of row pointers, already pitched
+    matrix, page-locked rows (one DMA copy from where they lie): the same residues on the device (gap counts and a
+    strict trim's similarity values as the witnesses), also on a context that held another shape in between"""
     m, n = shape
     a = synth_msa(m, n, 40 + m)
     vhash, dist = oracle.aa_matrix()
@@ -345,6 +342,18 @@ def test_upload_paths_agree(ctx, shape):
     ctx.shape = (m, n)
     g2, x2 = ctx.gaps(with_indet=True)
     assert np.array_equal(g2, g0) and np.array_equal(x2, x0)
+    locked = a.copy()
+    other = synth_msa(37, 130, 3)
+    staged = ctx_with(MSA_UPLOAD_DIRECT="0")
+    for c, pin in ((ctx, True), (staged, False), (ctx, True)):
+        c.upload(other, ord("X"))  # (another shape first: the padding columns of the device rows are dirty)
+        assert np.array_equal(c.gaps(), (other == ord("-")).sum(axis=0))
+        c.upload(locked, ord("X"), pin=pin)
+        g3, x3 = c.gaps(with_indet=True)
+        assert np.array_equal(g3, g0) and np.array_equal(x3, x0)
+        if m > 1:
+            assert np.array_equal(bits(c.similarity(vhash, dist)[1]), bits(q0))
+    del locked  # (its finalizer unregisters the rows)
 
 
 def _alphabet_case(m, n, letters, seed):
@@ -356,27 +365,24 @@ def _alphabet_case(m, n, letters, seed):
     return np.ascontiguousarray(a)
 
 
-@pytest.mark.parametrize("letters", [b"AC", b"ACDEFGHIKLMNPQRSTVWY", b"ACDEFGHIKLMNPQRSTVWYBZJUO*.?",  # <= 31 symbols: 5 planes
-                                     b"ACDEFGHIKLMNPQRSTVWYacdefghiklmnpqrstvwy",                      # 6 planes
-                                     bytes(range(33, 127))])                                         # raw planes
+@pytest.mark.parametrize("letters", [b"AC", b"ACDEFGHIKLMNPQRSTVWY", b"ACDEFGHIKLMNPQRSTVWYBZJUO*.?",
+                                     b"ACDEFGHIKLMNPQRSTVWYacdefghiklmnpqrstvwy", bytes(range(33, 127))])
 @pytest.mark.parametrize("shape", [(70, 200), (300, 97)])
-def test_pair_counts_dense_codes_by_alphabet_size(ctx_with, letters, shape):
-    """the pair pass picks its number of code planes from the byte values that occur: 5, 6, or the raw seven"""
+def test_pair_counts_by_alphabet_size(ctx, letters, shape):
+    """the pair pass compares raw bytes: alphabets from two symbols to every printable character, and a second
+    alignment with another alphabet on the same context"""
     m, n = shape
     a = _alphabet_case(m, n, letters, len(letters) + m)
     ohit, odst = oracle.pair_counts(a, ord("X"))
-    for dense in ("2", "0"):
-        ctx = ctx_with(MSA_PAIR_DENSE=dense)
-        for _ in range(2):
-            ctx.upload(a, ord("X"))
-            hit, dst = ctx.pair_counts()
-            assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
-        # a second alignment with another alphabet on the same context (the set is collected per alignment)
-        b = _alphabet_case(m, n, b"ACGT", 5)
-        ctx.upload(b, ord("X"))
+    for _ in range(2):
+        ctx.upload(a, ord("X"))
         hit, dst = ctx.pair_counts()
-        bhit, bdst = oracle.pair_counts(b, ord("X"))
-        assert np.array_equal(hit, bhit) and np.array_equal(dst, bdst)
+        assert np.array_equal(hit, ohit) and np.array_equal(dst, odst)
+    b = _alphabet_case(m, n, b"ACGT", 5)
+    ctx.upload(b, ord("X"))
+    hit, dst = ctx.pair_counts()
+    bhit, bdst = oracle.pair_counts(b, ord("X"))
+    assert np.array_equal(hit, bhit) and np.array_equal(dst, bdst)
 
 
 def _sim_parity(ctx, a, indet=ord("X")):
@@ -391,67 +397,34 @@ def _sim_parity(ctx, a, indet=ord("X")):
     assert np.array_equal(bits(mdk), bits(omdk))
 
 
-# binade-exact with per-lane grids: one column per wave (default = "lg") / two columns per wave; its
-# one-grid-per-round predecessor; numerator + denominator chain kernels; single chain
-KERNELS = ["", "lg", "q2", "bx", "chain", "pc"]
+# The similarity kernel (binade-exact, per-lane grids) in its two instantiations -- 32-bit byte offsets of the W rows in
+# the lists (default up to 32768 rows) and row indices multiplied out on the scalar unit (MSA_LG_BIG=1 forces it at
+# any size) -- and the plain sequential kernel (MSA_SIM_KERNEL=seq: one lane per column, the reference's two loops).
+KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq")]
+KERNEL_IDS = ["lg", "lg-big", "seq"]
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (113, 200), (225, 96), (337, 130), (640, 257)])
 def test_similarity_kernel_variants(ctx_with, kernel, shape):
     """Every similarity path against the oracle, at row counts on both sides of the round boundaries (64 rows per
-    round of the binade-exact kernel, 112 per round of the chain kernels) and with ragged column tiles."""
+    round) and with ragged numbers of columns."""
     m, n = shape
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(m, n, 4242 + m))
+    _sim_parity(ctx_with(**kernel), synth_msa(m, n, 4242 + m))
 
 
-@pytest.mark.parametrize("compact", ["0", "1"])
-@pytest.mark.parametrize("r0", ["0", "3", "8", "40"])
-def test_binade_kernel_shapes(ctx_with, compact, r0):
-    """The lane layout (consecutive rows / consecutive valid rows) and the number of rows evaluated in order before
-    the first round must not matter."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT=compact, MSA_BX_R0=r0), synth_msa(300, 150, 31))
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT=compact, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
-
-
-@pytest.mark.parametrize("kernel", ["lg", "q2"])
+@pytest.mark.parametrize("big", ["", "1"])
 @pytest.mark.parametrize("r0", ["0", "1", "3", "8", "40", "64", "70", "200"])
-def test_lane_grid_kernel_ordered_prefix(ctx_with, kernel, r0):
+def test_lane_grid_kernel_ordered_prefix(ctx_with, big, r0):
     """Per-lane grids: the number of rows evaluated in order before the first round (which then starts in the middle
     of a 64-row block, or several blocks in) must not matter."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_BX_R0=r0), synth_msa(300, 150, 31))
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_BX_R0=r0), _conserved_case(200, 70, 5))
+    _sim_parity(ctx_with(MSA_LG_BIG=big, MSA_LG_R0=r0), synth_msa(300, 150, 31))
+    _sim_parity(ctx_with(MSA_LG_BIG=big, MSA_LG_R0=r0), _conserved_case(200, 70, 5))
 
 
-@pytest.mark.parametrize("regs", ["0", "1"])
-def test_lane_grid_kernel_table_in_registers(ctx_with, regs):
-    """One column per wave: the lane's table column in LDS (default) or in 32 registers."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="lg", MSA_LG_REGS=regs), synth_msa(640, 257, 4882))
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="lg", MSA_LG_REGS=regs), _conserved_case(200, 70, 5))
-
-
-def test_column_pairs_with_disjoint_rows(ctx_with):
-    """Two columns per wave: neighbours whose valid rows barely overlap (the union list is twice as long as either
-    column's), columns that begin with more than 64 rows that take no part, an odd number of columns."""
-    r = np.random.default_rng(11)
-    a = synth_msa(330, 41, 77)
-    a[::2, 0:10] = ord("-")    # even rows only
-    a[1::2, 10:20] = ord("-")  # odd rows only
-    a[:150, 20:24] = ord("-")  # start late
-    a[:70, 24:27] = ord("-")
-    a[100:, 27:30] = ord("-")  # end early
-    a[r.random(a.shape) < 0.01] = ord("X")
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="q2"), np.ascontiguousarray(a))
-
-
-def test_column_pairs_many_workgroups(ctx_with):
-    """Two columns per wave with more pairs than two workgroups per CU hold at one wave each: 6000 columns of 130 rows."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="q2"), synth_msa(130, 6000, 99))
-
-
-@pytest.mark.parametrize("kernel", ["lg", "q2"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 def test_lane_grid_kernel_adversarial_predictions(ctx_with, kernel):
-    ctx = ctx_with(MSA_SIM_KERNEL=kernel)
+    ctx = ctx_with(**kernel)
     """Columns whose sums the per-lane predictor cannot foresee: the top half of the rows identical sequences (all
     their mutual weights zero, then a jump), a block of gaps in the middle of every column, residues sorted by row."""
     r = np.random.default_rng(5)
@@ -463,68 +436,38 @@ def test_lane_grid_kernel_adversarial_predictions(ctx_with, kernel):
     _sim_parity(ctx, np.ascontiguousarray(a))
 
 
-@pytest.mark.parametrize("shape", [(2, 70), (65, 64), (640, 257), (2100, 72), (9000, 8)])
-def test_binade_kernel_compact_lanes(ctx_with, shape):
+@pytest.mark.parametrize("kernel", KERNELS[:2], ids=KERNEL_IDS[:2])
+@pytest.mark.parametrize("shape", [(2016, 40), (2017, 33), (2100, 72), (4040, 20), (9000, 8)])
+def test_similarity_many_rows(ctx_with, kernel, shape):
+    """thousands of rows, a handful of columns (a single partial workgroup)"""
     m, n = shape
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_COMPACT="1"), synth_msa(m, n, 4242 + m))
+    _sim_parity(ctx_with(**kernel), synth_msa(m, n, 77 + m))
 
 
-@pytest.mark.parametrize("asm", ["0", "1"])
-@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (300, 150), (640, 257), (2100, 72), (4040, 20)])
-def test_binade_kernel_loop_variants(ctx_with, asm, shape):
-    """The round loop as the compiler builds it and with the table read folded into the multiply (inline asm,
-    fixed table registers, EXEC limited to the rows that take part)."""
-    m, n = shape
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_ASM=asm), synth_msa(m, n, 977 + m))
-    if m == 300:
-        _sim_parity(ctx_with(MSA_SIM_KERNEL="bx", MSA_BX_ASM=asm), _conserved_case(200, 70, 5))
-
-
-@pytest.mark.parametrize("kernel", ["chain", "pc"])
-@pytest.mark.parametrize("tcols", ["16", "24", "40"])
-def test_similarity_narrow_column_tiles(ctx_with, kernel, tcols):
-    """MSA_SIM_TCOLS: fewer than 64 active lanes per wave (the tile width is baked into the codes)."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel, MSA_SIM_TCOLS=tcols), synth_msa(150, 211, 99))
-
-
-@pytest.mark.parametrize("kernel", KERNELS)
-def test_similarity_above_resident_limit(ctx_with, kernel):
-    """m > 2016: second instantiation of the chain numerator kernel; the other kernels at that size."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2100, 72, 77))
-
-
-@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
-def test_similarity_36_round_resident_kernel(ctx_with, kernel):
-    """2016 < m <= 4032: the 36-round instantiation of the resident numerator kernel."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2017, 33, 79))
-
-
-@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
-def test_similarity_streaming_numerator(ctx_with, kernel):
-    """m > 4032: the chain numerator kernel streams its codes two rounds ahead."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(4040, 20, 80))
-
-
-@pytest.mark.parametrize("switch", ["MSA_SIM_TP=0", "MSA_DEN_KERNEL=exec"])
-@pytest.mark.parametrize("shape", [(9, 33), (225, 96), (640, 257), (2017, 33), (4040, 20)])
-def test_similarity_fallback_kernels(ctx_with, switch, shape):
-    """The chain kernels' predecessors stay selectable and exact: numerator producers on the [oct][column] codes
-    (a producer lane = a column, 16-byte ring stores), and the EXEC-masked denominator kernel (one lane per
-    column), which also serves alignments whose W rows do not fit the LDS."""
-    name, value = switch.split("=")
-    m, n = shape
-    _sim_parity(ctx_with(MSA_SIM_KERNEL="chain", **{name: value}), synth_msa(m, n, 515 + m))
-
-
-@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
-def test_similarity_many_rows_few_columns(ctx_with, kernel):
-    """m = 9000, a single partial column tile."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(9000, 8, 81))
-
-
-@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
-def test_similarity_at_resident_limit(ctx_with, kernel):
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(2016, 40, 78))
+def test_similarity_beyond_32768_rows(ctx_with):
+    """40 000 sequences x 16 columns: past the 32-bit byte offsets of the W rows (m * ldw * 4 > 2^32), the lists hold row
+    indices and the kernel multiplies them out.  Against the oracle -- with W taken from the device's pair pass, as in
+    test_c3_full_size_properties: the oracle's own pair pass would take minutes here -- and against the plain
+    sequential kernel, bit for bit.  (The pair counts themselves are checked against the oracle on row slices.)"""
+    m, n = 40000, 16
+    a = synth_msa(m, n, 40000)
+    vhash, dist = oracle.aa_matrix()
+    ctx = ctx_with()
+    ctx.upload(a, ord("X"))
+    g = ctx.gaps()
+    assert np.array_equal(g, (a == ord("-")).sum(axis=0))
+    mdk, q = ctx.similarity(vhash, dist)
+    seq = ctx_with(MSA_SIM_KERNEL="seq")
+    seq.upload(a, ord("X"))
+    mdk2, q2 = seq.similarity(vhash, dist)
+    assert np.array_equal(bits(q), bits(q2)) and np.array_equal(bits(mdk), bits(mdk2))
+    seq.close()
+    _, w = ctx.identities(want_ident=False)
+    rows = np.r_[0:40, 19990:20030, 39960:40000]
+    ohit, odst = oracle.pair_counts(a[rows])
+    assert np.array_equal(bits(w[np.ix_(rows, rows)]), bits(oracle.weights(ohit, odst)))
+    omdk, oq = oracle.similarity(a, w, g, vhash, dist)
+    assert np.array_equal(bits(q), bits(oq)) and np.array_equal(bits(mdk), bits(omdk))
 
 
 def _conserved_case(m, n, seed):
@@ -546,18 +489,17 @@ def _conserved_case(m, n, seed):
     return np.ascontiguousarray(a)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("shape", [(70, 40), (200, 70), (513, 66)])
 def test_similarity_zero_and_late_sums(ctx_with, kernel, shape):
     m, n = shape
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), _conserved_case(m, n, 700 + m))
+    _sim_parity(ctx_with(**kernel), _conserved_case(m, n, 700 + m))
 
 
-@pytest.mark.parametrize("kernel", ["lg", "q2", "bx"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("letters", ["ACGT", "ABCDEFGHIKLMNOPQRSTUVWYZ", "ABCDEFGHIJKLMNOPQRSTUVWYZ"])
 def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
-    """Custom matrices over 4, 24 and 25 letters (indetermination X): the per-wave LDS tables hold alphabet + 1 rows;
-    two columns per wave serve up to 22 letters and hand larger alphabets to the one-column kernel."""
+    """Custom matrices over 4, 24 and 25 letters (indetermination X): the per-wave LDS tables hold alphabet + 1 rows."""
     r = np.random.default_rng(len(letters))
     npos = len(letters)
     sim = r.integers(-4, 9, (npos, npos)).astype(np.float32)
@@ -568,7 +510,7 @@ def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
     a[r.random(a.shape) < 0.2] = ord("-")
     a[r.random(a.shape) < 0.02] = ord("X")
     a = np.ascontiguousarray(a)
-    ctx = ctx_with(MSA_SIM_KERNEL=kernel)
+    ctx = ctx_with(**kernel)
     ctx.upload(a, ord("X"))
     og, _, _, _ = oracle.gaps(a)
     ohit, odst = oracle.pair_counts(a, ord("X"))
@@ -580,9 +522,9 @@ def test_similarity_alphabet_sizes(ctx_with, kernel, letters):
 
 @pytest.mark.parametrize("seed", [21, 22])
 def test_similarity_kernels_agree_on_random_shapes(seed):
-    """tools/cross_check.py: per-lane grids (one and two columns per wave) and the one-grid-per-round kernel against
-    the dependent-add chain kernels on random shapes and compositions (conserved, sorted, gap blocks, m = 2 .. 3000):
-    independent implementations of one bit-exact statistic must agree bit for bit."""
+    """tools/cross_check.py: the binade-exact kernel (both list formats) against the plain sequential kernel on random
+    shapes and compositions (conserved, sorted, gap blocks, m = 2 .. 3000): independent implementations of one
+    bit-exact statistic must agree bit for bit."""
     import subprocess
     import sys
 
@@ -632,7 +574,7 @@ def test_nucleotide_statistics(ctx, degenerate):
     assert err is None
 
 
-@pytest.mark.parametrize("kernel", ["", "lg", "q2", "bx", "chain"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 def test_wide_alignment_many_workgroups(ctx_with, kernel):
-    """Many more column tiles than CUs (the chain workgroups take a CU each): several waves of workgroups."""
-    _sim_parity(ctx_with(MSA_SIM_KERNEL=kernel), synth_msa(60, 40000, 4321))
+    """Many more columns than wave slots: several waves of workgroups."""
+    _sim_parity(ctx_with(**kernel), synth_msa(60, 40000, 4321))

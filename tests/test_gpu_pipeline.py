@@ -17,16 +17,16 @@ ALPHA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 
 @pytest.fixture
 def contexts(monkeypatch):
-    """(pipelined, serial, pipelined with the side stream at any size, dense pair codes at any size) contexts: the
+    """(pipelined, serial, pipelined with the side stream at any size, row-index lists at any size) contexts: the
     switches are read when a context is created"""
     made = []
     for value in ("1", "0", "3"):
         monkeypatch.setenv("MSA_PIPELINE", value)
         made.append(_lib.Context(0))
     monkeypatch.delenv("MSA_PIPELINE")
-    monkeypatch.setenv("MSA_PAIR_DENSE", "2")  # (and one with the pair pass on dense residue codes at any size)
+    monkeypatch.setenv("MSA_LG_BIG", "1")  # (and one with the similarity kernel's row-index lists at any size)
     made.append(_lib.Context(0))
-    monkeypatch.delenv("MSA_PAIR_DENSE")
+    monkeypatch.delenv("MSA_LG_BIG")
     yield made
     for c in made:
         c.close()

@@ -232,23 +232,34 @@ def test_threads_are_independent(enog_ali):
         assert_matches_oracle(t, oracle.pack(list(ali.sequences)), method="strict")
 
 
-def test_trimal_warnings_become_runtime_warnings():
-    """The `MSA_W_*` bits of `msa_trim_info.warnings` surface as `RuntimeWarning`, the category the reference
-    gives to trimAl's warnings (src/trimal/source/reportsystem.cpp:132-173)."""
+def test_trimal_warnings_become_runtime_warnings(caplog):
+    """What trimAl reports as a warning surfaces as `RuntimeWarning`, the category the reference gives to trimAl's
+    warnings (src/trimal/source/reportsystem.cpp:132-173): one per sequence removed because the trimming left it with
+    gaps only.  The library's other `MSA_W_*` bits have no trimAl counterpart: they go to the `pytrimal_amd` logger, never
+    to `warnings` (a caller running with -W error sees exactly the exceptions the reference would raise)."""
     # the only residues of the third sequence sit in a gappy column: trimming it away leaves gaps only
     ali = Alignment([b"a", b"b", b"c"], ["ACDEF-", "ACDEF-", "-----W"])
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         t = ManualTrimmer(gap_threshold=0.5, platform=PLATFORM).trim(ali)
     assert t.sequences_mask == [True, True, False]
-    assert any(issubclass(w.category, RuntimeWarning) and "only by gaps" in str(w.message) and "'c'" in str(w.message)
-               for w in caught)
-    # two sequences without a single residue: no column counts for the pair, its identity is undefined
-    ali = Alignment([b"a", b"b", b"c"], ["ACDEFGHIKLMNPQ", "--------------", "----X---------"])
+    assert [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)] == ["Removing sequence 'c' composed only by gaps"]
+    # two such sequences: two warnings, in row order
+    ali = Alignment([b"a", b"b", b"c", b"d"], ["ACDEF--", "ACDEF--", "-----W-", "------Y"])
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
+        t = ManualTrimmer(gap_threshold=0.5, platform=PLATFORM).trim(ali)
+    assert t.sequences_mask == [True, True, False, False]
+    assert [str(w.message) for w in caught] == ["Removing sequence 'c' composed only by gaps", "Removing sequence 'd' composed only by gaps"]
+    # two sequences without a single residue: no column counts for the pair, its identity is undefined
+    ali = Alignment([b"a", b"b", b"c"], ["ACDEFGHIKLMNPQ", "--------------", "----X---------"])
+    import logging
+
+    with warnings.catch_warnings(record=True) as caught, caplog.at_level(logging.INFO, logger="pytrimal_amd"):
+        warnings.simplefilter("always")
         RepresentativeTrimmer(identity_threshold=0.9, platform=PLATFORM).trim(ali)
-    assert any(issubclass(w.category, RuntimeWarning) and "identity" in str(w.message) for w in caught)
+    assert not [w for w in caught if "identity" in str(w.message)]
+    assert any("identity" in r.getMessage() for r in caplog.records)
     # and nothing is raised for an ordinary alignment
     with warnings.catch_warnings():
         warnings.simplefilter("error")

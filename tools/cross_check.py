@@ -37,10 +37,12 @@ def make(m, n):
 
 
 def run(kernel, a):
-    for k in ("MSA_SIM_KERNEL",):
+    for k in ("MSA_SIM_KERNEL", "MSA_LG_BIG"):
         os.environ.pop(k, None)
-    if kernel:
-        os.environ["MSA_SIM_KERNEL"] = kernel
+    if kernel == "seq":
+        os.environ["MSA_SIM_KERNEL"] = "seq"
+    elif kernel == "lg-big":
+        os.environ["MSA_LG_BIG"] = "1"
     ctx = _lib.Context(0)
     try:
         ctx.upload(a, ord("X"))
@@ -57,8 +59,8 @@ for i in range(cases):
     if m >= 1500:
         n = min(n, 100)
     a = make(m, n)
-    ref = run("chain" if m > 4 else "pc", a)
-    for k in ("lg", "q2", "bx"):
+    ref = run("seq", a)  # the reference's two loops, one lane per column
+    for k in ("lg", "lg-big"):
         got = run(k, a)
         ok = np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
         if not ok:

@@ -17,15 +17,15 @@ rng = np.random.default_rng(seed)
 AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a strict trim must raise where the oracle does
 
-CONTEXTS = [dict(), dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_PAIR_DENSE="2"), dict(MSA_PAIR_DENSE="0", MSA_PAIR_PIPE="0"),
-            dict(MSA_PAIR_DENSE="0", MSA_PAIR_XCD="0")]
+CONTEXTS = [dict(), dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq"),
+            dict(MSA_MDK_HOST="1", MSA_UPLOAD_DIRECT="0")]
 ctxs = []
 for env in CONTEXTS:
-    for k in ("MSA_PIPELINE", "MSA_PAIR_DENSE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD"):
+    for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctxs.append(_lib.Context(0))
-for k in ("MSA_PIPELINE", "MSA_PAIR_DENSE", "MSA_PAIR_PIPE", "MSA_PAIR_XCD"):
+for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT"):
     os.environ.pop(k, None)
 
 mx = SimilarityMatrix.aa()

@@ -1,8 +1,9 @@
 #!/bin/bash
-# round-2 profiles: bench lines, rocprofv3 kernel stats and PMC HBM traffic per workload, SQ counters of C3.
-# Output under gpurun_out/r02/; tools/summarise_profiles_r02.py turns it into profiles/r02_*.
+# profiles of a round: bench lines, rocprofv3 kernel stats and PMC HBM traffic per workload, SQ counters of C3.
+#   bash tools/gpu_profiles.sh r03     -> gpurun_out/r03/; tools/summarise_profiles.py r03 turns it into profiles/r03_*.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02
+TAG=${1:-r03}
+OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
 for w in C3 C2 C4 C5; do
@@ -23,11 +24,13 @@ timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_A
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1_C4 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload C4 > $OUT/sq1_C4.log 2>&1
 cd $ROOT
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wstream tools/ubench_wstream.hip && timeout 120 /tmp/ubench_wstream > $OUT/ubench_wstream.txt 2>&1
-timeout 300 python tools/lg_sweep.py 2>/dev/null | grep "^{" > $OUT/lg_sweep.jsonl
-for k in "" q2 bx; do MSA_SIM_KERNEL=$k timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms | sed "s/^{/{\"kernel\": \"${k:-lg}\", /"; done > $OUT/bx_stamps.jsonl
-timeout 300 python tools/pairs_time.py 2>/dev/null | grep "^{" > $OUT/pairs_time.jsonl
-for sw in MSA_PAIR_DENSE=1,0 MSA_PIPELINE=1,0; do timeout 300 python tools/step_overheads.py C3 C2 C4 C5 --switch $sw 2>/dev/null | grep "ms/step"; done > $OUT/ab_switches.txt
-bash tools/gpu_pmc_pairs.sh > $OUT/pmc_pairs.txt 2>/dev/null
+timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms > $OUT/bx_stamps.jsonl
+timeout 120 python tools/bx_stamps.py 1000 4000 2000 2>/dev/null | grep sim_ms >> $OUT/bx_stamps.jsonl
+timeout 300 python bench.py --workload REF --out $OUT/reference_shape.jsonl > $OUT/bench_REF.json 2> $OUT/bench_REF.err
+timeout 300 python tools/c5_batch.py 1 2 4 6 8 > $OUT/c5_batch.jsonl 2>/dev/null
+timeout 300 python tools/upload_time.py > $OUT/upload.txt 2>/dev/null
+timeout 600 python tools/sim_by_data.py > $OUT/sim_by_data.jsonl 2>/dev/null
+bash tools/gpu_c5_timeline.sh 4 > $OUT/c5_timeline.txt 2>/dev/null
 bash tools/gpu_timeline.sh > /dev/null 2>&1
 for w in C3 C2 C4; do cp $ROOT/gpurun_out/tl/timeline_$w.txt $OUT/ 2>/dev/null; done
 ls $OUT | head -60

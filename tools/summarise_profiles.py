@@ -1,10 +1,11 @@
-"""gpurun_out/r02 (tools/gpu_profiles_r02.sh) -> profiles/r02_*: bench lines, rocprofv3 kernel stats per workload,
+"""gpurun_out/<tag> (tools/gpu_profiles.sh <tag>) -> profiles/<tag>_*: bench lines, rocprofv3 kernel stats per workload,
 PMC HBM traffic per kernel and workload (-> profiles/traffic.json, read by bench.py as `roofline.traffic`), SQ counters."""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -24,13 +25,12 @@ def counters(d):
 
 
 family = {  # kernel -> the name bench.py's roofline uses
-    "msak::similarity_bx_kernel": "sim", "msak::similarity_lg_kernel": "sim", "msak::similarity_lg_regs_kernel": "sim",
-    "msak::similarity_lg2_kernel": "sim", "msak::lg2_union_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::pair_counts_pipe_kernel": "pairs",
-    "msak::pair_counts_dense_kernel": "pairs", "msak::gap_counts_kernel": "gaps",
+    "msak::similarity_lg_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::pair_counts_pipe_kernel": "pairs",
+    "msak::gap_counts_kernel": "gaps",
     "msak::prep_planes_kernel": "prep", "msak::identity_rows_kernel": "idstats", "msak::sim_encode_cm_kernel": "encode",
     "msak::bx_compact_kernel": "encode", "msak::cluster_mis_kernel": "cluster", "msak::cluster_adjacency_kernel": "cluster",
 }
-traffic = {"_source": "profiles/r02_pmc_hbm_traffic.txt (builder PMC passes of tools/gpu_profiles_r02.sh, not measured in the bench run)",
+traffic = {"_source": "profiles/" + TAG + "_pmc_hbm_traffic.txt (builder PMC passes of tools/gpu_profiles.sh, not measured in the bench run)",
            "_note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch (gfx950: FETCH_SIZE counts half of the bytes of wide "
                     "coalesced reads, MI355X_MICROARCH.md); Infinity-Cache hits are counted by these counters"}
 lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over python3 bench.py --workload W",
@@ -52,18 +52,18 @@ for w in ("C3", "C2", "C4", "C5"):
             fam[family[k]] += b
     for name, b in fam.items():
         traffic[f"{w}:{name}"] = int(b)
-open(os.path.join(DST, "r02_pmc_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(DST, TAG + "_pmc_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 
 for w in ("C3", "C2", "C4", "C5"):
     files = glob.glob(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv"))
     if files:
-        shutil.copy(files[0], os.path.join(DST, f"r02_rocprofv3_kernel_stats_{w.lower()}.csv"))
+        shutil.copy(files[0], os.path.join(DST, f"{TAG}_rocprofv3_kernel_stats_{w.lower()}.csv"))
     b = os.path.join(SRC, f"bench_{w}.json")
     if os.path.exists(b):
         last = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
         if last:
-            open(os.path.join(DST, f"r02_bench_{w.lower()}.json"), "w").write(last[-1] + "\n")
+            open(os.path.join(DST, f"{TAG}_bench_{w.lower()}.json"), "w").write(last[-1] + "\n")
 
 out = ["# rocprofv3 --pmc <SQ / GRBM counters> --kernel-trace over python3 bench.py --steps 3 --warmup 1; averages per dispatch.",
        "# SQ_* cycle counters count quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs:",
@@ -91,13 +91,13 @@ for tag, dirs in (("C3", ("sq1_C3", "sq2_C3", "sq3_C3")), ("C4", ("sq1_C4",))):
             cyc = vals["GRBM_GUI_ACTIVE"] / 8
             out.append(f"    -> texture addresser busy {vals['TA_TA_BUSY_sum'] / 256 / cyc:.2f} of the kernel (sum over 256 CUs), "
                        f"texture data {vals.get('TD_TD_BUSY_sum', 0) / 256 / cyc:.2f}, LDS {vals.get('SQ_LDS_IDX_ACTIVE', 0) / 256 / cyc:.2f}")
-open(os.path.join(DST, "r02_pmc_sq.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(DST, TAG + "_pmc_sq.txt"), "w").write("\n".join(out) + "\n")
 ub = os.path.join(SRC, "ubench_wstream.txt")
 if os.path.exists(ub):
-    shutil.copy(ub, os.path.join(DST, "r02_ubench_wstream.txt"))
-for name in ("lg_sweep.jsonl", "bx_stamps.jsonl", "pairs_time.jsonl", "ab_switches.txt", "pmc_pairs.txt", "timeline_C3.txt",
-             "timeline_C2.txt", "timeline_C4.txt"):
+    shutil.copy(ub, os.path.join(DST, TAG + "_ubench_wstream.txt"))
+for name in ("bx_stamps.jsonl", "ab_switches.txt", "timeline_C3.txt", "timeline_C2.txt", "timeline_C4.txt", "reference_shape.jsonl",
+             "c5_batch.jsonl", "upload.txt", "sim_by_data.jsonl", "c5_timeline.txt", "bench_REF.json"):
     if os.path.exists(os.path.join(SRC, name)):
-        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r02_" + name))
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 print("\n".join(lines[-40:]))
 print("\n".join(out))
