@@ -128,9 +128,7 @@ struct msa_ctx {
     DevBuf<float> wlow;        // strictly lower triangular mirror of wmat (binade-exact similarity kernel)
     DevBuf<float> wbar;        // mean weight of every row over its later partners (that kernel's predictor)
     DevBuf<uint8_t> codeT;     // column-major similarity codes of that kernel
-    DevBuf<uint32_t> bx_off;   // ... and the compacted lists of every column's valid rows: W row offset,
-    DevBuf<uint16_t> bx_row;   //     row index,
-    DevBuf<uint8_t> bx_code;   //     code,
+    DevBuf<uint32_t> bx_off;   // ... and the compacted lists of every column's valid rows: W row offset (or index),
     DevBuf<uint16_t> bx_trow;  //     byte offset of the residue's row in a [row][64 lanes] float table
     DevBuf<int32_t> bx_nvalid;
     DevBuf<int32_t> simcols;   // the columns that kernel evaluates (those the 80 % gap rule does not zero), sorted by gap count
@@ -599,14 +597,12 @@ int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t s
     const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
     HIPCHK(c, c->codeT.reserve(lsz));
     HIPCHK(c, c->bx_off.reserve(lsz));
-    HIPCHK(c, c->bx_row.reserve(lsz));
-    HIPCHK(c, c->bx_code.reserve(lsz));
     HIPCHK(c, c->bx_trow.reserve(lsz));
     HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
     {
         ProfScope pe(c, "encode", st);
         msak::launch_sim_encode_cm(st, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
-        msak::launch_bx_compact(st, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, c->bx_nvalid.p);
+        msak::launch_bx_compact(st, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_trow.p, c->bx_nvalid.p);
     }
     HIPCHK(c, hipGetLastError());
     return MSA_OK;
@@ -630,7 +626,7 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
         const int e = c->tuning.sim_kernel == 1
                           ? msak::launch_similarity_seq(c->stream, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wmat.p, c->ldw, c->tab.p,
                                                         c->simnum.p, c->simden.p)
-                          : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_row.p, c->bx_code.p, c->bx_trow.p, npos,
+                          : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_trow.p, npos,
                                                        c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wlow.p, c->wmat.p,
                                                        c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate, c->wbar.p);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
@@ -1171,7 +1167,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_row.release(); c->bx_code.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->gaps_w.release();
     c->mdk.release(); c->simnum.release(); c->simden.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();

@@ -42,12 +42,11 @@ size_t bx_wlow_rows(int m);
 bool lg_big(int m, int ldw);  // the lists hold row indices instead of 32-bit byte offsets (beyond 32768 rows)
 void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
                           const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key);
-void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vrow,
-                       uint8_t *vcode, uint16_t *vtrow, int32_t *nvalid);
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vtrow,
+                       int32_t *nvalid);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr, int *gate = nullptr);
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
-                         int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
                          const int *gate, const float *wbar);
 void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar);

@@ -114,23 +114,16 @@ __device__ __forceinline__ float block_step(float s, float x) {
     return s;
 }
 
-// The valid rows of one column, compacted (bx_compact_kernel): entry t is the t-th row whose residue takes part.
+// One column as the kernels see it.
 struct ColView {
-    const __attribute__((address_space(1))) uint32_t *off;  // byte offset of that row in W (row * ldw * 4); padding: a zero row
-    const __attribute__((address_space(1))) uint16_t *row;  // its row index; padding: m
-    gu8p code;                                               // its code (8 x table row); padding: BX_SKIP
-    int nvalid;
-    gu8p colcode;                                            // the column's codes by row (codeT), BX_SKIP for a row that takes no part
+    const __attribute__((address_space(1))) uint32_t *off;  // compacted list of its valid rows (bx_compact_kernel): byte offset of the row
+                                                             // in W (row * ldw * 4), or the row index (`big` lists); padding: the zero row m
+    int nvalid;                                              // entries of that list
+    gu8p colcode;  // the column's codes by row (codeT): 8 x table row, BX_SKIP for a row that takes no part and behind row m
     int ldw;
-    int lastpad;  // the last entry of the lists (padding)
-    int big;      // `off` holds row INDICES (any m) instead of byte offsets, and `row` (16 bits) is not used
+    int m;
 };
 
-// Row j of one column in the reference's order: its partners are the valid rows behind it, i.e. the entries
-// tfirst .. nvalid-1 of the compacted list (tfirst = number of valid rows <= j), 64 per block (lane = partner).
-// s = {numerator sum, denominator sum}; `which` selects the sums to advance.
-// (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
-// loop counters look divergent to the compiler.)
 // 256 consecutive terms (x[i]: term 64 i + lane) added to s in order: one test for all of them, else block by block
 __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
     float B, u;
@@ -154,39 +147,38 @@ __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
     return s;
 }
 
-__device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int tfirst, int which, f2 s) {
+// Row j of one column in the reference's order: its partners are the rows k > j, 64 per block (lane = partner), 256 per
+// chunk.  Dense: EVERY row behind j is read -- W[j][k] from the row-major upper triangle (coalesced), the column's code
+// of row k (coalesced bytes) -- and a row that takes no part contributes W x 0 = 0, which changes no float32 sum; the
+// rows up to j inside the first block read the zeros of the lower triangle, the codes behind row m are BX_SKIP.  No
+// list, hence no load that depends on another: the loads of a chunk are issued while the chunk before it is added up
+// (with the compacted lists of round 2 every chunk waited for a gather through entries it had to load first, under a
+// vector-memory pipeline that the round loops of the other waves keep saturated: 20 000 cycles per ordered row).
+// s = {numerator sum, denominator sum}; `which` selects the sums to advance.
+// (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
+// loop counters look divergent to the compiler.)
+__device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int which, f2 s) {
     const int lane = threadIdx.x & 63;
     const uint32_t cj = cv.colcode[j];
     if (uni((int)cj) == (int)BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
-    // Chunks of four blocks (256 terms).  Entries behind the lists' padding are clamped onto its last entry.
-    auto entries = [&](int t, uint32_t(&k)[4], uint32_t(&c)[4]) {
+    auto request = [&](int kb, float(&w)[4], uint32_t(&c)[4]) {  // (reads at most 255 entries past row m: W's slack, the code padding)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = min(t + 64 * i + lane, cv.lastpad);
-            k[i] = cv.big ? cv.off[e] : (uint32_t)cv.row[e];
-            c[i] = cv.code[e];
+            w[i] = wr[kb + 64 * i + lane];
+            c[i] = cv.colcode[kb + 64 * i + lane];
         }
     };
-    auto values = [&](const uint32_t(&k)[4], const uint32_t(&c)[4], float(&w)[4], f2(&de)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            w[i] = wr[k[i]];  // wup[j][k]; whatever lies at column m is multiplied by a skipped code's zeros
-            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
-        }
-    };
-    // (list entries a chunk ahead; the W gather and the table gather of a chunk are issued together.  A deeper
-    // pipeline -- values a chunk ahead as well -- measured no faster: what an ordered row waits for is its turn to
-    // issue, which is why the callers raise the wave priority, and it costs 32 registers)
-    uint32_t k[4], c[4];
-    int tb = tfirst;
-    entries(tb, k, c);
-    for (; tb < cv.nvalid; tb += 256) {
-        float w[4];
+    float w[4], wn[4];
+    uint32_t c[4], cn[4];
+    int kb = (j + 1) & ~63;
+    request(kb, w, c);
+    for (; kb < cv.m; kb += 256) {
+        request(kb + 256 < cv.m ? kb + 256 : kb, wn, cn);  // the next chunk (a repeat behind the last: not used)
         f2 de[4];
-        values(k, c, w, de);
-        entries(tb + 256, k, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
         if (which & 1) {
             const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
             s0 = chunk_step(s0, x);
@@ -194,6 +186,11 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int
         if (which & 2) {
             const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
             s1 = chunk_step(s1, x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w[i] = wn[i];
+            c[i] = cn[i];
         }
     }
     return f2{s0, s1};
@@ -260,16 +257,14 @@ struct ResolvedLg {
     unsigned long long t_ordered;  // STAMP: cycles spent in the ordered rows
 };
 template <bool STAMP>
-__device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, int tbase, unsigned long long vall,
-                                              unsigned long long vmask, int kind, float s, float Bl, float ie, float io) {
+__device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, unsigned long long vmask, int kind, float s,
+                                                 float Bl, float ie, float io) {
     const int lane = threadIdx.x & 63;
-    // (row j0 + x: its partners start at entry tbase + (valid rows of the round up to and including x))
-    auto tfirst = [&](int x) { return tbase + __builtin_popcountll(vall & ((2ull << x) - 1ull)); };
     unsigned long long t_ordered = 0;
     auto ordered_row = [&](int x, float from) {
         unsigned long long t0 = 0;
         if (STAMP) t0 = __builtin_readcyclecounter();
-        const f2 r = exact_row(cv, wup, tab, j0 + x, tfirst(x), kind ? 2 : 1, f2{from, from});
+        const f2 r = exact_row(cv, wup, tab, j0 + x, kind ? 2 : 1, f2{from, from});
         const float v = unif(kind ? r.y : r.x);
         if (STAMP) t_ordered += __builtin_readcyclecounter() - t0;
         return v;
@@ -439,8 +434,8 @@ constexpr int LG_WAVES_MAX = 8;  // waves per workgroup (they share the distance
 // 64 KB: M0 holds 16 bits).
 template <bool STAMP, bool BIG>
 __device__ __forceinline__ void similarity_lg_body(
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,
-    const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_,
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid,
+    const uint8_t *__restrict__ codeT_,
     int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,
     const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
     float *__restrict__ num_out, float *__restrict__ den_out, const float *__restrict__ wbar) {
@@ -464,13 +459,10 @@ __device__ __forceinline__ void similarity_lg_body(
     const int col = uni(cols[ci]);
     ColView cv;
     cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
-    cv.row = uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vrow_ + (size_t)col * ldk);
-    cv.code = uniform_ptr((gu8p)(uint64_t)vcode_ + (size_t)col * ldk);
     cv.nvalid = uni(nvalid[col]);
     cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
     cv.ldw = ldw_;
-    cv.lastpad = (int)ldk - 1;
-    cv.big = BIG ? 1 : 0;
+    cv.m = m;
     const __attribute__((address_space(1))) uint16_t *vtrow =
         uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
     const int nv = cv.nvalid;
@@ -481,7 +473,10 @@ __device__ __forceinline__ void similarity_lg_body(
     }
     __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
     // the column's residue frequencies -> G
-    for (int t = lane; t < nv; t += 64) atomicAdd(&hist[wave][cv.code[t] >> 3], 1u);
+    for (int k = lane; k < m; k += 64) {
+        const uint32_t ck = cv.colcode[k];
+        if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (lane < 32) {
         float g = 0.0f;
@@ -495,6 +490,10 @@ __device__ __forceinline__ void similarity_lg_body(
     float qn0 = 0.0f, qd0 = 0.0f;
     int jstart = 0, tb = 0;
     {
+        // (the rows in front of the first one that takes part need nothing: skipped 64 at a time -- a column whose first
+        // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
+        for (; jstart + 64 < m - 1; jstart += 64)
+            if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
         bool seen = false;
         while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
             const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
@@ -504,7 +503,7 @@ __device__ __forceinline__ void similarity_lg_body(
                 const float rem = (float)(nv - tb) * unif(wbar[jstart]);
                 qd0 += rem;
                 qn0 += rem * gtab[wave][cj >> 3];
-                s2 = exact_row(cv, wup, tabp, jstart, tb, 3, s2);
+                s2 = exact_row(cv, wup, tabp, jstart, 3, s2);
             }
             ++jstart;
         }
@@ -572,8 +571,8 @@ __device__ __forceinline__ void similarity_lg_body(
         // the SIMD's other waves (which are bound by the W stream, not by issue): it runs at the highest wave priority.
         __builtin_amdgcn_s_setprio(3);
         // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
-        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
-        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, tbase, vall, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
+        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
+        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
                                          takes ? ad.y - (Bd + Bd * 0x1p-23f) : 0.0f);
         const float sn1 = unif(rn.s), sd1 = unif(rd.s);
         if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);
@@ -621,12 +620,12 @@ __device__ __forceinline__ void similarity_lg_body(
 // Compiled for five waves per SIMD (the LDS allocation admits 20 waves per CU for a 20-letter alphabet).  Two
 // instantiations: 32-bit byte offsets in the lists, or row indices (BIG, m > 32768).
 #define LG_PARAMS                                                                                                      \
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vrow_, const uint8_t *__restrict__ vcode_,      \
-        const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, const uint8_t *__restrict__ codeT_, \
+    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, \
+        const uint8_t *__restrict__ codeT_,                                                                          \
         int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
         const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
         float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate, const float *__restrict__ wbar
-#define LG_ARGS voff_, vrow_, vcode_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar
+#define LG_ARGS voff_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar
 template <bool STAMP, bool BIG>
 __global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
     // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
@@ -768,19 +767,18 @@ __global__ __launch_bounds__(128) void identity_final_kernel(const float *__rest
     }
 }
 
-// codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W,
-// row index, code; padded behind the last valid row by >= 192 entries of {zero row m, row m, skipped}.
+// codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W (or its
+// index: `big`) and byte offset of its residue's row in the per-wave table; padded behind the last valid row with
+// {zero row m, the table's zero row}.  6 bytes per residue (round 2 also kept the row index and the code for the
+// ordered rows, which now read the column densely: 9 bytes).
 __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
-                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vrow,
-                                                         uint8_t *__restrict__ vcode, uint16_t *__restrict__ vtrow, int skiprow,
-                                                         int32_t *__restrict__ nvalid, int big) {
+                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
+                                                         int skiprow, int32_t *__restrict__ nvalid, int big) {
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= ncols_pad) return;
     const uint8_t *src = codeT + (size_t)col * ldk;
     uint32_t *po = voff + (size_t)col * ldk;
-    uint16_t *pr = vrow + (size_t)col * ldk;
-    uint8_t *pc = vcode + (size_t)col * ldk;
     uint16_t *pt = vtrow + (size_t)col * ldk;  // byte offset of the residue's row in a [row][64 lanes] float table
     int count = 0;
     for (int kb = 0; kb < m; kb += 64) {
@@ -790,16 +788,12 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
         if (code != BX_SKIP) {
             const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
             po[pos] = big ? (uint32_t)k : (uint32_t)k * ldw4;  // (big: the row index; the kernel multiplies it out)
-            pr[pos] = (uint16_t)k;
-            pc[pos] = (uint8_t)code;
             pt[pos] = (uint16_t)((code >> 3) * 256u);
         }
         count += __builtin_popcountll(mask);
     }
     for (int64_t t = count + lane; t < ldk; t += 64) {
         po[t] = big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
-        pr[t] = (uint16_t)m;                              // column m of W: zeros
-        pc[t] = (uint8_t)BX_SKIP;
         pt[t] = (uint16_t)(skiprow * 256);  // the table's zero row
     }
     if (lane == 0) nvalid[col] = count;
@@ -862,17 +856,16 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
 // the lists hold 32-bit byte offsets of the W rows while those fit (row m included); beyond that, row indices
 bool lg_big(int m, int ldw) { return tuning().lg_big != 0 || ((uint64_t)m + 2) * (uint64_t)ldw * 4u > 0xFFFFFFFFull; }
 
-void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vrow,
-                       uint8_t *vcode, uint16_t *vtrow, int32_t *nvalid) {
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vtrow,
+                       int32_t *nvalid) {
     const int ncp = bx_cols_pad(n);
-    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vrow, vcode, vtrow, npos, nvalid,
+    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vtrow, npos, nvalid,
                                                     lg_big(m, ldw) ? 1 : 0);
 }
 
 // cols: the columns to evaluate (device, ncols entries; pad with the index n, the all-skipped column); the sums of every
 // other column are left alone.  Any number of rows (see lg_big).
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vrow, const uint8_t *vcode, const uint16_t *vtrow,
-                         int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
+int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
                          const int *gate, const float *wbar) {
     const int64_t ldk = bx_ldk(m);
@@ -890,7 +883,7 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vr
     do {                                                                                                               \
         const int e = set_max_lds_once((const void *)KERNEL, (int)dyn);                                                \
         if (e) return e;                                                                                               \
-        KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vrow, vcode, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
+        KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
                                              t, num_out, den_out, gate, wbar);                                        \
     } while (0)
     if (stamp && big) LG_LAUNCH((similarity_lg_kernel<true, true>));
