@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
 for w in C3 C2 C4 C5; do
-  timeout 900 python bench.py --steps 10 --warmup 2 --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w rc=$?"
+  timeout 900 python bench.py --steps 20 --warmup 3 --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w rc=$?"
 done
 export TMPDIR=/tmp
 cd /tmp
@@ -24,6 +24,7 @@ timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_A
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1_C4 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload C4 > $OUT/sq1_C4.log 2>&1
 cd $ROOT
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wstream tools/ubench_wstream.hip && timeout 120 /tmp/ubench_wstream > $OUT/ubench_wstream.txt 2>&1
+for sw in MSA_PIPELINE=1,0 MSA_UPLOAD_DIRECT=1,0; do timeout 300 python tools/step_overheads.py C3 C2 C4 C5 --switch $sw 2>/dev/null | grep "ms/step"; done > $OUT/ab_switches.txt
 timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms > $OUT/bx_stamps.jsonl
 timeout 120 python tools/bx_stamps.py 1000 4000 2000 2>/dev/null | grep sim_ms >> $OUT/bx_stamps.jsonl
 timeout 300 python bench.py --workload REF --out $OUT/reference_shape.jsonl > $OUT/bench_REF.json 2> $OUT/bench_REF.err
