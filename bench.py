@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
 # the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane loads of L2-resident rows, measured with
-# tools/ubench_wstream.hip on an MI355X (profiles/r02_ubench_wstream.txt): global_load_dword 29 - 30 TB/s chip-wide
+# tools/ubench_wstream.hip on an MI355X (profiles/r03_ubench_wstream.txt): global_load_dword 29 - 30 TB/s chip-wide
 # (5.3 CU-cycles per wave-load at the nominal clock; buffer_load_dword with an SGPR row offset: 18.3 TB/s, 8.6 cycles)
 W_STREAM_PEAK_GBS = 29700.0
 
@@ -282,7 +282,8 @@ def main():
                     help="default: C3 (the headline) at one GPU, C5 (BASELINE config 5, strong scaling) with --gpus N > 1")
     ap.add_argument("--out", default=None, help="REF: also write the four result lines to this file (JSON lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cols", type=int, default=4000)
+    ap.add_argument("--cpu-sample-cols", type=int, default=10000,
+                    help="columns of the workload's alignment the CPU baseline is timed on (default: all of them at C3: ~7 s per flavour)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.workload is None:
@@ -460,7 +461,8 @@ def main():
         fence()
         resident_s = max_over_ranks(time.perf_counter() - t0)
         # ... and through the public API: Alignment -> trimmer.trim -> TrimmedAlignment (its own per-thread context)
-        api_masks = step_public_api()
+        step_public_api()
+        api_masks = step_public_api()  # (the alignment's rows are page-locked on its second trim: once, outside the timed steps)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -503,10 +505,10 @@ def main():
                 rate = wbytes / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
                 roofline["w_stream"] = {
                     "bound": "vector-memory pipeline (L1/TA), 256-byte global_load_dword wave-loads of L2-resident W rows "
-                             "(texture addresser 92 % busy at the clock the kernel runs at: profiles/r02_pmc_sq.txt)",
+                             "(texture addresser 92 % busy at the clock the kernel runs at: profiles/r03_pmc_sq.txt)",
                     "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
-                    "peak_source": "tools/ubench_wstream.hip on one MI355X (profiles/r02_ubench_wstream.txt), not measured in this run",
+                    "peak_source": "tools/ubench_wstream.hip on one MI355X (profiles/r03_ubench_wstream.txt), not measured in this run",
                 }
             if dom in ("sim", "pairs"):
                 # the pairwise passes are VALU-issue work, not bandwidth: one "pair-column" = one (j, k, column) term
@@ -519,9 +521,8 @@ def main():
                              "grids, DESIGN.md section 5): three VALU instructions, one LDS row and one 256-byte W row per 64 "
                              "(row, partner) terms; bound by the W stream through the vector-memory pipeline (roofline.w_stream), "
                              "HBM is irrelevant (the path moves tens of MB)") if dom == "sim" else
-                            "bit-sliced compare / popcount over 32 columns per word on dense residue codes (5 code planes for up "
-                            "to 31 symbols: 8 VALU instructions per pair and word, 11 on the raw seven planes below 1500 "
-                            "sequences): VALU issue (82 % busy at 5000 x 5000, profiles/r02_pmc_pairs.txt), not bandwidth",
+                            "bit-sliced compare / popcount over 32 columns per word on the seven symbol planes + validity: 11 VALU "
+                            "instructions per pair and word; VALU issue (86 % busy at 5000 x 5000, profiles/r03_pmc_sq.txt), not bandwidth",
                 }
         roofline_all = {}
         for kname, kv in kernels.items():

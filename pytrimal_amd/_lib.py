@@ -206,7 +206,8 @@ def pin_array(a):
         _pinned.pop(key, None)
         lib.msa_host_unregister(ctypes.c_void_p(address))
 
-    _pinned[id(a)] = weakref.finalize(a, release)  # runs when the array is collected, before numpy frees the buffer
+    fin = _pinned[id(a)] = weakref.finalize(a, release)  # runs when the array is collected, before numpy frees the buffer
+    fin.atexit = False  # (at interpreter exit the process's mappings go away by themselves: no calls into a runtime that is shutting down)
     return True
 
 
