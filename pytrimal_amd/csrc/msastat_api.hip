@@ -1220,6 +1220,16 @@ class PackPool {
         }
         cv_.notify_all();
     }
+    // the job is packed: drop it if no helper has yet (a helper pops an exhausted job only when it next looks at the queue;
+    // in a forked child there are no helpers at all)
+    void retire(const std::shared_ptr<PackJob> &job) {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+            if (it->get() == job.get()) {
+                jobs_.erase(it);
+                break;
+            }
+    }
     int helpers() const { return (int)threads_.size(); }
 
   private:
@@ -1316,6 +1326,7 @@ int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
         }
         if (rc == MSA_OK) rc = send_piece(p);  // (after an error: keep draining, the helpers still write into h_raw)
     }
+    pool.retire(job);
     return rc;
 }
 }  // namespace

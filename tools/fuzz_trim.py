@@ -1,5 +1,6 @@
 """Randomised whole-trim check: random shapes, compositions, alphabets and trimmer settings through msa_trim (contexts under
-the default switches, the serial flow, the side stream at any size, dense pair codes at any size, the raw pair loops) against
+the default switches, the serial flow, the side stream at any size, row-index lists, the sequential similarity kernel, host
+exponentials + packed uploads) against
 the oracle's trim -- masks, selected method, identity means, cut points.
   python tools/fuzz_trim.py [seconds=120] [seed=1]      (prints one JSON line; exit code 1 on the first mismatch)"""
 import ctypes, json, os, sys, time
