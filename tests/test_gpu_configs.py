@@ -153,6 +153,26 @@ def test_native_batch_equals_one_by_one():
         assert [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)] == ["Removing sequence 'x' composed only by gaps"]
 
 
+def test_two_ranks_share_one_gpu():
+    """`trim_batch` under a two-rank process group, both ranks on this box's one GPU (gloo carries the gather: RCCL needs
+    a GPU per rank): the sharding over ranks, a native batch object per rank and the gather of the masks, against the
+    same trims in a single process."""
+    import json
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tests", "measure", "two_rank_batch.py")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["ranks"] == 2 and rec["alignments"] == 7 and rec["equal_to_single_process"] is True
+
+
 def test_batch_module_in_a_fresh_process():
     """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
     package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`
