@@ -412,7 +412,8 @@ def main():
         def step_host_rows():
             # host rows -> device: the rows are page-locked on the first call (msa_host_register, once per array: the same
             # alignment is trimmed step after step), every upload is then one pitched DMA copy from where they lie
-            ctx.upload(a, ord("X"), pin=True)
+            # ... enqueued without a wait of its own: the trim behind it waits for the stream once (`a` outlives the step)
+            ctx.upload(a, ord("X"), pin=True, wait=False)
             keep_res, keep_seq, info = ctx.trim(params)
             finish(keep_res)
             return keep_res, keep_seq, info

@@ -37,7 +37,7 @@ METHOD_CODES = {
 # every symbol include/msastat.h declares (tests check the library exports all of them)
 EXPORTS = [
     "msa_strerror", "msa_device_count", "msa_last_hip_error", "msa_ctx_create", "msa_ctx_destroy",
-    "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_host_register", "msa_host_unregister", "msa_attach_device",
+    "msa_ctx_stream", "msa_ctx_sync", "msa_upload_rows", "msa_upload_packed", "msa_upload_packed_async", "msa_host_register", "msa_host_unregister", "msa_attach_device",
     "msa_gaps", "msa_gaps_cached", "msa_pair_counts", "msa_identities", "msa_identity_stats", "msa_similarity",
     "msa_overlap", "msa_window_i32", "msa_window_f32", "msa_gaps_cutpoint",
     "msa_gaps_cutpoint_2nd_slope", "msa_similarity_cutpoint", "msa_clean_gaps",
@@ -125,6 +125,7 @@ def load():
         L.msa_upload_packed.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
         L.msa_host_register.argtypes = [vp, ctypes.c_size_t]
         L.msa_host_unregister.argtypes = [vp]
+        L.msa_upload_packed_async.argtypes = L.msa_upload_packed.argtypes
         L.msa_attach_device.argtypes = [vp, vp, i32, i32, ctypes.c_int64, ctypes.c_uint8]
         L.msa_gaps.argtypes = [vp, vp, vp]
         L.msa_gaps_cached.argtypes = [vp, i32, vp]
@@ -268,14 +269,20 @@ class Context:
             pass
 
     # --- uploads ---
-    def upload(self, matrix, indet, pin=False):
+    def upload(self, matrix, indet, pin=False, wait=True):
         """`pin`: page-lock the rows first (once per array object; kept until the array dies) -- for rows that are
-        uploaded again and again."""
+        uploaded again and again.  `wait=False`: do not wait for the copy -- the caller keeps `matrix` alive and unchanged
+        until the next call that returns results (`trim`, `gaps`, ...); the array is remembered here until then."""
         a = np.ascontiguousarray(matrix, dtype=np.uint8)
         if pin and a is matrix:
             pin_array(a)
         m, n = a.shape
-        check(self.lib, self.h, self.lib.msa_upload_packed(self.h, ptr(a), m, n, n, indet))
+        if wait:
+            check(self.lib, self.h, self.lib.msa_upload_packed(self.h, ptr(a), m, n, n, indet))
+            self._in_flight = None
+        else:
+            check(self.lib, self.h, self.lib.msa_upload_packed_async(self.h, ptr(a), m, n, n, indet))
+            self._in_flight = a  # (a reference: the rows cannot be freed under the copy)
         self.shape = (m, n)
 
     def upload_rows(self, rows, indet):
@@ -356,6 +363,7 @@ class Context:
         keep_seq = np.ones(m, dtype=np.uint8)
         info = TrimInfo()
         rc = self.lib.msa_trim(self.h, ctypes.byref(params), ptr(keep_res), ptr(keep_seq), ctypes.byref(info))
+        self._in_flight = None  # (msa_trim waited for the stream, error or not)
         check(self.lib, self.h, rc, info.err)
         return keep_res.astype(bool), keep_seq.astype(bool), info
 

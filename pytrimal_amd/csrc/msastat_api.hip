@@ -1401,6 +1401,10 @@ int msa_upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n,
     return upload_packed(c, rowmajor, m, n, ld, indet, true);
 }
 
+int msa_upload_packed_async(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet) {
+    return upload_packed(c, rowmajor, m, n, ld, indet, false);
+}
+
 int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n, uint8_t indet) {
     if (!c || (!rows && m > 0) || m < 0 || n < 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1531,8 +1535,20 @@ struct TrimTrace {
 };
 }  // namespace
 
+static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info);
+
 int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
+    const int rc = trim_impl(c, p, keep_res, keep_seq, info);
+    if (rc != MSA_OK) {
+        // an error return is a return with nothing in flight as well (an upload enqueued by msa_upload_packed_async included)
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    return rc;
+}
+
+static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     HIPCHK(c, hipSetDevice(c->device));
     TrimTrace trace(c->tuning.trace != 0);
     TuneScope tune(c);

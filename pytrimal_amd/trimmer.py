@@ -182,7 +182,7 @@ class BaseTrimmer:
         if m == 0 or n == 0:
             return self._finish(names, dense, alignment._datatype, np.ones(n, dtype=bool), np.ones(m, dtype=bool), None, None, None, params)
         ctx = _lib.thread_context()
-        ctx.upload(dense, indet)
+        ctx.upload(dense, indet, wait=False)  # (`dense` lives until the trim has waited for the stream)
         keep_res, keep_seq, info = ctx.trim(params)
         rows = ctx.only_gaps_rows() if info.warnings & _lib.W_ONLY_GAPS_SEQUENCES else None
         hw = max(params.window if params.window != -1 else params.gap_window, 0)
