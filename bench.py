@@ -90,7 +90,7 @@ def algorithmic_bytes(kernel, m, n):
 def launch_ranks(args):
     """--gpus N without a launcher: become the launcher.  Nothing here may touch a GPU (no HIP call, no
     torch.cuda.is_available(); counting devices does not initialise them on this image)."""
-    if not args.launch_check:
+    if not args.launch_check and not args.share_gpu:
         import torch
 
         ndev = torch.cuda.device_count()
@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--cpu-sample-cols", type=int, default=10000,
                     help="columns of the workload's alignment the CPU baseline is timed on (default: all of them at C3: ~7 s per flavour)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: every rank on GPU 0, process group over gloo (RCCL needs a GPU per rank) -- runs the whole "
+                         "multi-rank code path on a one-GPU box; the line it prints is marked and is not a multi-GPU measurement")
     args = ap.parse_args()
     if args.workload is None:
         # BASELINE.json's multi-GPU config is the batch of 64 (config 5): that is what a scaling run measures unless told otherwise
@@ -307,13 +310,19 @@ def main():
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
+        os.environ["PYTRIMAL_AMD_DEVICE"] = "0"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun even a 1-rank job uses RCCL
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     if args.workload == "REF":
         if world > 1:
@@ -351,13 +360,13 @@ def main():
     def max_over_ranks(seconds):
         if dist is None:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     ctx = _lib.Context(local_rank)
     params = params_for(args.workload)
-    kernels, resident_s, public_api_s, info, units_per_step = {}, None, None, None, None
+    kernels, resident_s, public_api_s, info, units_per_step, single_gpu_s = {}, None, None, None, None, None
 
     if args.workload == "C5":
         from pytrimal_amd.batch import trim_batch
@@ -370,7 +379,7 @@ def main():
         units_per_step = C5_BATCH * n  # the whole batch, however many ranks share it: strong scaling
 
         def step():
-            return trim_batch(trimmer, alis, device=device, threads=4)
+            return trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4)
 
         for _ in range(args.warmup):
             step()
@@ -380,6 +389,17 @@ def main():
             out = step()
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        # the same batch on ONE GPU (rank 0 alone, the others wait): the strong-scaling reference, so that a line of an
+        # N-GPU run carries the 1-GPU number of the very same workload beside its own
+        single_gpu_s = None
+        if world > 1:
+            if rank == 0:
+                trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, shard=False)
+                t0 = time.perf_counter()
+                for _ in range(max(1, min(args.steps, 5))):
+                    trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, shard=False)
+                single_gpu_s = (time.perf_counter() - t0) / max(1, min(args.steps, 5))
+            fence()
         # kernel times of one alignment of the batch (profiled separately: the batch runs on per-thread contexts)
         a = synth_msa(m, n, seed + rank)
         ctx.prof_enable(True)
@@ -394,12 +414,13 @@ def main():
         dev = torch.zeros((m, ld), dtype=torch.uint8, device=device)
         dev[:, :n] = torch.from_numpy(a).to(device)
         torch.cuda.synchronize()
-        gathered = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+        cdev = "cpu" if args.share_gpu else device  # where the collectives' tensors live
+        gathered = [torch.empty(n, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
         units_per_step = world * n  # one alignment per rank per step: weak scaling
 
         def finish(keep_res):
             if dist is not None:
-                mask = torch.from_numpy(keep_res.view(np.uint8)).to(device)
+                mask = torch.from_numpy(keep_res.view(np.uint8)).to(cdev)
                 dist.gather(mask, gathered, dst=0)
 
         def step():
@@ -538,7 +559,7 @@ def main():
             workload = (f"{trimmer_repr} on synthetic {m} seq x {n} col protein MSA ({args.workload}, seed {seed}+rank), one "
                         f"alignment per GPU per step, every step from host rows (pack + H2D, kernels, D2H, host selection) to masks")
         out = {
-            "metric": "MSA columns/s (gap+similarity+identity)",
+            "metric": "MSA columns/s (gap+similarity+identity)" + (" [--share-gpu: all ranks on ONE GPU over gloo, a code-path test]" if args.share_gpu else ""),
             "value": round(value, 2),
             "unit": "columns/s",
             "n_gpus": world,
@@ -565,6 +586,10 @@ def main():
             "kernels_ms_source": ("HIP events: pairs and sim over the timed (host-rows) region, the other kernels over 5 untimed steps after it"
                                   if args.workload != "C5" else "HIP events over 3 untimed trims of one alignment of the batch"),
         }
+        if args.workload == "C5" and world > 1 and single_gpu_s:
+            out["strong_scaling_reference_1gpu"] = {
+                "value": round(units_per_step / single_gpu_s, 2), "unit": "columns/s", "ms_per_step": round(single_gpu_s * 1e3, 4),
+                "note": "the same batch of 64 on rank 0's GPU alone, timed behind the timed region: value / this = speed-up over one GPU"}
         if resident_s is not None:
             out["value_resident"] = round(units_per_step * args.steps / resident_s, 2)
             out["ms_per_step_resident"] = round(resident_s / args.steps * 1e3, 4)

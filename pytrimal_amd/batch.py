@@ -80,7 +80,7 @@ def _pack_masks(results):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
 
-def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6):
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6, shard=True):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
@@ -92,8 +92,9 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
 
     `trim_fn(alignment) -> TrimmedAlignment` replaces the device path (used by the CPU tests,
     which have no device): the shard is then trimmed one alignment after the other in the calling thread.
+    `shard=False`: ignore the process group and trim the whole list on this rank (returns the list).
     """
-    distributed = dist.is_available() and dist.is_initialized()
+    distributed = shard and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     mine = shard_indices(len(alignments), world, rank)

@@ -173,6 +173,24 @@ def test_two_ranks_share_one_gpu():
     assert rec["ranks"] == 2 and rec["alignments"] == 7 and rec["equal_to_single_process"] is True
 
 
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """`python bench.py --gpus 2 --share-gpu`: the launcher, two ranks, BASELINE config 5 sharded over them through the
+    native batch path, the gather of the masks, the max-over-ranks timing and the one JSON line -- everything a
+    multi-GPU run does except RCCL itself (both ranks use this box's one GPU, the process group runs over gloo)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 2 and "C5" in rec["config"]["workload"]
+    assert rec["config"]["kept_columns"] == 192501  # what the 64 trims keep in total (every mask: test_c5_batch_golden)
+    assert rec["strong_scaling_reference_1gpu"]["value"] > 0 and rec["value"] > 0
+
+
 def test_batch_module_in_a_fresh_process():
     """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
     package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`
