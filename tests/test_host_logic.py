@@ -213,3 +213,49 @@ def test_alignment_type_detection_matches_the_oracle():
     edge = np.stack([row, row])
     assert detect_alignment_type(edge) == oracle.alignment_type(edge) == 4
     assert {1, 4} <= seen
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/msastat.h compiles as C99 (`gcc -std=c99 -pedantic -Wall -Werror`) and a C program linked against
+    libmsastat_hip.so can call the host-only entry points: the boundary is a C ABI, not a C++ one."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "msastat.h"
+int main(void) {
+    int32_t g[8] = {0, 3, 6, 3, 0, 0, 9, 0}, w[8];
+    uint8_t keep[8];
+    msa_trim_params p;
+    msa_trim_info info;
+    memset(&p, 0, sizeof p);
+    memset(&info, 0, sizeof info);
+    if (msa_window_i32(g, 8, 1, w) != MSA_OK) return 1;
+    if (msa_select_method(0.6f, 0.7f, 100) != 1 || msa_select_method(0.2f, 0.3f, 100) != 2) return 2;
+    if (msa_clean_gaps(g, 8, 3.0, 0.0f, keep) != MSA_OK) return 3;
+    if (strcmp(msa_strerror(MSA_E_WINDOW_TOO_BIG), "window size is too big for this alignment") != 0) return 4;
+    if (msa_trim(NULL, &p, keep, keep, &info) != MSA_E_INVALID) return 5;           /* argument checks need no device */
+    if (msa_trim_batch(NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) != MSA_E_INVALID) return 6;
+    printf("%d %d %d %d %d %d %d %d | %d%d%d%d%d%d%d%d\n", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], keep[0], keep[1], keep[2],
+           keep[3], keep[4], keep[5], keep[6], keep[7]);
+    return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    libdir = os.path.join(root, "pytrimal_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                         "-L", libdir, "-l:libmsastat_hip.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, (run.returncode, run.stderr)
+    windowed, mask = run.stdout.strip().split(" | ")
+    want = oracle.gaps_window(np.array([0, 3, 6, 3, 0, 0, 9, 0], dtype=np.int32), 1)
+    assert [int(x) for x in windowed.split()] == want.tolist()
+    assert mask == "".join("1" if x <= 3 else "0" for x in [0, 3, 6, 3, 0, 0, 9, 0])
