@@ -46,8 +46,8 @@ constexpr int PLANES_TOTAL = 8;
 __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restrict__ raw, int m, int n,
                                                           int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
                                                           int nchunk, int m_pad, int *__restrict__ err_flag) {
-    const int row = blockIdx.x * 256 + threadIdx.x;  // < m_pad
-    const int cpair = blockIdx.y;                    // 64-column group
+    const int row = blockIdx.y * 256 + threadIdx.x;  // < m_pad
+    const int cpair = blockIdx.x;                    // 64-column group (the x dimension: no 65 535 limit on the columns)
     if (row >= m_pad) return;
     uint32_t out[2][8];
 #pragma unroll
@@ -739,7 +739,7 @@ int set_max_lds_once(const void *kernel, int bytes) {
 
 void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, uint32_t *planes,
                         int nchunk, int m_pad, int *err_flag) {
-    dim3 grid((m_pad + 255) / 256, (nchunk + 1) / 2);
+    dim3 grid((nchunk + 1) / 2, (m_pad + 255) / 256);
     prep_planes_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, rep4(indet), planes, nchunk, m_pad, err_flag);
 }
 int planes_total() { return PLANES_TOTAL; }

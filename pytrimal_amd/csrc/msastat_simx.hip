@@ -157,10 +157,11 @@ __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
 // s = {numerator sum, denominator sum}; `which` selects the sums to advance.
 // (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
 // loop counters look divergent to the compiler.)
-__device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, int which, f2 s) {
+// cj: the column's code of row j (the callers hold it: loading it here put one more memory latency in front of the row's
+// own loads, a fifth of an ordered row's time on short rows).
+__device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, uint32_t cj, int which, f2 s) {
     const int lane = threadIdx.x & 63;
-    const uint32_t cj = cv.colcode[j];
-    if (uni((int)cj) == (int)BX_SKIP) return s;
+    if (cj == BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
     auto request = [&](int kb, float(&w)[4], uint32_t(&c)[4]) {  // (reads at most 255 entries past row m: W's slack, the code padding)
@@ -257,14 +258,14 @@ struct ResolvedLg {
     unsigned long long t_ordered;  // STAMP: cycles spent in the ordered rows
 };
 template <bool STAMP>
-__device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, unsigned long long vmask, int kind, float s,
-                                                 float Bl, float ie, float io) {
+__device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, uint32_t code, unsigned long long vmask, int kind,
+                                                 float s, float Bl, float ie, float io) {
     const int lane = threadIdx.x & 63;
     unsigned long long t_ordered = 0;
     auto ordered_row = [&](int x, float from) {
         unsigned long long t0 = 0;
         if (STAMP) t0 = __builtin_readcyclecounter();
-        const f2 r = exact_row(cv, wup, tab, j0 + x, kind ? 2 : 1, f2{from, from});
+        const f2 r = exact_row(cv, wup, tab, j0 + x, (uint32_t)__builtin_amdgcn_readlane((int)code, x), kind ? 2 : 1, f2{from, from});
         const float v = unif(kind ? r.y : r.x);
         if (STAMP) t_ordered += __builtin_readcyclecounter() - t0;
         return v;
@@ -503,7 +504,7 @@ __device__ __forceinline__ void similarity_lg_body(
                 const float rem = (float)(nv - tb) * unif(wbar[jstart]);
                 qd0 += rem;
                 qn0 += rem * gtab[wave][cj >> 3];
-                s2 = exact_row(cv, wup, tabp, jstart, 3, s2);
+                s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
             }
             ++jstart;
         }
@@ -571,8 +572,8 @@ __device__ __forceinline__ void similarity_lg_body(
         // the SIMD's other waves (which are bound by the W stream, not by issue): it runs at the highest wave priority.
         __builtin_amdgcn_s_setprio(3);
         // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
-        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
-        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
+        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
+        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
                                          takes ? ad.y - (Bd + Bd * 0x1p-23f) : 0.0f);
         const float sn1 = unif(rn.s), sd1 = unif(rd.s);
         if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);

@@ -578,3 +578,18 @@ def test_nucleotide_statistics(ctx, degenerate):
 def test_wide_alignment_many_workgroups(ctx_with, kernel):
     """Many more columns than wave slots: several waves of workgroups."""
     _sim_parity(ctx_with(**kernel), synth_msa(60, 40000, 4321))
+
+
+def test_more_columns_than_a_grid_dimension(ctx):
+    """trimAl has no column limit: an alignment with more 64-column groups than a launch's y / z dimensions hold
+    (65 535 x 64 columns) -- every statistic and a whole trim against the oracle."""
+    from pytrimal_amd import Alignment, AutomaticTrimmer
+
+    n = 65535 * 64 + 257
+    a = synth_msa(6, n, 99)
+    all_stats(ctx, a)
+    ali = Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+    out = AutomaticTrimmer("strict", platform="hip").trim(ali)
+    res, seq, _ = oracle.trim(a, method="strict")
+    assert np.array_equal(np.asarray(out.residues_mask, dtype=bool), res.astype(bool))
+    assert np.array_equal(np.asarray(out.sequences_mask, dtype=bool), seq.astype(bool))

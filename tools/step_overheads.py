@@ -1,5 +1,5 @@
 """ms per step of the bench workloads under alternating settings of one diagnostic switch, same process, same box
-(A B A B): python tools/step_overheads.py [C3 C2 C4 C5x1] [--switch MSA_PAIR_DENSE=1,0].  Without --switch: with and
+(A B A B): python tools/step_overheads.py [C3 C2 C4 C5x1] [--switch MSA_PIPELINE=1,0].  Without --switch: with and
 without the per-kernel event pairs (msa_prof_enable) -- what the measurement itself costs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
