@@ -41,6 +41,9 @@ OVERLAP_EXAMPLE = [
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # trimAl's "Removing sequence ... composed only by gaps" is API behaviour the randomised tests trigger hundreds of
+    # times; the tests that are about it use pytest.warns, which sees it regardless of this filter
+    config.addinivalue_line("filterwarnings", "ignore:Removing sequence:RuntimeWarning")
 
 
 def data_path(name):
