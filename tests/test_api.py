@@ -454,6 +454,34 @@ def test_clustal_writer_reproduces_the_reference_fixture_body():
     assert got.split(b"\n", 1)[1] == expected.split(b"\n", 1)[1]
 
 
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 59), (1, 60), (1, 61), (3, 120), (5, 121), (7, 0), (9, 179), (20, 600), (4, 5)])
+def test_whole_matrix_writers_equal_the_line_by_line_ones(m, n):
+    """FASTA and Clustal are written from the dense matrix in one piece (`_fast_fasta`, `_fast_clustal`); the bytes must
+    be those of the line-by-line writers the reference fixtures above pin -- at every line-length remainder, for names of
+    different lengths, for a trimmed view, and for names that are not ASCII (Clustal then falls back)."""
+    from pytrimal_amd import alignment as A
+    from pytrimal_amd.synth import synth_msa
+
+    rng = np.random.default_rng(m * 1000 + n)
+    a = synth_msa(m, max(n, 1), 5)[:, :n]
+    names = [("seq%d" % i + "x" * int(rng.integers(0, 12))).encode() for i in range(m)]
+
+    def line_by_line(ali, fmt):
+        out = io.StringIO()
+        A._WRITERS[fmt](out, [x.decode() for x in ali.names], list(ali.sequences), ali._alignment_type())
+        return out.getvalue()
+
+    cases = [Alignment(names, [bytes(r) for r in a])]
+    if m > 1 and n > 2:
+        keep_seq = [i % 3 != 1 for i in range(m)]
+        keep_res = [c % 4 != 2 for c in range(n)]
+        cases.append(TrimmedAlignment(names, [bytes(r).decode() for r in a], keep_seq, keep_res))
+        cases.append(Alignment([("s\u00e9q%d" % i).encode("utf-8") for i in range(m)], [bytes(r) for r in a]))
+    for ali in cases:
+        for fmt in ("fasta", "clustal"):
+            assert ali.dumps(fmt) == line_by_line(ali, fmt), (fmt, type(ali).__name__)
+
+
 def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
     """`msa_clustal_scan` / `msa_clustal_fill` (C ABI, host code) against the line-splitting parser they replace:
     the reference's fixture, the 6 x 46 example in three blocks with counts and conservation lines, blocks whose
