@@ -191,7 +191,8 @@ class Alignment:
     @classmethod
     def _from_parts(cls, names, matrix, datatype=0, seq_mask=None, res_mask=None):
         self = cls.__new__(cls)
-        self._names = list(names)
+        # (the names of an alignment are never changed in place: a list handed over by another alignment is shared)
+        self._names = names if type(names) is list else list(names)
         self._matrix = matrix
         self._datatype = datatype
         m, n = matrix.shape

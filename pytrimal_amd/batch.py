@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .trimmer import _raise_warnings
 from .alignment import Alignment, TrimmedAlignment
 
 # One native batch object (worker threads + their device contexts: O(m^2) buffers each) per (device, workers), kept
@@ -80,7 +81,8 @@ def _pack_masks(results):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
 
 
-def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6, shard=True):
+def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6, shard=True,
+               masks_only=False):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
@@ -93,6 +95,9 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     `trim_fn(alignment) -> TrimmedAlignment` replaces the device path (used by the CPU tests,
     which have no device): the shard is then trimmed one alignment after the other in the calling thread.
     `shard=False`: ignore the process group and trim the whole list on this rank (returns the list).
+    `masks_only=True`: return `(residues_mask, sequences_mask)` pairs of bool arrays instead of `TrimmedAlignment`
+    objects -- what the gather moves; building 64 result objects is interpreter time behind the device's work (and, on
+    rank 0 of a sharded run, serial work for every other rank's alignments).
     """
     distributed = shard and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
@@ -129,8 +134,15 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
                 res, seq, info, _, rows = results[k]
             else:  # an empty alignment never reaches the device
                 res, seq, info, rows = np.ones(dense.shape[1], dtype=bool), np.ones(dense.shape[0], dtype=bool), None, None
-            t = trimmer._finish(names, dense, alignments[mine[k]]._datatype, res, seq, info, rows, None, params)
+            if masks_only:
+                if info is not None and info.warnings:
+                    _raise_warnings(info, names, rows)
+                t = None
+            else:
+                t = trimmer._finish(names, dense, alignments[mine[k]]._datatype, res, seq, info, rows, None, params)
             local.append((res, seq, t))
+    if masks_only and (not distributed or world == 1):
+        return [(np.asarray(r, dtype=bool), np.asarray(s, dtype=bool)) for r, s, _ in local]
     if not distributed or world == 1:
         # (what the workers produced, as it is: rebuilding 64 results from their masks in the calling thread was a serial
         # tail of ~4 ms behind a 35 ms batch)
@@ -162,6 +174,9 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
             res = flat[pos:pos + n].astype(bool)
             seq = flat[pos + n:pos + n + m].astype(bool)
             pos += n + m
+            if masks_only:
+                out[i] = (res, seq)
+                continue
             t = mine_trimmed.get(i) if r == rank else None
             out[i] = t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], res, seq)
     return out
@@ -169,4 +184,5 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
 
 def _rebuild(alignment, keep_res, keep_seq):
     dense = alignment._dense()
-    return TrimmedAlignment._from_parts(alignment.names, dense, alignment._datatype, keep_seq, keep_res)
+    whole = len(alignment._seq_idx) == len(alignment._names)  # (every sequence visible: the list of names is shared, not copied)
+    return TrimmedAlignment._from_parts(alignment._names if whole else alignment.names, dense, alignment._datatype, keep_seq, keep_res)

@@ -57,10 +57,14 @@ def _worker(rank, world, port, q):
         assert shard_indices(5, world, rank) == list(range(rank, 5, world))
         batch = _make_batch()
         out = trim_batch(trimmer, batch, trim_fn=_oracle_trim)
+        masks = trim_batch(trimmer, batch, trim_fn=_oracle_trim, masks_only=True)  # what the gather moves, nothing rebuilt
         if rank == 0:
+            assert len(masks) == len(out)
+            for (res, seq), t in zip(masks, out):
+                assert res.tolist() == t.residues_mask and seq.tolist() == t.sequences_mask
             q.put([(t.names, list(t.sequences), t.residues_mask, t.sequences_mask) for t in out])
         else:
-            assert out is None
+            assert out is None and masks is None
             q.put(None)
     finally:
         dist.destroy_process_group()

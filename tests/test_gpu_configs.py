@@ -124,7 +124,10 @@ def test_native_batch_equals_one_by_one():
             warnings.simplefilter("ignore")
             out = trim_batch(trimmer, alis, threads=5)
             single = [trimmer.trim(x) for x in alis]
-        assert len(out) == len(alis)
+            masks = trim_batch(trimmer, alis, threads=5, masks_only=True)
+        assert len(out) == len(alis) == len(masks)
+        for (res, seq), t in zip(masks, out):
+            assert res.tolist() == t.residues_mask and seq.tolist() == t.sequences_mask
         for a, t, s1 in zip(mats, out, single):
             assert t.residues_mask == s1.residues_mask and t.sequences_mask == s1.sequences_mask
             assert t.names == s1.names and list(t.sequences) == list(s1.sequences)
