@@ -256,15 +256,16 @@ struct ResolvedLg {
     float s;
     int ordered;
     unsigned long long t_ordered;  // STAMP: cycles spent in the ordered rows
+    unsigned long long rows;       // STAMP: the rows that went through the ordered path (bit = lane)
 };
 template <bool STAMP>
 __device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab, int j0, uint32_t code, unsigned long long vmask, int kind,
                                                  float s, float Bl, float ie, float io) {
     const int lane = threadIdx.x & 63;
-    unsigned long long t_ordered = 0;
+    unsigned long long t_ordered = 0, rows_ordered = 0;
     auto ordered_row = [&](int x, float from) {
         unsigned long long t0 = 0;
-        if (STAMP) t0 = __builtin_readcyclecounter();
+        if (STAMP) t0 = __builtin_readcyclecounter(), rows_ordered |= 1ull << x;
         const f2 r = exact_row(cv, wup, tab, j0 + x, (uint32_t)__builtin_amdgcn_readlane((int)code, x), kind ? 2 : 1, f2{from, from});
         const float v = unif(kind ? r.y : r.x);
         if (STAMP) t_ordered += __builtin_readcyclecounter() - t0;
@@ -299,7 +300,7 @@ __device__ __forceinline__ ResolvedLg resolve_lg(ColView cv, gf32p wup, ldsp tab
         ++ordered;
         todo &= ~(segm & ((2ull << x) - 1ull));
     }
-    return ResolvedLg{s, ordered, t_ordered};
+    return ResolvedLg{s, ordered, t_ordered, rows_ordered};
 }
 
 // The round loop with the lane's table column in LDS instead of 32 registers.  Per wave and round a [row][lane]
@@ -467,7 +468,7 @@ __device__ __forceinline__ void similarity_lg_body(
     const __attribute__((address_space(1))) uint16_t *vtrow =
         uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
     const int nv = cv.nvalid;
-    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0;
+    unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0, n_both = 0;
     if (STAMP) {
         t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
@@ -588,6 +589,7 @@ __device__ __forceinline__ void similarity_lg_body(
             t0c = t1;
             n_ordered += (unsigned)(rn.ordered + rd.ordered);
             t_ord += rn.t_ordered + rd.t_ordered;
+            n_both += (unsigned)__builtin_popcountll(rn.rows & rd.rows);
         }
     }
     if (STAMP && lane == 0) {
@@ -601,6 +603,7 @@ __device__ __forceinline__ void similarity_lg_body(
         atomicMax(&g_bx_stamps[8], n_rounds);
         atomicAdd(&g_bx_stamps[10], n_ordered);
         atomicAdd(&g_bx_stamps[11], t_ord);
+        atomicAdd(&g_bx_stamps[12], n_both);  // rows that were ordered in BOTH chains (one pass could serve both)
         if (ci < 16384) {
             unsigned int *r = g_bx_rec + 8 * ci;
             r[0] = (unsigned)col;
