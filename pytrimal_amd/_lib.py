@@ -414,11 +414,17 @@ class Batch:
             raise RuntimeError(f"cannot create a batch of {workers} HIP contexts on device {device}: "
                                f"{self.lib.msa_strerror(rc).decode()} (there is no CPU fallback)")
         self.h, self.device, self.workers = h, int(device), int(workers)
+        # one call at a time per batch object (msa_trim_batch refuses a second one): calls from several threads queue up here
+        self._lock = threading.Lock()
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.msa_batch_destroy(self.h)
-            self.h = None
+        lock = getattr(self, "_lock", None)
+        if lock is None:
+            return
+        with lock:
+            if getattr(self, "h", None):
+                self.lib.msa_batch_destroy(self.h)
+                self.h = None
 
     def __del__(self):
         try:
@@ -461,17 +467,22 @@ class Batch:
             pos += n + m
         infos = (TrimInfo * count)()
         rcs = np.zeros(count, dtype=np.int32)
-        self.lib.msa_trim_batch(self.h, count, data, ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, kres, kseq, infos, ptr(rcs))
         out = []
-        for k, (pos, n, m) in enumerate(views):
-            rows = []
-            if infos[k].warnings & W_ONLY_GAPS_SEQUENCES:
-                cnt = self.lib.msa_batch_only_gaps_rows(self.h, k, None, 0)
-                if cnt > 0:
-                    buf = np.empty(cnt, dtype=np.int32)
-                    self.lib.msa_batch_only_gaps_rows(self.h, k, ptr(buf), cnt)
-                    rows = [int(r) for r in buf]
-            out.append((masks[pos:pos + n].astype(bool), masks[pos + n:pos + n + m].astype(bool), infos[k], int(rcs[k]), rows))
+        with self._lock:
+            if not self.h:
+                raise RuntimeError("the batch object is closed")
+            rc_all = self.lib.msa_trim_batch(self.h, count, data, ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, kres, kseq, infos, ptr(rcs))
+            if rc_all != OK and not rcs.any():  # the call itself was refused: no alignment was looked at
+                raise MsaError(rc_all, self.lib.msa_strerror(rc_all).decode())
+            for k, (pos, n, m) in enumerate(views):
+                rows = []
+                if infos[k].warnings & W_ONLY_GAPS_SEQUENCES:
+                    cnt = self.lib.msa_batch_only_gaps_rows(self.h, k, None, 0)
+                    if cnt > 0:
+                        buf = np.empty(cnt, dtype=np.int32)
+                        self.lib.msa_batch_only_gaps_rows(self.h, k, ptr(buf), cnt)
+                        rows = [int(r) for r in buf]
+                out.append((masks[pos:pos + n].astype(bool), masks[pos + n:pos + n + m].astype(bool), infos[k], int(rcs[k]), rows))
         return out
 
     def check(self, rc, info):

@@ -216,3 +216,38 @@ print('ok')
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_batches_from_two_threads_at_once():
+    """Two threads calling `trim_batch` on the same device share one native batch object, which takes one call at a
+    time: the calls queue up (a refused call used to go unnoticed and return all-ones masks)."""
+    import threading
+
+    import oracle
+    from pytrimal_amd.batch import trim_batch
+
+    trimmer = AutomaticTrimmer("strict", platform="hip")
+    groups = []
+    for g in range(2):
+        mats = [synth_msa(90 + 30 * k + 7 * g, 400 + 50 * k, 4400 + 10 * g + k) for k in range(6)]
+        alis = [Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a]) for a in mats]
+        want = [oracle.trim(a, method="strict")[:2] for a in mats]
+        groups.append((alis, want))
+    failures = []
+
+    def run(alis, want):
+        try:
+            for _ in range(4):
+                out = trim_batch(trimmer, alis, threads=3, masks_only=True)
+                for (res, seq), (ores, oseq) in zip(out, want):
+                    if not (np.array_equal(res, ores.astype(bool)) and np.array_equal(seq, oseq.astype(bool))):
+                        failures.append("masks differ")
+        except Exception as err:  # noqa: BLE001
+            failures.append(repr(err))
+
+    threads = [threading.Thread(target=run, args=g) for g in groups]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
