@@ -397,6 +397,10 @@ class Context:
         return self.lib.msa_ctx_stream(self.h)
 
 
+class BatchClosed(RuntimeError):
+    """`Batch.trim` on an object another thread has closed in the meantime (`pytrimal_amd.batch` then takes the new one)."""
+
+
 class Batch:
     """One `msa_batch`: native worker threads, each with its own device context, that trim the alignments of a call side
     by side (`msa_trim_batch`: the reference's `ThreadPool.map(trimmer.trim, ...)` without the interpreter)."""
@@ -470,7 +474,7 @@ class Batch:
         out = []
         with self._lock:
             if not self.h:
-                raise RuntimeError("the batch object is closed")
+                raise BatchClosed("the batch object is closed")
             rc_all = self.lib.msa_trim_batch(self.h, count, data, ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, kres, kseq, infos, ptr(rcs))
             if rc_all != OK and not rcs.any():  # the call itself was refused: no alignment was looked at
                 raise MsaError(rc_all, self.lib.msa_strerror(rc_all).decode())

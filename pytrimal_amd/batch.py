@@ -122,8 +122,15 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
         todo = [k for k, (_, dense, _, _, _) in enumerate(prepared) if dense.shape[0] and dense.shape[1]]
         results = {}
         if todo:
-            batch = _native_batch(index, max(1, min(int(threads), 64)))
-            outs = batch.trim([(prepared[k][1], prepared[k][2], prepared[k][3]) for k in todo])
+            items = [(prepared[k][1], prepared[k][2], prepared[k][3]) for k in todo]
+            for attempt in range(3):
+                batch = _native_batch(index, max(1, min(int(threads), 64)))
+                try:
+                    outs = batch.trim(items)
+                    break
+                except _lib.BatchClosed:  # a thread asking for another worker count replaced the device's batch object
+                    if attempt == 2:
+                        raise
             for k, out in zip(todo, outs):
                 if out[3] != _lib.OK:
                     batch.check(out[3], out[2])
