@@ -1,7 +1,7 @@
 """Four threads, each with its own contexts, trimming random alignments against the oracle at the same time (what
-ThreadPool.map(trimmer.trim, alignments) does to the library): python tools/fuzz_threads.py [seconds=60] [threads=4]"""
+ThreadPool.map(trimmer.trim, alignments) does to the library): python tests/fuzz/fuzz_threads.py [seconds=60] [threads=4]"""
 import json, os, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

@@ -2,9 +2,9 @@
 the default switches, the serial flow, the side stream at any size, row-index lists, the sequential similarity kernel, host
 exponentials + packed uploads) against
 the oracle's trim -- masks, selected method, identity means, cut points.
-  python tools/fuzz_trim.py [seconds=120] [seed=1]      (prints one JSON line; exit code 1 on the first mismatch)"""
+  python tests/fuzz/fuzz_trim.py [seconds=120] [seed=1]      (prints one JSON line; exit code 1 on the first mismatch)"""
 import ctypes, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

@@ -1,7 +1,7 @@
 # host-only entry points of the library (ingest, windows, cut points, cleaners) from an ASan/UBSan build of msastat_host.cpp
 import ctypes, os, sys, io
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import oracle
 L = ctypes.CDLL("/tmp/libmsahost_asan.so")
 vp, i32, i64, f32, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double

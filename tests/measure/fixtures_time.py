@@ -1,7 +1,7 @@
 """The reference's own test alignments (tests/golden/data) through every trimmer: public-API latency on the GPU beside the
-CPU oracle's time for the same trim (one core), masks compared.   python tools/fixtures_time.py > profiles/rNN_fixtures_time.jsonl"""
+CPU oracle's time for the same trim (one core), masks compared.   python tests/measure/fixtures_time.py > profiles/rNN_fixtures_time.jsonl"""
 import json, os, statistics, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -189,7 +189,7 @@ def test_repeated_similarity_on_one_alignment(contexts):
 
 @pytest.mark.parametrize("seed", [31, 32])
 def test_random_trims_against_the_oracle(seed):
-    """tools/fuzz_trim.py: random shapes, compositions and trimmer settings through msa_trim under six switch settings
+    """tests/fuzz/fuzz_trim.py: random shapes, compositions and trimmer settings through msa_trim under six switch settings
     (default, serial flow, side stream at any size, dense pair codes at any size, the raw pair loops) against the oracle's
     trim: masks, the selected method and the identity mean, and errors raised exactly where the oracle raises."""
     import json
@@ -198,7 +198,7 @@ def test_random_trims_against_the_oracle(seed):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_trim.py"), "8", str(seed)], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_trim.py"), "8", str(seed)], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -206,7 +206,7 @@ def test_random_trims_against_the_oracle(seed):
 
 
 def test_public_api_from_threads_against_the_oracle():
-    """tools/fuzz_threads.py: four threads trimming random protein / DNA / RNA alignments through the four trimmer classes
+    """tests/fuzz/fuzz_threads.py: four threads trimming random protein / DNA / RNA alignments through the four trimmer classes
     (type detection, default matrices, per-thread contexts) against the oracle's trim at the same time."""
     import json
     import os
@@ -214,7 +214,7 @@ def test_public_api_from_threads_against_the_oracle():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_threads.py"), "10", "4"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_threads.py"), "10", "4"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])

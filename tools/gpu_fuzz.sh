@@ -3,9 +3,9 @@
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=gpurun_out/fuzz.txt
 : > $OUT
-run() { echo -n "$* -> " >> $OUT; timeout 900 "$@" 2>/dev/null | tail -1 >> $OUT; }
-run python tools/fuzz_trim.py ${1:-200} 707
-run python tools/fuzz_trim.py ${1:-200} 808
+run() { echo -n "$* -> " >> $OUT; timeout 2400 "$@" 2>/dev/null | tail -1 >> $OUT; }
+run python tests/fuzz/fuzz_trim.py ${1:-200} 707
+run python tests/fuzz/fuzz_trim.py ${1:-200} 808
 run python tools/cross_check.py 600 13
-run python tools/fuzz_threads.py ${2:-150} 4
+run python tests/fuzz/fuzz_threads.py ${2:-150} 4
 cat $OUT
