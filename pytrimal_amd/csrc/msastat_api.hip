@@ -101,6 +101,8 @@ struct msa_ctx {
     hipEvent_t ev_rowtot = nullptr;  // behind the copy of stage_row_totals
     PinBuf<int32_t> h_len;           // ungapped lengths on their way to the host
     hipEvent_t ev_gaps = nullptr;  // behind the staged copy of the gap counts: waiting for it does not wait for later work
+    hipEvent_t ev_upload = nullptr;  // behind the copies of msa_upload_packed_async
+    bool upload_pending = false;     // ... which no wait on the stream has covered yet: msa_trim waits for the event before it returns
     char hip_err[256] = {0};
 
     // alignment
@@ -220,6 +222,7 @@ static int sync_stream(msa_ctx *c) {
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
+    c->upload_pending = false;  // (whatever an asynchronous upload enqueued is through)
     if (fetching && c->pairflag_state == 1) c->pairflag_state = 2;  // (the pair pass's flag word came with this fetch)
     if (c->gaps_staged == 1) c->gaps_staged = 2;
     if (c->rowtot_staged == 1) c->rowtot_staged = 2;
@@ -1175,6 +1178,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();
     c->h_gapstage.release(); c->h_rowtot.release(); c->h_len.release(); c->h_colcnt.release();
     if (c->ev_gaps) (void)hipEventDestroy(c->ev_gaps);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
     if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
     if (c->ev_rowtot) (void)hipEventDestroy(c->ev_rowtot);
     if (c->stream2) {
@@ -1353,6 +1357,10 @@ static int zero_padding_for_shape(msa_ctx *c, int m, int n) {
 static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet, bool wait) {
     if (!c || (!rowmajor && m > 0 && n > 0) || ld < n) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->upload_pending) {  // an asynchronous upload nobody waited for: its caller's rows are released by this call
+        HIPCHK(c, hipEventSynchronize(c->ev_upload));
+        c->upload_pending = false;
+    }
     int rc = set_shape(c, m, n, indet);
     if (rc) return rc;
     c->ld = round_up(std::max(n, 1), 64);
@@ -1383,7 +1391,15 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
             if (rc) return rc;
         }
     }
-    if (wait) SYNC(c);  // the caller may free `rowmajor` on return
+    if (wait) {
+        SYNC(c);  // the caller may free `rowmajor` on return
+    } else if (m > 0 && n > 0) {
+        // the caller keeps the rows until the next call that returns results: msa_trim waits for this event before it
+        // returns, whatever the trim itself waited for (a trim that removes nothing may not read the rows at all)
+        if (!c->ev_upload) HIPCHK(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
+        c->upload_pending = true;
+    }
     return MSA_OK;
 }
 
@@ -1544,6 +1560,11 @@ int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *k
         // an error return is a return with nothing in flight as well (an upload enqueued by msa_upload_packed_async included)
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         (void)hipStreamSynchronize(c->stream);
+        c->upload_pending = false;
+    }
+    if (c->upload_pending) {  // the rows of msa_upload_packed_async are the caller's again
+        (void)hipEventSynchronize(c->ev_upload);
+        c->upload_pending = false;
     }
     return rc;
 }

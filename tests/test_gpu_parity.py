@@ -593,3 +593,26 @@ def test_more_columns_than_a_grid_dimension(ctx):
     res, seq, _ = oracle.trim(a, method="strict")
     assert np.array_equal(np.asarray(out.residues_mask, dtype=bool), res.astype(bool))
     assert np.array_equal(np.asarray(out.sequences_mask, dtype=bool), seq.astype(bool))
+
+
+def test_rows_are_the_callers_again_when_a_trim_returns():
+    """`msa_upload_packed_async` + `msa_trim`: when the trim returns the copy is complete, also when the trim itself had
+    nothing to compute (no threshold set: every column and sequence stays) -- the caller overwrites its rows right
+    behind the call and the context must still hold what was uploaded."""
+    c = _lib.Context(0)
+    try:
+        a = synth_msa(4000, 10000, 77)
+        want = (a == ord("-")).sum(axis=0).astype(np.int32)
+        nothing = _lib.TrimParams(_lib.METHOD_CODES[None], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
+        for _ in range(3):
+            rows = a.copy()
+            c.upload(rows, ord("X"), pin=True, wait=False)
+            keep_res, keep_seq, _ = c.trim(nothing)
+            rows[:] = ord("-")
+            assert keep_res.all() and keep_seq.all()
+            assert np.array_equal(c.gaps(), want)
+            c.upload(a.copy(), ord("X"), wait=False)  # an upload nobody waits for, released by the next one
+            c.upload(a, ord("X"), wait=False)
+            assert np.array_equal(c.gaps(), want)
+    finally:
+        c.close()
