@@ -151,6 +151,7 @@ struct msa_ctx {
     int tab_npos = -1, tab_indet = -1;
     DevBuf<int32_t> gaps_w;
     DevBuf<float> mdk, simnum, simden;  // mdk: MDK [n] followed by Q [n]
+    DevBuf<float> simstate;             // the similarity kernel's per-column state between its launches (many rows: a few rounds per launch)
     DevView<unsigned long long> errkey;  // first bad residue of the similarity pass, complemented (0 = none): state block
     DevView<int> errflag;                // prep_planes' non-ASCII flag (state block)
     DevView<int> pairflag;               // set by the pair pass when some pair has dst = 0 (undefined identity; state block)
@@ -623,6 +624,7 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
     HIPCHK(c, c->mdk.reserve((size_t)2 * n + 64));  // MDK [n], Q [n]
     HIPCHK(c, c->simnum.reserve((size_t)n + 64));
     HIPCHK(c, c->simden.reserve((size_t)n + 64));
+    HIPCHK(c, c->simstate.reserve(msak::lg_state_floats(n)));
     // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
     {
         ProfScope ps(c, "sim");
@@ -631,7 +633,7 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
                                                         c->simnum.p, c->simden.p)
                           : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_trow.p, npos,
                                                        c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wlow.p, c->wmat.p,
-                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate, c->wbar.p);
+                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate, c->wbar.p, c->simstate.p);
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
@@ -1172,7 +1174,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
     c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->gaps_w.release();
-    c->mdk.release(); c->simnum.release(); c->simden.release(); c->col_ok.release();
+    c->mdk.release(); c->simnum.release(); c->simden.release(); c->simstate.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
     c->h_i32.release(); c->h_f32.release(); c->h_u64.release(); c->h_u8.release(); c->h_raw.release();

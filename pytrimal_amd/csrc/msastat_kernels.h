@@ -18,6 +18,7 @@ struct Tuning {
     int upload_direct = 1;     // MSA_UPLOAD_DIRECT=0: every upload through the packed pinned staging pieces (diagnostics)
     int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
+    int lg_rounds = -1;        // MSA_LG_ROUNDS: rounds of the similarity kernel per launch (-1: by size, 0: one launch; tests: any)
     int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
 };
 Tuning tuning_from_env();
@@ -48,7 +49,8 @@ void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, fl
                            float *out2, float *row_min = nullptr, int *gate = nullptr);
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
-                         const int *gate, const float *wbar);
+                         const int *gate, const float *wbar, float *state);  // state: lg_state_floats(n) floats (per-column state between launches), or null: one launch
+size_t lg_state_floats(int n);
 void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar);
 int launch_similarity_seq(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wup, int ldw,
                           const void *tab, float *num_out, float *den_out);

@@ -721,6 +721,7 @@ Tuning tuning_from_env() {
     t.lg_r0 = num("MSA_LG_R0", -1);
     t.lg_big = num("MSA_LG_BIG", 0);
     t.mdk_host = num("MSA_MDK_HOST", 0);
+    t.lg_rounds = num("MSA_LG_ROUNDS", -1);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

@@ -36,6 +36,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "msastat_kernels.h"
 
 namespace msak {
@@ -430,7 +432,8 @@ __device__ __forceinline__ void round_loop_lds(const float *wlow_g, uint32_t row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-constexpr int LG_WAVES_MAX = 8;  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
+constexpr int LG_WAVES_MAX = 8;
+constexpr int LG_STATE = 40;  // floats of per-column state between launches (similarity_lg_body)  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
 
 // The lane's table column lives in LDS (round_loop_lds; `nr` rows per wave behind the static arrays, within the first
 // 64 KB: M0 holds 16 bits).
@@ -440,7 +443,8 @@ __device__ __forceinline__ void similarity_lg_body(
     const uint8_t *__restrict__ codeT_,
     int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,
     const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
-    float *__restrict__ num_out, float *__restrict__ den_out, const float *__restrict__ wbar) {
+    float *__restrict__ num_out, float *__restrict__ den_out, const float *__restrict__ wbar, int jbegin, int jend,
+    float *__restrict__ state) {
     const gf32p wup = (gf32p)(uint64_t)wup_;
     __shared__ f2 tab[32 * 32];                  // {distance, both valid}[row code][column code], rows 28.. zero
     __shared__ uint32_t hist[LG_WAVES_MAX][32];  // residue counts of the wave's column
@@ -473,6 +477,16 @@ __device__ __forceinline__ void similarity_lg_body(
         t0c = __builtin_readcyclecounter();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
+    // A launch covers the rounds whose first row lies in [jbegin, jend) (launch_similarity_lg: one launch for everything, or
+    // a few rounds per launch from ~3000 rows on).  Between launches a column's state lives in `state`: the two sums, the two
+    // ratios of the predictor, its position (rows in front of the next round, valid rows in front of it, lanes of that
+    // round the ordered prologue has done) and G.
+    const bool resume = jbegin > 0;
+    float *st = state ? state + (size_t)ci * LG_STATE : nullptr;
+    f2 s2 = {0.0f, 0.0f};
+    float sn, sd, cn, cd;
+    int j0, first, tbase;
+    if (!resume) {
     __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
     // the column's residue frequencies -> G
     for (int k = lane; k < m; k += 64) {
@@ -484,11 +498,11 @@ __device__ __forceinline__ void similarity_lg_body(
         float g = 0.0f;
         for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
         gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
+        if (st) st[8 + lane] = gtab[wave][lane];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     // the first rows in the reference's order: at least up to the first row that takes part
-    f2 s2 = {0.0f, 0.0f};
     float qn0 = 0.0f, qd0 = 0.0f;
     int jstart = 0, tb = 0;
     {
@@ -510,27 +524,35 @@ __device__ __forceinline__ void similarity_lg_body(
             ++jstart;
         }
     }
-    float sn = unif(s2.x), sd = unif(s2.y);
+    sn = unif(s2.x), sd = unif(s2.y);
     qn0 = unif(qn0);
     qd0 = unif(qd0);
     // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
-    float cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
-    float cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
+    cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
+    cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
     if (STAMP) {
         const unsigned long long t1 = __builtin_readcyclecounter();
         t_pro = t1 - t0c;
         t0c = t1;
     }
     __builtin_amdgcn_s_setprio(0);
-    int j0 = jstart & ~63;
-    int first = jstart - j0;  // the round's lanes before it were evaluated above
-    int tbase;                // valid rows before j0
+    j0 = jstart & ~63;
+    first = jstart - j0;  // the round's lanes before it were evaluated above
     {
         const int r = j0 + lane;
         const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
-        tbase = tb - __builtin_popcountll(__ballot(v));
+        tbase = tb - __builtin_popcountll(__ballot(v));  // valid rows before j0
     }
-    for (; j0 < m - 1 && tbase < nv; j0 += 64) {
+    } else {
+        sn = unif(st[0]), sd = unif(st[1]), cn = unif(st[2]), cd = unif(st[3]);
+        tbase = uni(reinterpret_cast<const int *>(st)[4]);
+        j0 = uni(reinterpret_cast<const int *>(st)[5]);
+        first = uni(reinterpret_cast<const int *>(st)[6]);
+        if (!(j0 < m - 1 && tbase < nv)) return;  // the column was finished by an earlier launch (its sums are written)
+        if (lane < 32) gtab[wave][lane] = st[8 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    for (; j0 < m - 1 && tbase < nv && j0 < jend; j0 += 64) {
         const int nrows = min(64, m - 1 - j0);
         const uint32_t craw = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
         const unsigned long long vall = __ballot(craw != BX_SKIP);
@@ -615,6 +637,12 @@ __device__ __forceinline__ void similarity_lg_body(
             r[6] = (unsigned)n_ordered;
         }
     }
+    if (st && lane == 0) {
+        st[0] = sn, st[1] = sd, st[2] = cn, st[3] = cd;
+        reinterpret_cast<int *>(st)[4] = tbase;
+        reinterpret_cast<int *>(st)[5] = j0;
+        reinterpret_cast<int *>(st)[6] = first;
+    }
     if (col < n && lane == 0) {
         num_out[col] = sn;
         den_out[col] = sd;
@@ -628,8 +656,9 @@ __device__ __forceinline__ void similarity_lg_body(
         const uint8_t *__restrict__ codeT_,                                                                          \
         int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
         const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
-        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate, const float *__restrict__ wbar
-#define LG_ARGS voff_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar
+        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate, const float *__restrict__ wbar, \
+        int jbegin, int jend, float *__restrict__ state
+#define LG_ARGS voff_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar, jbegin, jend, state
 template <bool STAMP, bool BIG>
 __global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
     // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
@@ -869,9 +898,21 @@ void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ld
 
 // cols: the columns to evaluate (device, ncols entries; pad with the index n, the all-skipped column); the sums of every
 // other column are left alone.  Any number of rows (see lg_big).
+size_t lg_state_floats(int n) { return (size_t)bx_cols_pad(n) * LG_STATE; }
+
+// rounds per launch: 0 = everything in one launch.  The waves of an XCD share a 64-column block of W (m x 256 bytes) in its
+// L2 only while they walk the same round, and light columns run ahead of heavy ones: a launch boundary every few rounds
+// brings the columns back together.  Measured (tools/sim_rounds_ab.py, profiles/r03_sim_rounds.jsonl): 2000 x 10000 2.87 ->
+// 2.74 ms, 3583 x 7287 8.65 -> 6.0, 5000 x 5000 15.4 -> 8.2 (45 % L2 hits in one launch), 8000 x 3000 28.7 -> 13.9; six to ten
+// rounds per launch are all about the same; below ~1800 rows (W within the L2's reach whatever the drift) one launch wins.
+int lg_rounds_per_launch(int m) {
+    if (tuning().lg_rounds >= 0) return tuning().lg_rounds;
+    return m >= 1800 ? 6 : 0;
+}
+
 int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
                          const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
-                         const int *gate, const float *wbar) {
+                         const int *gate, const float *wbar, float *state) {
     const int64_t ldk = bx_ldk(m);
     const int r0 = tuning().lg_r0 >= 0 ? tuning().lg_r0 : LG_R0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
@@ -883,12 +924,16 @@ int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vt
     if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
     const bool stamp = (tuning().sim_mode & 64) != 0, big = lg_big(m, ldw);
+    const int rounds = (std::max(m, 2) - 1 + 63) / 64, per = state ? lg_rounds_per_launch(m) : 0;
+    const int launches = per > 0 && per < rounds ? (rounds + per - 1) / per : 1;
 #define LG_LAUNCH(KERNEL)                                                                                              \
     do {                                                                                                               \
         const int e = set_max_lds_once((const void *)KERNEL, (int)dyn);                                                \
         if (e) return e;                                                                                               \
-        KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
-                                             t, num_out, den_out, gate, wbar);                                        \
+        for (int l = 0; l < launches; ++l)                                                                             \
+            KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
+                                                 t, num_out, den_out, gate, wbar, l * per * 64,                       \
+                                                 l + 1 == launches ? 0x7FFFFFFF : (l + 1) * per * 64, launches > 1 ? state : nullptr); \
     } while (0)
     if (stamp && big) LG_LAUNCH((similarity_lg_kernel<true, true>));
     else if (stamp) LG_LAUNCH((similarity_lg_kernel<true, false>));

@@ -34,7 +34,7 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
+        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -400,8 +400,10 @@ def _sim_parity(ctx, a, indet=ord("X")):
 # The similarity kernel (binade-exact, per-lane grids) in its two instantiations -- 32-bit byte offsets of the W rows in
 # the lists (default up to 32768 rows) and row indices multiplied out on the scalar unit (MSA_LG_BIG=1 forces it at
 # any size) -- and the plain sequential kernel (MSA_SIM_KERNEL=seq: one lane per column, the reference's two loops).
-KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq")]
-KERNEL_IDS = ["lg", "lg-big", "seq"]
+# lg-rounds: the similarity kernel in several launches of one round each (what it does by itself from ~3000 rows on, two
+# rounds per launch), the columns' state passed through memory
+KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"), dict(MSA_SIM_KERNEL="seq")]
+KERNEL_IDS = ["lg", "lg-big", "lg-rounds", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
@@ -436,7 +438,7 @@ def test_lane_grid_kernel_adversarial_predictions(ctx_with, kernel):
     _sim_parity(ctx, np.ascontiguousarray(a))
 
 
-@pytest.mark.parametrize("kernel", KERNELS[:2], ids=KERNEL_IDS[:2])
+@pytest.mark.parametrize("kernel", KERNELS[:3], ids=KERNEL_IDS[:3])
 @pytest.mark.parametrize("shape", [(2016, 40), (2017, 33), (2100, 72), (4040, 20), (9000, 8)])
 def test_similarity_many_rows(ctx_with, kernel, shape):
     """thousands of rows, a handful of columns (a single partial workgroup)"""
