@@ -23,6 +23,7 @@ kernel, HIP-event timed on the context's own stream) and, at N = 1, `cpu_baselin
 flavours, on a bounded sample of the same workload).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -530,6 +531,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": alg, "ms_avg": round(kernels[dom]["ms_avg"], 4),
             }
+            if dom == "sim":
+                # one similarity pass = this many launches of the kernel (six rounds each from 1800 rows on: the columns stay on
+                # the same blocks of W); ms_avg and achieved are per PASS, a profiler's per-kernel average is per launch
+                lib = _lib.load()
+                lib.msa_debug_sim_launches.argtypes = [ctypes.c_int]
+                roofline["kernel_launches_per_pass"] = int(lib.msa_debug_sim_launches(int(m)))
             if dom == "sim" and args.workload != "C5":
                 # what bounds it: the stream of W rows through the L1 / texture-addresser pipeline (all L2 hits), not HBM
                 wbytes, wsteps = similarity_w_stream_bytes(a)

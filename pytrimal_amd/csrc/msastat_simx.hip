@@ -972,6 +972,12 @@ extern "C" int msa_debug_bx_stamps(unsigned long long *out16, int reset) {
     return rc;
 }
 
+// kernel launches of one similarity pass over m rows (bench.py reports it beside the pass's time: a profiler lists the launches)
+extern "C" int msa_debug_sim_launches(int m) {
+    const int rounds = (std::max(m, 2) - 1 + 63) / 64, per = lg_rounds_per_launch(m);
+    return per > 0 && per < rounds ? (rounds + per - 1) / per : 1;
+}
+
 extern "C" int msa_debug_bx_records(unsigned int *out, int nwaves) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bx_rec), sizeof(unsigned int) * 8 * (size_t)(nwaves < 16384 ? nwaves : 16384));
 }
