@@ -537,6 +537,8 @@ def main():
                 lib = _lib.load()
                 lib.msa_debug_sim_launches.argtypes = [ctypes.c_int]
                 roofline["kernel_launches_per_pass"] = int(lib.msa_debug_sim_launches(int(m)))
+                # (what `rocprofv3 --stats` lists as the kernel's average duration)
+                roofline["ms_avg_per_kernel_launch"] = round(kernels[dom]["ms_avg"] / roofline["kernel_launches_per_pass"], 4)
             if dom == "sim" and args.workload != "C5":
                 # what bounds it: the stream of W rows through the L1 / texture-addresser pipeline (all L2 hits), not HBM
                 wbytes, wsteps = similarity_w_stream_bytes(a)
