@@ -1,5 +1,6 @@
 """Cycle stamps of the similarity kernel (MSA_SIM_MODE=64): per wave averages of the ordered prologue, the round loops
-and the stitching, ordered rows per wave, the shader clock under the kernel.
+and the stitching, ordered rows per wave, the shader clock under the kernel.  The pass runs as ONE launch here (MSA_LG_ROUNDS=0
+unless the variable is set): with a launch every six rounds a "wave" would be a column's share of one launch.
    python tools/bx_stamps.py [m n seed]      (default: the C3 alignment)"""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,8 +19,12 @@ def stamped_similarity(a, indet=ord("X"), matrix=None):
     lib = _lib.load()
     lib.msa_debug_bx_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     os.environ["MSA_SIM_MODE"] = "64"
+    rounds = os.environ.get("MSA_LG_ROUNDS")
+    os.environ["MSA_LG_ROUNDS"] = rounds if rounds is not None else "0"  # (one launch: the stamps are per wave = per column then)
     ctx = _lib.Context(0)
     os.environ.pop("MSA_SIM_MODE")
+    if rounds is None:
+        os.environ.pop("MSA_LG_ROUNDS")
     try:
         ctx.upload(a, indet)
         ctx.similarity(vhash, dist)
