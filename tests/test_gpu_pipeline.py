@@ -189,7 +189,7 @@ def test_repeated_similarity_on_one_alignment(contexts):
 
 @pytest.mark.parametrize("seed", [31, 32])
 def test_random_trims_against_the_oracle(seed):
-    """tests/fuzz/fuzz_trim.py: random shapes, compositions and trimmer settings through msa_trim under six switch settings
+    """tests/fuzz/fuzz_trim.py: random shapes, compositions and trimmer settings through msa_trim under seven switch settings
     (default, serial flow, side stream at any size, dense pair codes at any size, the raw pair loops) against the oracle's
     trim: masks, the selected method and the identity mean, and errors raised exactly where the oracle raises."""
     import json

@@ -37,12 +37,14 @@ def make(m, n):
 
 
 def run(kernel, a):
-    for k in ("MSA_SIM_KERNEL", "MSA_LG_BIG"):
+    for k in ("MSA_SIM_KERNEL", "MSA_LG_BIG", "MSA_LG_ROUNDS"):
         os.environ.pop(k, None)
     if kernel == "seq":
         os.environ["MSA_SIM_KERNEL"] = "seq"
     elif kernel == "lg-big":
         os.environ["MSA_LG_BIG"] = "1"
+    elif kernel == "lg-rounds":  # one round per launch, the columns' state through memory (by itself: six from 1800 rows on)
+        os.environ["MSA_LG_ROUNDS"] = "1"
     ctx = _lib.Context(0)
     try:
         ctx.upload(a, ord("X"))
@@ -60,7 +62,7 @@ for i in range(cases):
         n = min(n, 100)
     a = make(m, n)
     ref = run("seq", a)  # the reference's two loops, one lane per column
-    for k in ("lg", "lg-big"):
+    for k in ("lg", "lg-big", "lg-rounds"):
         got = run(k, a)
         ok = np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
         if not ok:
