@@ -15,7 +15,8 @@ def short(name):
 
 
 def counters(d):
-    files = sorted(glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv")))
+    # (the newest file: gpurun merges a run's output into what earlier runs of the same tag left behind)
+    files = sorted(glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     acc = defaultdict(list)
     if files:
         for r in csv.DictReader(open(files[-1])):
@@ -64,16 +65,17 @@ open(os.path.join(DST, TAG + "_pmc_hbm_traffic.txt"), "w").write("\n".join(lines
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 
 for w in ("C3", "C2", "C4", "C5"):
-    files = glob.glob(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv"))
+    files = sorted(glob.glob(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if files:
-        shutil.copy(files[0], os.path.join(DST, f"{TAG}_rocprofv3_kernel_stats_{w.lower()}.csv"))
+        shutil.copy(files[-1], os.path.join(DST, f"{TAG}_rocprofv3_kernel_stats_{w.lower()}.csv"))
     b = os.path.join(SRC, f"bench_{w}.json")
     if os.path.exists(b):
         last = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
         if last:
             open(os.path.join(DST, f"{TAG}_bench_{w.lower()}.json"), "w").write(last[-1] + "\n")
 
-out = ["# rocprofv3 --pmc <SQ / GRBM counters> --kernel-trace over python3 bench.py --steps 3 --warmup 1; averages per dispatch.",
+out = ["# rocprofv3 --pmc <SQ / GRBM counters> --kernel-trace over python3 bench.py --steps 3 --warmup 1; averages per dispatch",
+       "# (a similarity pass at C3 is six dispatches of similarity_lg_kernel: DESIGN 5.8).",
        "# SQ_* cycle counters count quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs:",
        "# kernel cycles = GRBM_GUI_ACTIVE / 8.  VALU busy = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles)."]
 for tag, dirs in (("C3", ("sq1_C3", "sq2_C3", "sq3_C3")), ("C4", ("sq1_C4",))):
