@@ -487,62 +487,62 @@ __device__ __forceinline__ void similarity_lg_body(
     float sn, sd, cn, cd;
     int j0, first, tbase;
     if (!resume) {
-    __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
-    // the column's residue frequencies -> G
-    for (int k = lane; k < m; k += 64) {
-        const uint32_t ck = cv.colcode[k];
-        if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (lane < 32) {
-        float g = 0.0f;
-        for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
-        gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
-        if (st) st[8 + lane] = gtab[wave][lane];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-
-    // the first rows in the reference's order: at least up to the first row that takes part
-    float qn0 = 0.0f, qd0 = 0.0f;
-    int jstart = 0, tb = 0;
-    {
-        // (the rows in front of the first one that takes part need nothing: skipped 64 at a time -- a column whose first
-        // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
-        for (; jstart + 64 < m - 1; jstart += 64)
-            if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
-        bool seen = false;
-        while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
-            const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
-            if (cj != BX_SKIP) {
-                ++tb;
-                seen = true;
-                const float rem = (float)(nv - tb) * unif(wbar[jstart]);
-                qd0 += rem;
-                qn0 += rem * gtab[wave][cj >> 3];
-                s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
-            }
-            ++jstart;
+        __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
+        // the column's residue frequencies -> G
+        for (int k = lane; k < m; k += 64) {
+            const uint32_t ck = cv.colcode[k];
+            if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
         }
-    }
-    sn = unif(s2.x), sd = unif(s2.y);
-    qn0 = unif(qn0);
-    qd0 = unif(qd0);
-    // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
-    cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
-    cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
-    if (STAMP) {
-        const unsigned long long t1 = __builtin_readcyclecounter();
-        t_pro = t1 - t0c;
-        t0c = t1;
-    }
-    __builtin_amdgcn_s_setprio(0);
-    j0 = jstart & ~63;
-    first = jstart - j0;  // the round's lanes before it were evaluated above
-    {
-        const int r = j0 + lane;
-        const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
-        tbase = tb - __builtin_popcountll(__ballot(v));  // valid rows before j0
-    }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (lane < 32) {
+            float g = 0.0f;
+            for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
+            gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
+            if (st) st[8 + lane] = gtab[wave][lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+        // the first rows in the reference's order: at least up to the first row that takes part
+        float qn0 = 0.0f, qd0 = 0.0f;
+        int jstart = 0, tb = 0;
+        {
+            // (the rows in front of the first one that takes part need nothing: skipped 64 at a time -- a column whose first
+            // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
+            for (; jstart + 64 < m - 1; jstart += 64)
+                if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
+            bool seen = false;
+            while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
+                const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
+                if (cj != BX_SKIP) {
+                    ++tb;
+                    seen = true;
+                    const float rem = (float)(nv - tb) * unif(wbar[jstart]);
+                    qd0 += rem;
+                    qn0 += rem * gtab[wave][cj >> 3];
+                    s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
+                }
+                ++jstart;
+            }
+        }
+        sn = unif(s2.x), sd = unif(s2.y);
+        qn0 = unif(qn0);
+        qd0 = unif(qd0);
+        // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
+        cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
+        cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
+        if (STAMP) {
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            t_pro = t1 - t0c;
+            t0c = t1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        j0 = jstart & ~63;
+        first = jstart - j0;  // the round's lanes before it were evaluated above
+        {
+            const int r = j0 + lane;
+            const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
+            tbase = tb - __builtin_popcountll(__ballot(v));  // valid rows before j0
+        }
     } else {
         sn = unif(st[0]), sd = unif(st[1]), cn = unif(st[2]), cd = unif(st[3]);
         tbase = uni(reinterpret_cast<const int *>(st)[4]);
