@@ -535,8 +535,8 @@ def main():
                 # one similarity pass = this many launches of the kernel (six rounds each from 1800 rows on: the columns stay on
                 # the same blocks of W); ms_avg and achieved are per PASS, a profiler's per-kernel average is per launch
                 lib = _lib.load()
-                lib.msa_debug_sim_launches.argtypes = [ctypes.c_int]
-                roofline["kernel_launches_per_pass"] = int(lib.msa_debug_sim_launches(int(m)))
+                lib.msa_debug_sim_launches.argtypes = [ctypes.c_void_p]
+                roofline["kernel_launches_per_pass"] = max(1, int(lib.msa_debug_sim_launches(ctx.h)))
                 # (what `rocprofv3 --stats` lists as the kernel's average duration)
                 roofline["ms_avg_per_kernel_launch"] = round(kernels[dom]["ms_avg"] / roofline["kernel_launches_per_pass"], 4)
             if dom == "sim" and args.workload != "C5":

@@ -255,6 +255,9 @@ void msa_prof_reset(msa_ctx *ctx);
 /* enable: 0 off; 1 an event pair around every kernel group; 2 around the similarity and the pair pass only (each pair
  * costs a few microseconds of queue time per trim) */
 void msa_prof_enable(msa_ctx *ctx, int enable);
+/* Kernel launches the context's last similarity pass issued (one, or one per six rounds from 1800 rows on): what a
+ * profiler lists per pass.  Diagnostics; bench.py reports it beside the pass's time. */
+int msa_debug_sim_launches(msa_ctx *ctx);
 
 #ifdef __cplusplus
 }

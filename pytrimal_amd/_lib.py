@@ -9,6 +9,7 @@ Note for processes that also use PyTorch-ROCm (bench.py, pytrimal_amd.batch): ``
 BEFORE the first call into this module.  The torch wheel bundles its own ``libamdhip64.so``; if
 the system runtime is mapped first (through this library), torch later finds no GPU.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -44,7 +45,7 @@ EXPORTS = [
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
     "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_trim_only_gaps_rows", "msa_batch_create", "msa_batch_destroy", "msa_batch_workers", "msa_trim_batch",
     "msa_batch_only_gaps_rows", "msa_batch_last_hip_error", "msa_prof_get", "msa_prof_reset",
-    "msa_prof_enable", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
+    "msa_prof_enable", "msa_debug_sim_launches", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
 ]
 
 
@@ -187,29 +188,78 @@ def ptr(arr):
     return None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
 
 
-_pinned = {}  # id(array) -> finalizer: arrays whose memory is page-locked for as long as the array object lives
+# Page-locked caller arrays (`pin_array`): id(array) -> [finalizer, bytes, address, pid], least recently used first.
+# Bounded: PYTRIMAL_AMD_PIN_MB (default 1024; 0 = never page-lock) is the most this process keeps locked through this
+# path; the least recently uploaded arrays are unregistered to make room.  Guarded by a lock (trims run from several
+# threads); an entry made by another process (a fork inherits the table, not the registrations) is ignored, and its
+# finalizer does not enter a HIP runtime that process never initialised.
+_pinned = collections.OrderedDict()
+_pin_lock = threading.Lock()
+
+
+def pin_budget_bytes():
+    try:
+        return max(0, int(os.environ.get("PYTRIMAL_AMD_PIN_MB", "1024"))) << 20
+    except ValueError:
+        return 1024 << 20
+
+
+def pinned_bytes():
+    """Bytes this process currently keeps page-locked through `pin_array`."""
+    pid = os.getpid()
+    with _pin_lock:
+        return sum(e[1] for e in _pinned.values() if e[3] == pid)
+
+
+def _unpin_entry(entry):
+    fin, _, address, pid = entry
+    fin.detach()
+    if pid == os.getpid():
+        load().msa_host_unregister(ctypes.c_void_p(address))
 
 
 def pin_array(a):
-    """Page-lock the memory of a C-contiguous array (`msa_host_register`) until the array object dies: uploads of it are
-    then one DMA copy straight from its rows.  Returns False (and changes nothing) when that is not possible."""
+    """Page-lock the memory of a C-contiguous array (`msa_host_register`) until the array object dies or the budget
+    (`pin_budget_bytes`) needs its room: uploads of it are then one DMA copy straight from its rows.  Returns False
+    (and changes nothing) when that is not possible or not allowed."""
     import weakref
 
-    if id(a) in _pinned:
+    budget = pin_budget_bytes()
+    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.nbytes == 0 or a.nbytes > budget:
+        return False
+    key, pid = id(a), os.getpid()
+    with _pin_lock:
+        entry = _pinned.get(key)
+        if entry is not None and entry[3] == pid:
+            _pinned.move_to_end(key)
+            return True
+        if entry is not None:  # inherited through a fork: not registered in this process
+            entry[0].detach()
+            del _pinned[key]
+        lib, address, nbytes = load(), a.ctypes.data, a.nbytes
+        # make room: the least recently uploaded arrays first
+        used = sum(e[1] for e in _pinned.values() if e[3] == pid)
+        for k in list(_pinned):
+            if used + nbytes <= budget:
+                break
+            e = _pinned.pop(k)
+            if e[3] == pid:
+                used -= e[1]
+            _unpin_entry(e)
+        if lib.msa_host_register(ctypes.c_void_p(address), nbytes) != OK:
+            return False
+
+        def release(key=key, address=address, pid=pid):
+            # (runs when the array is collected, before numpy frees the buffer -- from whatever thread, or process, does that)
+            with _pin_lock:
+                e = _pinned.pop(key, None)
+            if e is not None and pid == os.getpid():
+                lib.msa_host_unregister(ctypes.c_void_p(address))
+
+        fin = weakref.finalize(a, release)
+        fin.atexit = False  # (at interpreter exit the process's mappings go away by themselves: no calls into a runtime that is shutting down)
+        _pinned[key] = [fin, nbytes, address, pid]
         return True
-    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.nbytes == 0:
-        return False
-    lib, address = load(), a.ctypes.data
-    if lib.msa_host_register(ctypes.c_void_p(address), a.nbytes) != OK:
-        return False
-
-    def release(key=id(a)):
-        _pinned.pop(key, None)
-        lib.msa_host_unregister(ctypes.c_void_p(address))
-
-    fin = _pinned[id(a)] = weakref.finalize(a, release)  # runs when the array is collected, before numpy frees the buffer
-    fin.atexit = False  # (at interpreter exit the process's mappings go away by themselves: no calls into a runtime that is shutting down)
-    return True
 
 
 class MsaError(RuntimeError):

@@ -180,6 +180,8 @@ struct msa_ctx {
     std::vector<int32_t> h_gaps, h_indets;
     std::vector<int32_t> only_gaps_rows;  // the sequences the last msa_trim removed because the trimming left them with gaps only
 
+    int sim_launches = 0;  // kernel launches of the last similarity pass (msa_debug_sim_launches)
+
     // profiling
     int prof_on = 0;  // 0 off, 1 every kernel group, 2 the similarity and pair passes only
     std::map<std::string, ProfEntry> prof;
@@ -631,9 +633,15 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
         const int e = c->tuning.sim_kernel == 1
                           ? msak::launch_similarity_seq(c->stream, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wmat.p, c->ldw, c->tab.p,
                                                         c->simnum.p, c->simden.p)
-                          : msak::launch_similarity_lg(c->stream, c->bx_off.p, c->bx_trow.p, npos,
-                                                       c->bx_nvalid.p, c->codeT.p, m, n, c->simcols.p, ord.npad, c->wlow.p, c->wmat.p,
-                                                       c->ldw, c->tab.p, c->simnum.p, c->simden.p, gate, c->wbar.p, c->simstate.p);
+                          : [&]() {
+                                msak::LgAlign a = {};
+                                a.voff = c->bx_off.p, a.vtrow = c->bx_trow.p, a.nvalid = c->bx_nvalid.p, a.codeT = c->codeT.p;
+                                a.wlow = c->wlow.p, a.wup = c->wmat.p, a.wbar = c->wbar.p;
+                                a.num_out = c->simnum.p, a.den_out = c->simden.p, a.state = c->simstate.p;
+                                a.gate = gate, a.cols = c->simcols.p;
+                                a.ldk = msak::bx_ldk(m), a.m = m, a.n = n, a.ldw = c->ldw, a.ncols = ord.npad;
+                                return msak::launch_similarity_lg(c->stream, a, npos, c->tab.p, c->cus, &c->sim_launches);
+                            }();
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }
     msak::launch_sim_finish(c->stream, c->simnum.p, c->simden.p, gw_dev, m, n, c->mdk.p + n, c->mdk.p);
@@ -1816,6 +1824,9 @@ void msa_prof_reset(msa_ctx *c) {
     prof_collect(c);
     c->prof.clear();
 }
+
+// kernel launches of the context's last similarity pass (bench.py reports it beside the pass's time: a profiler lists launches)
+int msa_debug_sim_launches(msa_ctx *c) { return c ? c->sim_launches : 0; }
 
 void msa_prof_enable(msa_ctx *c, int enable) {
     if (c) c->prof_on = enable < 0 ? 0 : (enable > 2 ? 1 : enable);

@@ -19,6 +19,7 @@ struct Tuning {
     int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int lg_rounds = -1;        // MSA_LG_ROUNDS: rounds of the similarity kernel per launch (-1: by size, 0: one launch; tests: any)
+    int lg_split = 0;          // MSA_LG_SPLIT: waves of a workgroup that share one column of the similarity kernel (0: by shape; tests: 1, 2, 4, 8, 16)
     int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
 };
 Tuning tuning_from_env();
@@ -47,9 +48,25 @@ void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ld
                        int32_t *nvalid);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr, int *gate = nullptr);
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
-                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
-                         const int *gate, const float *wbar, float *state);  // state: lg_state_floats(n) floats (per-column state between launches), or null: one launch
+// One alignment as the similarity kernel sees it (device pointers).  By value for a single alignment, as a table in
+// device memory for a batch (msa_trim_batch: every column of every alignment of a shard in one grid).
+struct LgAlign {
+    const uint32_t *voff;    // compacted lists of every column's valid rows: W row offset (or index) ...
+    const uint16_t *vtrow;   // ... and table row offset
+    const int32_t *nvalid;   // entries per column
+    const uint8_t *codeT;    // column-major codes
+    const float *wlow, *wup, *wbar;
+    float *num_out, *den_out;
+    float *state;            // lg_state_floats(n) floats: per-column state between launches (null: always one launch)
+    const int *gate;         // device word that, when non-zero, turns the alignment's columns into no-ops (or null)
+    const int32_t *cols;     // single alignment: the columns to evaluate (ncols entries)
+    int64_t ldk;
+    int32_t m, n, ldw, ncols;
+};
+int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out);
+int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int2 *items, int nitems, int max_m, int npos, const void *tab,
+                               bool with_state, int *launches_out);
+int lg_split(int m, int ncols, int cus);  // waves per column the launcher picks
 size_t lg_state_floats(int n);
 void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar);
 int launch_similarity_seq(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wup, int ldw,

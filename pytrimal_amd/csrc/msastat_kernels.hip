@@ -722,6 +722,7 @@ Tuning tuning_from_env() {
     t.lg_big = num("MSA_LG_BIG", 0);
     t.mdk_host = num("MSA_MDK_HOST", 0);
     t.lg_rounds = num("MSA_LG_ROUNDS", -1);
+    t.lg_split = num("MSA_LG_SPLIT", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

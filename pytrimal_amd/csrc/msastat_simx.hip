@@ -432,24 +432,34 @@ __device__ __forceinline__ void round_loop_lds(const float *wlow_g, uint32_t row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-constexpr int LG_WAVES_MAX = 8;
-constexpr int LG_STATE = 40;  // floats of per-column state between launches (similarity_lg_body)  // waves per workgroup (they share the distance table; the launcher picks 4 or 8)
+constexpr int LG_WAVES_MAX = 8;   // waves per workgroup with a column each (they share the distance table; the launcher picks 4)
+constexpr int LG_SPLIT_MAX = 16;  // waves of a workgroup that share ONE column (S > 1 below)
+constexpr int LG_STATE = 40;      // floats of per-column state between launches (similarity_lg_body)
 
 // The lane's table column lives in LDS (round_loop_lds; `nr` rows per wave behind the static arrays, within the first
 // 64 KB: M0 holds 16 bits).
-template <bool STAMP, bool BIG>
-__device__ __forceinline__ void similarity_lg_body(
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid,
-    const uint8_t *__restrict__ codeT_,
-    int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,
-    const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,
-    float *__restrict__ num_out, float *__restrict__ den_out, const float *__restrict__ wbar, int jbegin, int jend,
-    float *__restrict__ state) {
-    const gf32p wup = (gf32p)(uint64_t)wup_;
+//
+// S > 1 -- the waves of a workgroup share ONE column (tall alignments: fewer columns than the chip has wave slots, and a
+// column of 20 000 rows is two million steps of one wave).  Every round's partner list is cut into S contiguous segments,
+// wave w accumulates segment w on the SAME predicted grids (every wave computes them from the same numbers), and the
+// increment pairs compose exactly as the rows of a round do (the header's proof, point 3): a lane whose sum in front has
+// parity p receives inc_p of segment 0, which decides the parity in front of segment 1, and so on -- a few selects per
+// lane and segment.  Wave 0 composes, stitches and publishes the new sums through LDS; three workgroup barriers per round.
+// The accumulators of every segment start at {B, B + u}: if the composed increments stay below B (the commit test of the
+// stitching), no segment's accumulator left the binade either, and a composed sum that reaches 2B is seen exactly as
+// before (all terms >= 0: a partial sum >= B stays >= B).
+template <bool STAMP, bool BIG, bool SPLIT>
+__device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, int ci, int nr, int r0_,
+                                                   const float *__restrict__ tab_g, int jbegin, int jend) {
+    const int S = SPLIT ? (int)(blockDim.x >> 6) : 1;  // waves that share the column
+    const int m = A.m, n = A.n;
+    const gf32p wup = (gf32p)(uint64_t)A.wup;
     __shared__ f2 tab[32 * 32];                  // {distance, both valid}[row code][column code], rows 28.. zero
     __shared__ uint32_t hist[LG_WAVES_MAX][32];  // residue counts of the wave's column
     __shared__ float gtab[LG_WAVES_MAX][32];     // G[a] = mean over the column's valid rows of D[.][a]
-    extern __shared__ float ltab[];              // [wave][nr][64 lanes]
+    __shared__ float seg[SPLIT ? LG_SPLIT_MAX - 1 : 1][4][64];  // SPLIT: the increment pairs of the segments 1 .. S-1
+    __shared__ float hdr[8];                     // SPLIT: sums, ratios and position, published by wave 0
+    extern __shared__ float ltab[];              // [wave][nr][64 lanes]  (S > 1: one table, shared)
     for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
         f2 v = {0.0f, 0.0f};
         if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
@@ -459,18 +469,19 @@ __device__ __forceinline__ void similarity_lg_body(
     __syncthreads();
     const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
     const int lane = threadIdx.x & 63;
-    const int wave = uni(threadIdx.x >> 6);
-    const int ci = blockIdx.x * (int)(blockDim.x >> 6) + wave;
-    if (ci >= ncols) return;
-    const int col = uni(cols[ci]);
+    const int wv = uni(threadIdx.x >> 6);
+    const int wave = SPLIT ? 0 : wv;     // slot of hist / gtab / ltab
+    const bool lead = !SPLIT || wv == 0;  // the wave that owns the column's sums
+    if (col < 0) return;  // (a wave behind the last column; uniform per workgroup when the waves share a column)
     ColView cv;
-    cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)voff_ + (size_t)col * ldk);
-    cv.nvalid = uni(nvalid[col]);
-    cv.colcode = uniform_ptr((gu8p)(uint64_t)codeT_ + (size_t)col * ldk);
-    cv.ldw = ldw_;
+    cv.off = uniform_ptr((const __attribute__((address_space(1))) uint32_t *)(uint64_t)A.voff + (size_t)col * A.ldk);
+    cv.nvalid = uni(A.nvalid[col]);
+    cv.colcode = uniform_ptr((gu8p)(uint64_t)A.codeT + (size_t)col * A.ldk);
+    cv.ldw = A.ldw;
     cv.m = m;
     const __attribute__((address_space(1))) uint16_t *vtrow =
-        uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)vtrow_ + (size_t)col * ldk);
+        uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)A.vtrow + (size_t)col * A.ldk);
+    const float *__restrict__ wbar = A.wbar;
     const int nv = cv.nvalid;
     unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0, n_both = 0;
     if (STAMP) {
@@ -478,80 +489,101 @@ __device__ __forceinline__ void similarity_lg_body(
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
     // A launch covers the rounds whose first row lies in [jbegin, jend) (launch_similarity_lg: one launch for everything, or
-    // a few rounds per launch from ~3000 rows on).  Between launches a column's state lives in `state`: the two sums, the two
+    // a few rounds per launch from ~1800 rows on).  Between launches a column's state lives in `state`: the two sums, the two
     // ratios of the predictor, its position (rows in front of the next round, valid rows in front of it, lanes of that
     // round the ordered prologue has done) and G.
     const bool resume = jbegin > 0;
-    float *st = state ? state + (size_t)ci * LG_STATE : nullptr;
+    float *st = A.state ? A.state + (size_t)col * LG_STATE : nullptr;
     f2 s2 = {0.0f, 0.0f};
-    float sn, sd, cn, cd;
-    int j0, first, tbase;
-    if (!resume) {
-        __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
-        // the column's residue frequencies -> G
-        for (int k = lane; k < m; k += 64) {
-            const uint32_t ck = cv.colcode[k];
-            if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (lane < 32) {
-            float g = 0.0f;
-            for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
-            gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
-            if (st) st[8 + lane] = gtab[wave][lane];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    float sn = 0.0f, sd = 0.0f, cn = 0.0f, cd = 0.0f;
+    int j0 = 0, first = 0, tbase = 0;
+    bool alive = true;
+    if (lead) {
+        if (!resume) {
+            __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
+            // the column's residue frequencies -> G
+            for (int k = lane; k < m; k += 64) {
+                const uint32_t ck = cv.colcode[k];
+                if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (lane < 32) {
+                float g = 0.0f;
+                for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
+                gtab[wave][lane] = nv > 0 ? g / (float)nv : 0.0f;
+                if (st) st[8 + lane] = gtab[wave][lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-        // the first rows in the reference's order: at least up to the first row that takes part
-        float qn0 = 0.0f, qd0 = 0.0f;
-        int jstart = 0, tb = 0;
-        {
-            // (the rows in front of the first one that takes part need nothing: skipped 64 at a time -- a column whose first
-            // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
-            for (; jstart + 64 < m - 1; jstart += 64)
-                if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
-            bool seen = false;
-            while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
-                const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
-                if (cj != BX_SKIP) {
-                    ++tb;
-                    seen = true;
-                    const float rem = (float)(nv - tb) * unif(wbar[jstart]);
-                    qd0 += rem;
-                    qn0 += rem * gtab[wave][cj >> 3];
-                    s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
+            // the first rows in the reference's order: at least up to the first row that takes part
+            float qn0 = 0.0f, qd0 = 0.0f;
+            int jstart = 0, tb = 0;
+            {
+                // (the rows in front of the first one that takes part need nothing: skipped 64 at a time -- a column whose first
+                // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
+                for (; jstart + 64 < m - 1; jstart += 64)
+                    if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
+                bool seen = false;
+                while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
+                    const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
+                    if (cj != BX_SKIP) {
+                        ++tb;
+                        seen = true;
+                        const float rem = (float)(nv - tb) * unif(wbar[jstart]);
+                        qd0 += rem;
+                        qn0 += rem * gtab[wave][cj >> 3];
+                        s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
+                    }
+                    ++jstart;
                 }
-                ++jstart;
+            }
+            sn = unif(s2.x), sd = unif(s2.y);
+            qn0 = unif(qn0);
+            qd0 = unif(qd0);
+            // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
+            cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
+            cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
+            if (STAMP) {
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                t_pro = t1 - t0c;
+                t0c = t1;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            j0 = jstart & ~63;
+            first = jstart - j0;  // the round's lanes before it were evaluated above
+            {
+                const int r = j0 + lane;
+                const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
+                tbase = tb - __builtin_popcountll(__ballot(v));  // valid rows before j0
+            }
+        } else {
+            sn = unif(st[0]), sd = unif(st[1]), cn = unif(st[2]), cd = unif(st[3]);
+            tbase = uni(reinterpret_cast<const int *>(st)[4]);
+            j0 = uni(reinterpret_cast<const int *>(st)[5]);
+            first = uni(reinterpret_cast<const int *>(st)[6]);
+            alive = j0 < m - 1 && tbase < nv;  // else: the column was finished by an earlier launch (its sums are written)
+            if (alive) {
+                if (lane < 32) gtab[wave][lane] = st[8 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
         }
-        sn = unif(s2.x), sd = unif(s2.y);
-        qn0 = unif(qn0);
-        qd0 = unif(qd0);
-        // increment per unit of the estimate (any positive value is correct; a poor one costs ordered rows)
-        cn = unif((sn > 0.0f && qn0 > 0.0f) ? sn / qn0 : 0.8f);
-        cd = unif((sd > 0.0f && qd0 > 0.0f) ? sd / qd0 : 0.8f);
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_pro = t1 - t0c;
-            t0c = t1;
+        if (SPLIT && lane == 0) {
+            hdr[0] = sn, hdr[1] = sd, hdr[2] = cn, hdr[3] = cd;
+            reinterpret_cast<int *>(hdr)[4] = tbase;
+            reinterpret_cast<int *>(hdr)[5] = j0;
+            reinterpret_cast<int *>(hdr)[6] = first;
+            reinterpret_cast<int *>(hdr)[7] = alive ? 1 : 0;
         }
-        __builtin_amdgcn_s_setprio(0);
-        j0 = jstart & ~63;
-        first = jstart - j0;  // the round's lanes before it were evaluated above
-        {
-            const int r = j0 + lane;
-            const bool v = r < jstart && cv.colcode[r] != BX_SKIP;
-            tbase = tb - __builtin_popcountll(__ballot(v));  // valid rows before j0
-        }
-    } else {
-        sn = unif(st[0]), sd = unif(st[1]), cn = unif(st[2]), cd = unif(st[3]);
-        tbase = uni(reinterpret_cast<const int *>(st)[4]);
-        j0 = uni(reinterpret_cast<const int *>(st)[5]);
-        first = uni(reinterpret_cast<const int *>(st)[6]);
-        if (!(j0 < m - 1 && tbase < nv)) return;  // the column was finished by an earlier launch (its sums are written)
-        if (lane < 32) gtab[wave][lane] = st[8 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
+    if (SPLIT) {
+        __syncthreads();
+        sn = unif(hdr[0]), sd = unif(hdr[1]), cn = unif(hdr[2]), cd = unif(hdr[3]);
+        tbase = uni(reinterpret_cast<const int *>(hdr)[4]);
+        j0 = uni(reinterpret_cast<const int *>(hdr)[5]);
+        first = uni(reinterpret_cast<const int *>(hdr)[6]);
+        alive = uni(reinterpret_cast<const int *>(hdr)[7]) != 0;
+    }
+    if (!alive) return;  // (uniform per workgroup when the waves share a column)
     for (; j0 < m - 1 && tbase < nv && j0 < jend; j0 += 64) {
         const int nrows = min(64, m - 1 - j0);
         const uint32_t craw = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
@@ -575,15 +607,23 @@ __device__ __forceinline__ void similarity_lg_body(
             Qd = rl(Pd, 63);
         }
         // (the ulp of a grid is B * 2^-23, exact: grid_of only accepts exponents >= 30)
-        f2 an = {Bn, Bn + Bn * 0x1p-23f}, ad = {Bd, Bd + Bd * 0x1p-23f};
+        const float Bno = Bn + Bn * 0x1p-23f, Bdo = Bd + Bd * 0x1p-23f;
+        f2 an = {Bn, Bno}, ad = {Bd, Bdo};
         const uint32_t joff = 4u * (uint32_t)(j0 + lane);
         {
             // the lane's table column into the wave's [row][lane] table (zeros for a row that takes no part: column 28)
             float *lt = ltab + (size_t)wave * nr * 64 + lane;
-            for (int a = 0; a < nr; ++a)
+            for (int a = SPLIT ? wv : 0; a < nr; a += S)
                 lt[a * 64] = (*reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tabp + ((a << 8) + cj8))).x;
             const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(ltab + (size_t)wave * nr * 64);
-            round_loop_lds<BIG>(wlow_, 4u * (uint32_t)ldw_, cv.off, vtrow, tbase & ~15, nv, joff, (uint32_t)uni((int)base), an, ad);
+            int ts = tbase & ~15, te = nv;
+            if (SPLIT) {
+                __syncthreads();  // the shared table is complete
+                const int per = ((nv - ts + 31) / 32 + S - 1) / S * 32;  // list entries per wave
+                ts += per * wv;
+                te = min(nv, ts + per);
+            }
+            if (ts < te) round_loop_lds<BIG>(A.wlow, 4u * (uint32_t)A.ldw, cv.off, vtrow, ts, te, joff, (uint32_t)uni((int)base), an, ad);
         }
         if (STAMP) {
             const unsigned long long t1 = __builtin_readcyclecounter();
@@ -591,29 +631,55 @@ __device__ __forceinline__ void similarity_lg_body(
             t0c = t1;
             ++n_rounds;
         }
-        // The stitching is a latency-bound instruction stream that competes for issue slots with the round loops of
-        // the SIMD's other waves (which are bound by the W stream, not by issue): it runs at the highest wave priority.
-        __builtin_amdgcn_s_setprio(3);
-        // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
-        const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 0, sn, Bn, an.x - Bn, an.y - (Bn + Bn * 0x1p-23f));
-        const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 1, sd, Bd, takes ? ad.x - Bd : 0.0f,
-                                         takes ? ad.y - (Bd + Bd * 0x1p-23f) : 0.0f);
-        const float sn1 = unif(rn.s), sd1 = unif(rd.s);
-        if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);
-        if (sd1 > sd && Qd > 0.0f) cd = unif((sd1 - sd) / Qd);
-        sn = sn1;
-        sd = sd1;
+        float ien = an.x - Bn, ion = an.y - Bno, ied = ad.x - Bd, iod = ad.y - Bdo;
+        if (SPLIT) {
+            if (wv > 0) {
+                seg[wv - 1][0][lane] = ien, seg[wv - 1][1][lane] = ion, seg[wv - 1][2][lane] = ied, seg[wv - 1][3][lane] = iod;
+            }
+            __syncthreads();
+            if (lead) {
+                // segments in the order of their partners; the parity of the sum in front of a segment is the mantissa's last
+                // bit of (grid base + what the segments before it added)
+#pragma unroll 1
+                for (int w = 0; w < S - 1; ++w) {
+                    const float en = seg[w][0][lane], on = seg[w][1][lane], ed = seg[w][2][lane], od = seg[w][3][lane];
+                    ien += (__float_as_uint(Bn + ien) & 1u) ? on : en;
+                    ion += (__float_as_uint(Bno + ion) & 1u) ? on : en;
+                    ied += (__float_as_uint(Bd + ied) & 1u) ? od : ed;
+                    iod += (__float_as_uint(Bdo + iod) & 1u) ? od : ed;
+                }
+            }
+        }
+        if (lead) {
+            // The stitching is a latency-bound instruction stream that competes for issue slots with the round loops of
+            // the SIMD's other waves (which are bound by the W stream, not by issue): it runs at the highest wave priority.
+            __builtin_amdgcn_s_setprio(3);
+            // (a lane whose row takes no part: the LDS loop added W to its denominator accumulators -- ignored)
+            const ResolvedLg rn = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 0, sn, Bn, ien, ion);
+            const ResolvedLg rd = resolve_lg<STAMP>(cv, wup, tabp, j0, cj8, vmask, 1, sd, Bd, takes ? ied : 0.0f, takes ? iod : 0.0f);
+            const float sn1 = unif(rn.s), sd1 = unif(rd.s);
+            if (sn1 > sn && Qn > 0.0f) cn = unif((sn1 - sn) / Qn);
+            if (sd1 > sd && Qd > 0.0f) cd = unif((sd1 - sd) / Qd);
+            sn = sn1;
+            sd = sd1;
+            __builtin_amdgcn_s_setprio(0);
+            if (STAMP) {
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                t_res += t1 - t0c;
+                t0c = t1;
+                n_ordered += (unsigned)(rn.ordered + rd.ordered);
+                t_ord += rn.t_ordered + rd.t_ordered;
+                n_both += (unsigned)__builtin_popcountll(rn.rows & rd.rows);
+            }
+            if (SPLIT && lane == 0) hdr[0] = sn, hdr[1] = sd, hdr[2] = cn, hdr[3] = cd;
+        }
         tbase += __builtin_popcountll(vall);
-        __builtin_amdgcn_s_setprio(0);
-        if (STAMP) {
-            const unsigned long long t1 = __builtin_readcyclecounter();
-            t_res += t1 - t0c;
-            t0c = t1;
-            n_ordered += (unsigned)(rn.ordered + rd.ordered);
-            t_ord += rn.t_ordered + rd.t_ordered;
-            n_both += (unsigned)__builtin_popcountll(rn.rows & rd.rows);
+        if (SPLIT) {
+            __syncthreads();
+            sn = unif(hdr[0]), sd = unif(hdr[1]), cn = unif(hdr[2]), cd = unif(hdr[3]);
         }
     }
+    if (!lead) return;
     if (STAMP && lane == 0) {
         atomicAdd(&g_bx_stamps[0], t_pro);
         atomicAdd(&g_bx_stamps[1], t_loop);
@@ -644,30 +710,41 @@ __device__ __forceinline__ void similarity_lg_body(
         reinterpret_cast<int *>(st)[6] = first;
     }
     if (col < n && lane == 0) {
-        num_out[col] = sn;
-        den_out[col] = sd;
+        A.num_out[col] = sn;
+        A.den_out[col] = sd;
     }
 }
 
-// Compiled for five waves per SIMD (the LDS allocation admits 20 waves per CU for a 20-letter alphabet).  Two
-// instantiations: 32-bit byte offsets in the lists, or row indices (BIG, m > 32768).
-#define LG_PARAMS                                                                                                      \
-    const uint32_t *__restrict__ voff_, const uint16_t *__restrict__ vtrow_, int nr, const int32_t *__restrict__ nvalid, \
-        const uint8_t *__restrict__ codeT_,                                                                          \
-        int64_t ldk, int m, int n, const int32_t *__restrict__ cols, int ncols, const float *__restrict__ wlow_,    \
-        const float *__restrict__ wup_, int ldw_, int r0_, const float *__restrict__ tab_g,         \
-        float *__restrict__ num_out, float *__restrict__ den_out, const int *__restrict__ gate, const float *__restrict__ wbar, \
-        int jbegin, int jend, float *__restrict__ state
-#define LG_ARGS voff_, vtrow_, nr, nvalid, codeT_, ldk, m, n, cols, ncols, wlow_, wup_, ldw_, r0_, tab_g, num_out, den_out, wbar, jbegin, jend, state
-template <bool STAMP, bool BIG>
-__global__ __launch_bounds__(64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5))) void similarity_lg_kernel(LG_PARAMS) {
+// Compiled for five waves per SIMD (the LDS allocation admits 20 waves per CU for a 20-letter alphabet).  Instantiations:
+// 32-bit byte offsets in the lists or row indices (BIG, m > 32768); a wave per column, four per workgroup, or (SPLIT) a
+// workgroup of blockDim / 64 waves per column.  One alignment (`one`, by value: no table to upload) or a batch: `table` + `items`
+// ({alignment, column} per work item -- msa_trim_batch's launch over every column of every alignment of a shard).
+template <bool STAMP, bool BIG, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 64 * LG_SPLIT_MAX : 64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void similarity_lg_kernel(LgAlign one, const LgAlign *__restrict__ table, const int2 *__restrict__ items, int nitems, int nr, int r0,
+                          const float *__restrict__ tab_g, int jbegin, int jend) {
+    const int ci = SPLIT ? (int)blockIdx.x : blockIdx.x * (int)(blockDim.x >> 6) + uni(threadIdx.x >> 6);
+    int col = -1;
+    if (table) {
+        if (ci < nitems) {
+            const int2 it = items[ci];
+            const int a = uni(it.x);
+            col = uni(it.y);
+            // (wave-uniform copy of the descriptor: scalar loads)
+            cu32p src = (cu32p)(uint64_t)(table + a);
+            uint32_t words[sizeof(LgAlign) / 4];
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(LgAlign) / 4); ++i) words[i] = src[i];
+            __builtin_memcpy(&one, words, sizeof(LgAlign));
+        }
+    } else if (ci < nitems) {
+        col = uni(one.cols[ci]);
+    }
     // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
     // kernel that computes them raises the gate when the similarity values will not be used)
-    if (gate && *gate) return;
-    similarity_lg_body<STAMP, BIG>(LG_ARGS);
+    if (col >= 0 && one.gate && *one.gate) col = -1;
+    similarity_lg_body<STAMP, BIG, SPLIT>(one, col, ci, nr, r0, tab_g, jbegin, jend);
 }
-#undef LG_PARAMS
-#undef LG_ARGS
 
 // ---- the statistic as the reference writes it ------------------------------------------------------------------------
 // Similarity::calculateVectors (statistics.pxd:55): for every column, rows j ascending, partners
@@ -896,8 +973,7 @@ void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ld
                                                     lg_big(m, ldw) ? 1 : 0);
 }
 
-// cols: the columns to evaluate (device, ncols entries; pad with the index n, the all-skipped column); the sums of every
-// other column are left alone.  Any number of rows (see lg_big).
+// the sums of the columns that are not in the list are left alone.  Any number of rows (see lg_big).
 size_t lg_state_floats(int n) { return (size_t)bx_cols_pad(n) * LG_STATE; }
 
 // rounds per launch: 0 = everything in one launch.  The waves of an XCD share a 64-column block of W (m x 256 bytes) in its
@@ -910,37 +986,75 @@ int lg_rounds_per_launch(int m) {
     return m >= 1800 ? 6 : 0;
 }
 
-int launch_similarity_lg(hipStream_t s, const uint32_t *voff, const uint16_t *vtrow, int npos, const int32_t *nvalid, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols,
-                         const float *wlow, const float *wup, int ldw, const void *tab, float *num_out, float *den_out,
-                         const int *gate, const float *wbar, float *state) {
-    const int64_t ldk = bx_ldk(m);
+// Waves per column.  A wave per column fills the chip from ~5000 columns on (256 CUs x 4 SIMDs x 5 waves); below that the
+// wave slots that would stay empty go to the columns' partner lists instead, as long as every wave still has a list worth
+// walking (>= ~1000 rows per wave) -- up to eight: measured at 20000 x 500 and 40000 x 300, 4 / 6 / 8 / 12 / 16 waves per column
+// are within 15 % of one another (the W stream then misses the L2 a fifth of the time: columns of different weight drift
+// apart inside a launch, and that, not the number of waves, sets the time) and sixteen need 1024-thread workgroups that no
+// longer all fit the chip at once.  MSA_LG_SPLIT forces a value (tests: any S up to 16 at any size).
+int lg_split(int m, int ncols, int cus) {
+    const int forced = tuning().lg_split;
+    if (forced > 0) return std::min(forced, LG_SPLIT_MAX);
+    const long slots = (long)cus * 20;
+    int s = (int)std::min<long>(8, slots / std::max(ncols, 1));
+    s = std::min(s, m / 1024);
+    return std::max(s, 1);
+}
+
+// one alignment (`one.cols` lists the `one.ncols` columns to evaluate), or a batch (`table`, `items`: device memory).
+// *launches_out: kernel launches issued.
+static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, const int2 *items, int nitems, int max_m, int ldw_for_big,
+                     int npos, const void *tab, bool with_state, int split, int *launches_out) {
     const int r0 = tuning().lg_r0 >= 0 ? tuning().lg_r0 : LG_R0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
-    // four waves per workgroup: five workgroups (20 waves) per CU for a 20-letter alphabet, and a workgroup's slots
-    // are refilled as soon as its four columns are done (eight per workgroup: 4.0 instead of 3.8 ms at C3)
+    if (launches_out) *launches_out = 0;
+    if (nitems <= 0) return 0;
+    // a wave per column: four waves per workgroup -- five workgroups (20 waves) per CU for a 20-letter alphabet, and a
+    // workgroup's slots are refilled as soon as its four columns are done (eight per workgroup: 4.0 instead of 3.8 ms at C3)
     const int waves = 4;
-    const size_t dyn = (size_t)waves * nr * 256;
-    const unsigned grid = (unsigned)((ncols + waves - 1) / waves);
-    if (grid == 0) return 0;
     const float *t = static_cast<const float *>(tab);
-    const bool stamp = (tuning().sim_mode & 64) != 0, big = lg_big(m, ldw);
-    const int rounds = (std::max(m, 2) - 1 + 63) / 64, per = state ? lg_rounds_per_launch(m) : 0;
+    const bool stamp = (tuning().sim_mode & 64) != 0, big = lg_big(max_m, ldw_for_big);
+    const int rounds = (std::max(max_m, 2) - 1 + 63) / 64, per = with_state ? lg_rounds_per_launch(max_m) : 0;
     const int launches = per > 0 && per < rounds ? (rounds + per - 1) / per : 1;
-#define LG_LAUNCH(KERNEL)                                                                                              \
+    LgAlign a1 = one;
+    if (launches == 1) a1.state = nullptr;  // (nothing to carry over)
+#define LG_LAUNCH(STAMP_, BIG_, SPLIT_)                                                                                \
     do {                                                                                                               \
-        const int e = set_max_lds_once((const void *)KERNEL, (int)dyn);                                                \
+        auto kernel = similarity_lg_kernel<STAMP_, BIG_, SPLIT_>;                                                      \
+        const size_t dyn = (size_t)(SPLIT_ ? 1 : waves) * nr * 256;                                                    \
+        const unsigned grid = SPLIT_ ? (unsigned)nitems : (unsigned)((nitems + waves - 1) / waves);                    \
+        const int e = set_max_lds_once((const void *)kernel, (int)dyn);                                                \
         if (e) return e;                                                                                               \
         for (int l = 0; l < launches; ++l)                                                                             \
-            KERNEL<<<grid, 64 * waves, dyn, s>>>(voff, vtrow, nr, nvalid, codeT, ldk, m, n, cols, ncols, wlow, wup, ldw, r0, \
-                                                 t, num_out, den_out, gate, wbar, l * per * 64,                       \
-                                                 l + 1 == launches ? 0x7FFFFFFF : (l + 1) * per * 64, launches > 1 ? state : nullptr); \
+            kernel<<<grid, SPLIT_ ? 64 * split : 64 * waves, dyn, s>>>(a1, table, items, nitems, nr, r0, t, l * per * 64, \
+                                                                       l + 1 == launches ? 0x7FFFFFFF : (l + 1) * per * 64); \
     } while (0)
-    if (stamp && big) LG_LAUNCH((similarity_lg_kernel<true, true>));
-    else if (stamp) LG_LAUNCH((similarity_lg_kernel<true, false>));
-    else if (big) LG_LAUNCH((similarity_lg_kernel<false, true>));
-    else LG_LAUNCH((similarity_lg_kernel<false, false>));
+#define LG_BY_BIG(STAMP_, SPLIT_)                    \
+    do {                                             \
+        if (big) LG_LAUNCH(STAMP_, true, SPLIT_);    \
+        else LG_LAUNCH(STAMP_, false, SPLIT_);       \
+    } while (0)
+    if (stamp && split > 1) LG_BY_BIG(true, true);
+    else if (stamp) LG_BY_BIG(true, false);
+    else if (split > 1) LG_BY_BIG(false, true);
+    else LG_BY_BIG(false, false);
+#undef LG_BY_BIG
 #undef LG_LAUNCH
+    if (launches_out) *launches_out = launches;
     return 0;
+}
+
+int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out) {
+    const int split = lg_split(one.m, one.ncols, cus);
+    return launch_lg(s, one, nullptr, nullptr, one.ncols, one.m, one.ldw, npos, tab, one.state != nullptr, split, launches_out);
+}
+
+// every column of every alignment of a shard in one grid (a wave per column): `table` and `items` in device memory; the
+// alignments' m <= max_m, byte offsets in every list (the caller keeps alignments beyond 32768 rows out of a batch)
+int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int2 *items, int nitems, int max_m, int npos, const void *tab,
+                               bool with_state, int *launches_out) {
+    LgAlign none = {};
+    return launch_lg(s, none, table, items, nitems, max_m, 64, npos, tab, with_state, 1, launches_out);
 }
 
 // mean weight of every row over its later partners (m + 64 floats): the similarity kernel's predictor reads it
@@ -970,12 +1084,6 @@ extern "C" int msa_debug_bx_stamps(unsigned long long *out16, int reset) {
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_stamps), z, sizeof(z));
     }
     return rc;
-}
-
-// kernel launches of one similarity pass over m rows (bench.py reports it beside the pass's time: a profiler lists the launches)
-extern "C" int msa_debug_sim_launches(int m) {
-    const int rounds = (std::max(m, 2) - 1 + 63) / 64, per = lg_rounds_per_launch(m);
-    return per > 0 && per < rounds ? (rounds + per - 1) / per : 1;
 }
 
 extern "C" int msa_debug_bx_records(unsigned int *out, int nwaves) {

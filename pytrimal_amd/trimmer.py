@@ -140,8 +140,9 @@ class BaseTrimmer:
         dense = alignment._dense()
         if dense is alignment._matrix and dense.size:
             # an alignment that is trimmed again (another trimmer, another setting): its rows are page-locked from the
-            # second trim on, for as long as the matrix lives -- every further upload is one DMA copy from where they lie
-            alignment._uploads = getattr(alignment, "_uploads", 0) + 1
+            # second trim on -- every further upload is one DMA copy from where they lie -- until the matrix dies or the
+            # process-wide budget needs the room (PYTRIMAL_AMD_PIN_MB, least recently uploaded first; 0 = never)
+            alignment._uploads = min(getattr(alignment, "_uploads", 0) + 1, 2)
             if alignment._uploads == 2:
                 _lib.pin_array(dense)
         ty = alignment._alignment_type()

@@ -34,7 +34,7 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
+        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -402,8 +402,11 @@ def _sim_parity(ctx, a, indet=ord("X")):
 # any size) -- and the plain sequential kernel (MSA_SIM_KERNEL=seq: one lane per column, the reference's two loops).
 # lg-rounds: the similarity kernel in several launches of one round each (what it does by itself from ~3000 rows on, two
 # rounds per launch), the columns' state passed through memory
-KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"), dict(MSA_SIM_KERNEL="seq")]
-KERNEL_IDS = ["lg", "lg-big", "lg-rounds", "seq"]
+# lg-split-S: S waves of a workgroup share one column, each on a segment of every round's partner list (what the launcher
+# picks by itself for tall alignments: fewer columns than wave slots); the increment pairs of the segments compose exactly
+KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="2"), dict(MSA_LG_SPLIT="4", MSA_LG_ROUNDS="1"),
+           dict(MSA_LG_SPLIT="8"), dict(MSA_LG_SPLIT="16", MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq")]
+KERNEL_IDS = ["lg", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8", "lg-split-16-big", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
@@ -438,12 +441,33 @@ def test_lane_grid_kernel_adversarial_predictions(ctx_with, kernel):
     _sim_parity(ctx, np.ascontiguousarray(a))
 
 
-@pytest.mark.parametrize("kernel", KERNELS[:3], ids=KERNEL_IDS[:3])
+@pytest.mark.parametrize("kernel", KERNELS[:-1], ids=KERNEL_IDS[:-1])
 @pytest.mark.parametrize("shape", [(2016, 40), (2017, 33), (2100, 72), (4040, 20), (9000, 8)])
 def test_similarity_many_rows(ctx_with, kernel, shape):
     """thousands of rows, a handful of columns (a single partial workgroup)"""
     m, n = shape
     _sim_parity(ctx_with(**kernel), synth_msa(m, n, 77 + m))
+
+
+@pytest.mark.parametrize("shape", [(20000, 500), (40000, 300)])
+def test_similarity_tall_alignments_split_columns(ctx_with, shape):
+    """Pfam-style shapes: far fewer columns than the chip has wave slots, so the launcher gives every column a workgroup of
+    8 / 16 waves (lg_split), each on a segment of every round's partner list.  Q and MDK of that default path against the
+    plain sequential kernel (one lane per column, the reference's two loops) and against the wave-per-column path, bit for
+    bit, every column."""
+    m, n = shape
+    a = synth_msa(m, n, 20000 + n)
+    vhash, dist = oracle.aa_matrix()
+    ctx = ctx_with()
+    ctx.upload(a, ord("X"))
+    mdk, q = ctx.similarity(vhash, dist)
+    ctx.close()
+    for env in (dict(MSA_SIM_KERNEL="seq"), dict(MSA_LG_SPLIT="1")):
+        other = ctx_with(**env)
+        other.upload(a, ord("X"))
+        mdk2, q2 = other.similarity(vhash, dist)
+        other.close()
+        assert np.array_equal(bits(q), bits(q2)) and np.array_equal(bits(mdk), bits(mdk2)), env
 
 
 def test_similarity_beyond_32768_rows(ctx_with):
