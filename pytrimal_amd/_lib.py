@@ -197,11 +197,19 @@ _pinned = collections.OrderedDict()
 _pin_lock = threading.Lock()
 
 
+_pin_budget_cache = (None, 1024 << 20)
+
+
 def pin_budget_bytes():
-    try:
-        return max(0, int(os.environ.get("PYTRIMAL_AMD_PIN_MB", "1024"))) << 20
-    except ValueError:
-        return 1024 << 20
+    global _pin_budget_cache
+    text = os.environ.get("PYTRIMAL_AMD_PIN_MB")
+    if text != _pin_budget_cache[0]:  # (parsed once per value: trim_batch asks for every alignment)
+        try:
+            value = max(0, int(text if text is not None else "1024")) << 20
+        except ValueError:
+            value = 1024 << 20
+        _pin_budget_cache = (text, value)
+    return _pin_budget_cache[1]
 
 
 def pinned_bytes():
@@ -493,42 +501,44 @@ class Batch:
         count = len(items)
         if count == 0:
             return []
-        data = (ctypes.c_void_p * count)()
-        ms = np.empty(count, dtype=np.int32)
-        ns = np.empty(count, dtype=np.int32)
-        lds = np.empty(count, dtype=np.int64)
-        indets = np.empty(count, dtype=np.uint8)
+        # (one pass over the items, plain Python ints; the arrays of the ABI are filled from the lists at once)
+        addr, ms, ns, lds, indets = [], [], [], [], []
         params = (TrimParams * count)()
-        total = 0
+        u8 = np.dtype(np.uint8)
         for k, (a, indet, p) in enumerate(items):
-            if a.dtype != np.uint8 or a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != 1):
+            shape, strides = a.shape, a.strides
+            if a.dtype != u8 or len(shape) != 2 or (shape[1] > 1 and strides[1] != 1):
                 raise ValueError("batch items must be uint8 matrices with contiguous rows")
-            data[k] = a.ctypes.data
-            ms[k], ns[k] = a.shape
-            lds[k] = a.strides[0] if a.shape[0] > 1 else max(a.shape[1], 1)
-            indets[k] = indet
+            addr.append(a.__array_interface__["data"][0])
+            ms.append(shape[0])
+            ns.append(shape[1])
+            lds.append(strides[0] if shape[0] > 1 else max(shape[1], 1))
+            indets.append(indet)
             params[k] = p
-            total += a.shape[0] + a.shape[1]
-        masks = np.ones(max(total, 1), dtype=np.uint8)
-        kres = (ctypes.c_void_p * count)()
-        kseq = (ctypes.c_void_p * count)()
-        pos, views = 0, []
-        for k, (a, _, _) in enumerate(items):
-            m, n = a.shape
-            kres[k] = masks.ctypes.data + pos
-            kseq[k] = masks.ctypes.data + pos + n
-            views.append((pos, n, m))
-            pos += n + m
+        ms = np.array(ms, dtype=np.int32)
+        ns = np.array(ns, dtype=np.int32)
+        lds = np.array(lds, dtype=np.int64)
+        indets = np.array(indets, dtype=np.uint8)
+        data = np.array(addr, dtype=np.uint64)
+        sizes = ns.astype(np.int64) + ms
+        ends = np.cumsum(sizes)
+        starts = ends - sizes
+        masks = np.ones(max(int(ends[-1]), 1), dtype=np.uint8)
+        base = masks.ctypes.data
+        kres = (starts + base).astype(np.uint64)
+        kseq = (starts + ns + base).astype(np.uint64)
         infos = (TrimInfo * count)()
         rcs = np.zeros(count, dtype=np.int32)
         out = []
         with self._lock:
             if not self.h:
                 raise BatchClosed("the batch object is closed")
-            rc_all = self.lib.msa_trim_batch(self.h, count, data, ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, kres, kseq, infos, ptr(rcs))
+            rc_all = self.lib.msa_trim_batch(self.h, count, ptr(data), ptr(ms), ptr(ns), ptr(lds), ptr(indets), params, ptr(kres), ptr(kseq),
+                                             infos, ptr(rcs))
             if rc_all != OK and not rcs.any():  # the call itself was refused: no alignment was looked at
                 raise MsaError(rc_all, self.lib.msa_strerror(rc_all).decode())
-            for k, (pos, n, m) in enumerate(views):
+            flags = masks.view(np.bool_)  # (the library writes 0 / 1: the same bytes as booleans, no copy per alignment)
+            for k, pos, n, m, rc in zip(range(count), starts.tolist(), ns.tolist(), ms.tolist(), rcs.tolist()):
                 rows = []
                 if infos[k].warnings & W_ONLY_GAPS_SEQUENCES:
                     cnt = self.lib.msa_batch_only_gaps_rows(self.h, k, None, 0)
@@ -536,7 +546,7 @@ class Batch:
                         buf = np.empty(cnt, dtype=np.int32)
                         self.lib.msa_batch_only_gaps_rows(self.h, k, ptr(buf), cnt)
                         rows = [int(r) for r in buf]
-                out.append((masks[pos:pos + n].astype(bool), masks[pos + n:pos + n + m].astype(bool), infos[k], int(rcs[k]), rows))
+                out.append((flags[pos:pos + n], flags[pos + n:pos + n + m], infos[k], rc, rows))
         return out
 
     def check(self, rc, info):

@@ -208,7 +208,8 @@ class Alignment:
 
     def _dense(self):
         """The visible (kept) residues as a C-contiguous uint8 matrix."""
-        if self._seq_mask.all() and self._res_mask.all():
+        # (index arrays as long as the matrix: every sequence and residue is visible -- no reduction over the masks per call)
+        if len(self._seq_idx) == self._matrix.shape[0] and len(self._res_idx) == self._matrix.shape[1]:
             return self._matrix
         return np.ascontiguousarray(self._matrix[np.ix_(self._seq_idx, self._res_idx)])
 

@@ -41,6 +41,13 @@ def _close_batches():
 atexit.register(_close_batches)
 
 
+def close_batches():
+    """Close this process's native batch objects (worker threads, device contexts and arenas); the next `trim_batch` creates
+    new ones, which read the MSA_BATCH_* / MSA_* diagnostic switches again."""
+    with _BATCHES_LOCK:
+        _close_batches()
+
+
 def _native_batch(device_index, workers):
     from . import _lib
 

@@ -24,6 +24,7 @@ struct Tuning {
 };
 Tuning tuning_from_env();
 void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults
+const Tuning *current_tuning();    // what set_tuning last received on this thread
 const Tuning &tuning();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 int set_max_lds_once(const void *kernel, int bytes);
@@ -64,10 +65,47 @@ struct LgAlign {
     int32_t m, n, ldw, ncols;
 };
 int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out);
-int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int2 *items, int nitems, int max_m, int npos, const void *tab,
-                               bool with_state, int *launches_out);
+int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int32_t *colprefix, int K, int ncols_total, int max_m, int npos,
+                               const void *tab, bool with_state, int *launches_out);
 int lg_split(int m, int ncols, int cus);  // waves per column the launcher picks
+int lg_rounds_per_launch(int m);          // rounds per launch (0: everything in one launch)
 size_t lg_state_floats(int n);
+// One alignment of a batch as the batched kernels see it (device pointers): msa_trim_batch uploads a table of these and,
+// per kernel family, the prefix sums of its blocks per alignment; ONE launch per family serves the whole shard.
+struct BAlign {
+    const uint8_t *raw;       // [m][ld] residues
+    const uint8_t *fetch_src; // page-locked caller rows the device reads by itself (fetch_rows_batch_kernel), or null: a copy brings them
+    int64_t fetch_ld;         // their row stride
+    int64_t ld, ldk;
+    uint32_t *planes;
+    int32_t *gaps, *indets, *rowtot;
+    int32_t *flags;           // 16 words, the layout of a context's state block (ST_*): non-ASCII flag, undefined-identity flag,
+                              // first-bad-residue key (2), the two selectMethod means (2), the gate
+    float *ident, *w, *wlow, *wbar, *row_avg, *row_max;
+    uint8_t *codeT;
+    uint8_t *codeR;           // row-major codes [m][ld] (groups of small alignments: similarity_cols, a lane per column)
+    uint32_t *off;
+    uint16_t *trow;
+    int32_t *nvalid;
+    float *simnum, *simden, *mdk;  // mdk [n] followed by Q [n]
+    int32_t m, n, nchunk, m_pad, ldw, ncols_pad;
+    uint32_t indet4;
+    int32_t gated;            // automated1: the identity statistics decide on the device whether the similarity values are needed
+};
+int pair_tiles_pipe(int m, int m_pad);    // tiles of the pair pass in its one-row-per-lane regime
+bool pair_pipe_regime(int m, int m_pad);  // ... which launch_pair_counts picks for this shape (a batch holds no other)
+void launch_fetch_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_gap_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_row_nongap_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, const uint8_t *lut);
+void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab);
+void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *prefix_encode, int blocks_encode, const int32_t *prefix_compact,
+                            int blocks_compact, int K, const uint8_t *lut, int npos);
 void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar);
 int launch_similarity_seq(hipStream_t s, const uint8_t *codeT, int m, int n, const int32_t *cols, int ncols, const float *wup, int ldw,
                           const void *tab, float *num_out, float *den_out);

@@ -43,11 +43,11 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
 
 constexpr int PLANES_TOTAL = 8;
 
-__global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restrict__ raw, int m, int n,
-                                                          int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
-                                                          int nchunk, int m_pad, int *__restrict__ err_flag) {
-    const int row = blockIdx.y * 256 + threadIdx.x;  // < m_pad
-    const int cpair = blockIdx.x;                    // 64-column group (the x dimension: no 65 535 limit on the columns)
+__device__ __forceinline__ void prep_planes_body(const uint8_t *__restrict__ raw, int m, int n,
+                                                 int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
+                                                 int nchunk, int m_pad, int *__restrict__ err_flag, int bx, int by) {
+    const int row = by * 256 + threadIdx.x;  // < m_pad
+    const int cpair = bx;                    // 64-column group (the x dimension: no 65 535 limit on the columns)
     if (row >= m_pad) return;
     uint32_t out[2][8];
 #pragma unroll
@@ -92,6 +92,67 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
         }
     }
 }
+__global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restrict__ raw, int m, int n,
+                                                          int64_t ld, uint32_t indet4, uint32_t *__restrict__ planes,
+                                                          int nchunk, int m_pad, int *__restrict__ err_flag) {
+    prep_planes_body(raw, m, n, ld, indet4, planes, nchunk, m_pad, err_flag, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- batches: one launch per kernel family for every alignment of a shard (msa_trim_batch) -------------------------------
+// A table of BAlign descriptors in device memory and, per family, the prefix sums of its blocks per alignment: a block
+// finds its alignment by bisection (wave-uniform: scalar loads) and runs the single-alignment body on its descriptor.
+typedef const __attribute__((address_space(4))) int32_t *ci32p;
+__device__ __forceinline__ int batch_find(const int32_t *prefix_, int K, int idx, int &local) {
+    ci32p prefix = (ci32p)(uint64_t)prefix_;
+    int lo = 0, hi = K;  // prefix[lo] <= idx < prefix[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= idx) lo = mid;
+        else hi = mid;
+    }
+    local = idx - prefix[lo];
+    return lo;
+}
+__device__ __forceinline__ BAlign batch_desc(const BAlign *table, int a) {  // wave-uniform copy: scalar loads
+    typedef const __attribute__((address_space(4))) uint32_t *cw;
+    cw src = (cw)(uint64_t)(table + a);
+    uint32_t words[sizeof(BAlign) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(BAlign) / 4); ++i) words[i] = src[i];
+    BAlign d;
+    __builtin_memcpy(&d, words, sizeof(BAlign));
+    return d;
+}
+// Page-locked caller rows -> the device's pitched rows, read over the link by the kernel itself: ONE launch for every
+// alignment of a group instead of a copy each (a copy per 100 KB alignment costs the copy queue 8 us: 12 GB/s; with a few
+// thousand loads in flight the link runs at its rate).  A thread moves 16 bytes of a destination row; columns n .. ld are
+// written as zeros.  Alignments whose rows arrive by copy have fetch_src == nullptr: their blocks return at once.
+__global__ __launch_bounds__(256) void fetch_rows_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    if (!d.fetch_src) return;
+    const int64_t chunk = (int64_t)local * 256 + threadIdx.x;  // 16-byte chunk of the destination
+    const int per_row = (int)(d.ld / 16);
+    const int r = (int)(chunk / per_row), c = (int)(chunk % per_row) * 16;
+    if (r >= d.m) return;
+    const uint8_t *src = d.fetch_src + (size_t)r * d.fetch_ld + c;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (c + 16 <= d.n && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+        w[0] = s4[0], w[1] = s4[1], w[2] = s4[2], w[3] = s4[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (c + i < d.n) w[i >> 2] |= (uint32_t)src[i] << (8 * (i & 3));
+    }
+    *reinterpret_cast<uint4 *>(const_cast<uint8_t *>(d.raw) + (size_t)r * d.ld + c) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ __launch_bounds__(256) void prep_planes_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int nbx = (d.nchunk + 1) / 2;
+    prep_planes_body(d.raw, d.m, d.n, d.ld, d.indet4, d.planes, d.nchunk, d.m_pad, d.flags + 0, local % nbx, local / nbx);
+}
 
 // ------------------------------------------------------------------------------------------
 // gap_counts: per-column '-' and indetermination counts (statistics::Gaps::CalculateVectors).
@@ -100,13 +161,13 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint8_t *__restr
 // HBM-bound: reads m*n bytes once.
 // ------------------------------------------------------------------------------------------
 constexpr int GAP_SLAB = 64;
-__global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                         uint32_t indet4, int32_t *__restrict__ gaps,
-                                                         int32_t *__restrict__ indets) {
-    const int c4 = blockIdx.x * 256 + threadIdx.x;  // dword column
+__device__ __forceinline__ void gap_counts_body(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                uint32_t indet4, int32_t *__restrict__ gaps,
+                                                int32_t *__restrict__ indets, int bx, int by) {
+    const int c4 = bx * 256 + threadIdx.x;  // dword column
     const bool active = (int64_t)c4 * 4 < ld;
     if (active) {
-        const int r0 = blockIdx.y * GAP_SLAB;
+        const int r0 = by * GAP_SLAB;
         const int r1 = min(m, r0 + GAP_SLAB);
         const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)r0 * ld) + c4;
         const size_t stride = (size_t)(ld >> 2);
@@ -139,6 +200,17 @@ __global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restri
         }
     }
 }
+__global__ __launch_bounds__(256) void gap_counts_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         uint32_t indet4, int32_t *__restrict__ gaps,
+                                                         int32_t *__restrict__ indets) {
+    gap_counts_body(raw, m, n, ld, indet4, gaps, indets, (int)blockIdx.x, (int)blockIdx.y);
+}
+__global__ __launch_bounds__(256) void gap_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int nbx = (int)((d.ld / 4 + 255) / 256);
+    gap_counts_body(d.raw, d.m, d.n, d.ld, d.indet4, d.gaps, d.indets, local % nbx, local / nbx);
+}
 
 // ------------------------------------------------------------------------------------------
 // pair_counts: hit/dst of every sequence pair (Cleaner::calculateSeqIdentity ==
@@ -155,10 +227,9 @@ __device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) { re
 // unevenly spread over the SIMDs (every active wave is resident from the start: the fullest SIMD sets the time).
 // j-block y holds min(n_iblocks, (y + 1) R) tiles, R = 64 TJ / TI.
 template <int TI, int TJ>
-__device__ __forceinline__ void pair_tile(int n_iblocks, int &ib, int &jb) {
+__device__ __forceinline__ void pair_tile(int n_iblocks, int t, int &ib, int &jb) {
     {
         constexpr int R = 64 * TJ / TI;
-        const int t = blockIdx.x;
         const int jc = (n_iblocks + R - 1) / R - 1;  // first j-block whose row of tiles is cut off at n_iblocks
         const int pc = R * jc * (jc + 1) / 2;
         if (t < pc) {
@@ -271,7 +342,7 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
                                                          int *__restrict__ undef_flag, int n_iblocks) {
     const int lane = threadIdx.x;
     int ib, jb;
-    pair_tile<TI, TJ>(n_iblocks, ib, jb);
+    pair_tile<TI, TJ>(n_iblocks, (int)blockIdx.x, ib, jb);
     const int i0 = ib * TI;  // uniform
     const int j0 = jb * (64 * TJ);
     if (j0 >= m_pad) return;
@@ -292,16 +363,16 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
 //     other group -- one phase of the wave (and of the SIMD's other waves) covers its latency.
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 template <int TJ>
-__global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
-                                                              int m, int ldw, uint32_t *__restrict__ hit_out,
-                                                              uint32_t *__restrict__ dst_out, float *__restrict__ ident,
-                                                              float *__restrict__ wmat, float *__restrict__ wlow,
-                                                              int *__restrict__ undef_flag, int n_iblocks) {
+__device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                      int m, int ldw, uint32_t *__restrict__ hit_out,
+                                                      uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                      float *__restrict__ wmat, float *__restrict__ wlow,
+                                                      int *__restrict__ undef_flag, int n_iblocks, int tile) {
     constexpr int TI = 8;
     typedef const __attribute__((address_space(4))) u32x8 *c8;
     const int lane = threadIdx.x;
     int ib, jb;
-    pair_tile<TI, TJ>(n_iblocks, ib, jb);
+    pair_tile<TI, TJ>(n_iblocks, tile, ib, jb);
     const int i0 = ib * TI;  // uniform
     const int j0 = jb * (64 * TJ);
     if (j0 >= m_pad) return;
@@ -397,6 +468,21 @@ __global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__
     arrived(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
     pair_epilogue<TI, TJ>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
 }
+template <int TJ>
+__global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+                                                              int m, int ldw, uint32_t *__restrict__ hit_out,
+                                                              uint32_t *__restrict__ dst_out, float *__restrict__ ident,
+                                                              float *__restrict__ wmat, float *__restrict__ wlow,
+                                                              int *__restrict__ undef_flag, int n_iblocks) {
+    pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, n_iblocks, (int)blockIdx.x);
+}
+// (a batch holds alignments of the one-row-per-lane regime only -- below ~4100 sequences: pair_tiles_pipe)
+__global__ __launch_bounds__(64) void pair_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    pair_counts_pipe_body<1>(d.planes, d.nchunk, d.m_pad, d.m, d.ldw, nullptr, nullptr, d.ident, d.w, d.wlow, d.flags + 1,
+                             (d.m + PAIR_TI - 1) / PAIR_TI, local);
+}
 
 // (the identity row statistics -- selectMethod's sequential float32 sums -- live in msastat_simx.hip: they are
 // evaluated with the same binade-exact block test as the ordered rows of the similarity kernel)
@@ -408,10 +494,10 @@ __global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__
 // denormal range, where flush modes could differ) is not trusted: it goes out as a NaN and the host evaluates
 // (float)exp(-(double)Q) itself (fetch_similarity_finish).  Both libraries are accurate to an ulp, so every value that
 // passes the test rounds to the same float on both sides: MDK is bit-identical to the host computation by construction.
-__global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict__ num, const float *__restrict__ den,
-                                                         const int32_t *__restrict__ gaps_w, int m, int n,
-                                                         float *__restrict__ q_out, float *__restrict__ mdk_out, int all_on_host) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sim_finish_body(const float *__restrict__ num, const float *__restrict__ den,
+                                                const int32_t *__restrict__ gaps_w, int m, int n,
+                                                float *__restrict__ q_out, float *__restrict__ mdk_out, int all_on_host, int bx) {
+    const int c = bx * 256 + threadIdx.x;
     if (c >= n) return;
     const bool skip = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
     float q = 0.0f, v = 0.0f;
@@ -430,6 +516,18 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict
     }
     if (q_out) q_out[c] = q;
     mdk_out[c] = v;
+}
+__global__ __launch_bounds__(256) void sim_finish_kernel(const float *__restrict__ num, const float *__restrict__ den,
+                                                         const int32_t *__restrict__ gaps_w, int m, int n,
+                                                         float *__restrict__ q_out, float *__restrict__ mdk_out, int all_on_host) {
+    sim_finish_body(num, den, gaps_w, m, n, q_out, mdk_out, all_on_host, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void sim_finish_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                               int all_on_host) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    if (d.gated && d.flags[6]) return;  // (selectMethod took gappyout on the device: the similarity values are not used)
+    sim_finish_body(d.simnum, d.simden, d.gaps, d.m, d.n, d.mdk + d.n, d.mdk, all_on_host, local);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,10 +590,10 @@ __global__ __launch_bounds__(256) void overlap_rows_kernel(const uint8_t *__rest
 // ------------------------------------------------------------------------------------------
 // masked non-gap counts for Cleaner::removeAllGapsSeqsAndCols
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                         const uint8_t *__restrict__ keep_res,
-                                                         int32_t *__restrict__ row_nongap) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void row_nongap_body(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                const uint8_t *__restrict__ keep_res,
+                                                int32_t *__restrict__ row_nongap, int bx) {
+    const int row = bx * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row < m) {
         // 16 bytes per lane and load (rows are 64-byte aligned, ld % 64 == 0; keep_res has 64 bytes of slack); bytes at
@@ -518,6 +616,16 @@ __global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restri
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
         if (lane == 0) row_nongap[row] = cnt;
     }
+}
+__global__ __launch_bounds__(256) void row_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         const uint8_t *__restrict__ keep_res,
+                                                         int32_t *__restrict__ row_nongap) {
+    row_nongap_body(raw, m, n, ld, keep_res, row_nongap, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void row_nongap_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    row_nongap_body(d.raw, d.m, d.n, d.ld, nullptr, d.rowtot, local);
 }
 
 __global__ __launch_bounds__(256) void col_nongap_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
@@ -701,6 +809,7 @@ static inline uint32_t rep4(uint8_t b) { return 0x01010101u * b; }
 // ---- diagnostic switches ---------------------------------------------------------------------
 static thread_local const Tuning *tl_tuning = nullptr;
 void set_tuning(const Tuning *t) { tl_tuning = t; }
+const Tuning *current_tuning() { return tl_tuning; }
 const Tuning &tuning() {
     static const Tuning defaults;
     return tl_tuning ? *tl_tuning : defaults;
@@ -769,6 +878,33 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     const unsigned tiles = (unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib);
     if (two) pair_counts_kernel<PAIR_TI, 2><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
     else pair_counts_pipe_kernel<1><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
+}
+
+// tiles of the pair pass in its one-row-per-lane regime (launch_pair_counts; what a batch uses for every alignment)
+int pair_tiles_pipe(int m, int m_pad) {
+    const int nib = (m + PAIR_TI - 1) / PAIR_TI, njb = m_pad / 64;
+    const int R = 64 / PAIR_TI, jc = (nib + R - 1) / R - 1;
+    return R * jc * (jc + 1) / 2 + (njb - jc) * nib;
+}
+bool pair_pipe_regime(int m, int m_pad) { return (long)((m + PAIR_TI - 1) / PAIR_TI) * (m_pad / 128) / 2 < 8192; }
+
+void launch_fetch_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) fetch_rows_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_gap_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) gap_counts_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_row_nongap_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) row_nongap_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) prep_planes_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) pair_counts_batch_kernel<<<blocks, 64, 0, s>>>(table, prefix, K);
+}
+void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) sim_finish_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K, tuning().mdk_host);
 }
 
 void launch_sim_finish(hipStream_t s, const float *num, const float *den, const int32_t *gaps_w, int m, int n,

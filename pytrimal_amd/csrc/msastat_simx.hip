@@ -62,6 +62,19 @@ __device__ __forceinline__ P uniform_ptr(P p) {  // a pointer every lane agrees 
     return (P)(((uint64_t)hi << 32) | lo);
 }
 
+// (batches) the alignment a block belongs to: bisection over the prefix sums of blocks per alignment, wave-uniform
+typedef const __attribute__((address_space(4))) int32_t *ci32p;
+__device__ __forceinline__ int batch_find(const int32_t *prefix_, int K, int idx, int &local) {
+    ci32p prefix = (ci32p)(uint64_t)prefix_;
+    int lo = 0, hi = K;  // prefix[lo] <= idx < prefix[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= idx) lo = mid;
+        else hi = mid;
+    }
+    local = idx - prefix[lo];
+    return lo;
+}
 __device__ __forceinline__ float rl(float v, int lane) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
 }
@@ -721,15 +734,14 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
 // ({alignment, column} per work item -- msa_trim_batch's launch over every column of every alignment of a shard).
 template <bool STAMP, bool BIG, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 64 * LG_SPLIT_MAX : 64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5)))
-void similarity_lg_kernel(LgAlign one, const LgAlign *__restrict__ table, const int2 *__restrict__ items, int nitems, int nr, int r0,
+void similarity_lg_kernel(LgAlign one, const LgAlign *__restrict__ table, const int32_t *__restrict__ items, int nitems, int nr, int r0,
                           const float *__restrict__ tab_g, int jbegin, int jend) {
     const int ci = SPLIT ? (int)blockIdx.x : blockIdx.x * (int)(blockDim.x >> 6) + uni(threadIdx.x >> 6);
     int col = -1;
     if (table) {
         if (ci < nitems) {
-            const int2 it = items[ci];
-            const int a = uni(it.x);
-            col = uni(it.y);
+            // (a batch: `items` = the prefix sums of the alignments' column counts, `one.ncols` alignments)
+            const int a = batch_find(reinterpret_cast<const int32_t *>(items), one.ncols, ci, col);
             // (wave-uniform copy of the descriptor: scalar loads)
             cu32p src = (cu32p)(uint64_t)(table + a);
             uint32_t words[sizeof(LgAlign) / 4];
@@ -784,9 +796,9 @@ __global__ __launch_bounds__(64) void similarity_seq_kernel(const uint8_t *__res
 
 // wbar[j] = mean of W[j][k] over k > j (the upper triangle of a row; 0 for the last row): the similarity kernel's
 // predictor scales its per-row estimates with it.  Any order of summation: it is an estimate, nothing exact hangs on it.
-__global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar) {
+__device__ __forceinline__ void w_row_means_body(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar, int bx) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = bx * 4 + (threadIdx.x >> 6);
     if (j >= m + 64) return;
     float s = 0.0f;
     if (j < m) {
@@ -797,6 +809,9 @@ __global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restric
     }
     if (lane == 0) wbar[j] = (j < m - 1) ? s / (float)(m - 1 - j) : 0.0f;  // (rows m .. m + 63: zeros, a round reads past the end)
 }
+__global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar) {
+    w_row_means_body(wup, m, ldw, wbar, (int)blockIdx.x);
+}
 
 // ---- identity row statistics (Cleaner::calculateSeqIdentity's consumers: selectMethod, getCutPointClusters) --------
 // Per sequence: the float32 sum of its identities with every other sequence IN INDEX ORDER (/ (m - 1)), their
@@ -804,11 +819,11 @@ __global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restric
 // >= 0, so the sequential sums are evaluated a chunk of 256 terms at a time with the binade test of the similarity
 // kernel's ordered rows (chunk_step): one wave per sequence instead of one dependent add chain per lane (83 + 24 us
 // -> a few us at m = 2000), bit-identical.
-__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
-                                                            float *__restrict__ row_avg, float *__restrict__ row_max,
-                                                            float *__restrict__ row_min) {
+__device__ __forceinline__ void identity_rows_body(const float *__restrict__ ident, int m, int ldw,
+                                                   float *__restrict__ row_avg, float *__restrict__ row_max,
+                                                   float *__restrict__ row_min, int bx) {
     const int lane = threadIdx.x & 63;
-    const int i = uni((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int i = uni((int)(bx * 4 + (threadIdx.x >> 6)));
     if (i >= m) return;
     const float *r = ident + (size_t)i * ldw;  // ident[i][j] == ident[j][i]
     float s = 0.0f, mx = 0.0f, mn = 1.0f;      // (getCutPointClusters starts its minimum at 1)
@@ -839,12 +854,17 @@ __global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restr
         if (row_min) row_min[i] = mn;
     }
 }
+__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+                                                            float *__restrict__ row_avg, float *__restrict__ row_max,
+                                                            float *__restrict__ row_min) {
+    identity_rows_body(ident, m, ldw, row_avg, row_max, row_min, (int)blockIdx.x);
+}
 
 // (two waves: one per sum.  gate != nullptr: Cleaner::selectMethod's decision is taken here as well -- *gate = 1 when it
 // selects gappyout, i.e. the similarity kernel enqueued behind this one has nothing to do; the host takes the same
 // decision from the same two numbers when they arrive)
-__global__ __launch_bounds__(128) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
-                                                             int m, float *__restrict__ out2, int *__restrict__ gate) {
+__device__ __forceinline__ void identity_final_body(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                    int m, float *__restrict__ out2, int *__restrict__ gate) {
     __shared__ float res[2];
     const int lane = threadIdx.x & 63;
     const int which = uni((int)(threadIdx.x >> 6));
@@ -876,16 +896,20 @@ __global__ __launch_bounds__(128) void identity_final_kernel(const float *__rest
         *gate = sel == 1 ? 1 : 0;
     }
 }
+__global__ __launch_bounds__(128) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                             int m, float *__restrict__ out2, int *__restrict__ gate) {
+    identity_final_body(row_avg, row_max, m, out2, gate);
+}
 
 // codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W (or its
 // index: `big`) and byte offset of its residue's row in the per-wave table; padded behind the last valid row with
 // {zero row m, the table's zero row}.  6 bytes per residue (round 2 also kept the row index and the code for the
 // ordered rows, which now read the column densely: 9 bytes).
-__global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
-                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
-                                                         int skiprow, int32_t *__restrict__ nvalid, int big) {
+__device__ __forceinline__ void bx_compact_body(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
+                                                uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
+                                                int skiprow, int32_t *__restrict__ nvalid, int big, int bx) {
     const int lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col = bx * 4 + (threadIdx.x >> 6);
     if (col >= ncols_pad) return;
     const uint8_t *src = codeT + (size_t)col * ldk;
     uint32_t *po = voff + (size_t)col * ldk;
@@ -908,24 +932,29 @@ __global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restri
     }
     if (lane == 0) nvalid[col] = count;
 }
+__global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
+                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
+                                                         int skiprow, int32_t *__restrict__ nvalid, int big) {
+    bx_compact_body(codeT, ldk, m, ncols_pad, ldw4, voff, vtrow, skiprow, nvalid, big, (int)blockIdx.x);
+}
 
 // raw bytes -> column-major codes (64 x 64 tiles through LDS); first bad residue through atomicMin as in the
 // other encode kernels.  Columns cut by the ">= 80 % gaps" rule and all padding hold BX_SKIP.
-__global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                            const uint8_t *__restrict__ lut_g,
-                                                            const int32_t *__restrict__ gaps_w, uint8_t *__restrict__ codeT,
-                                                            int64_t ldk, int ncols_pad,
-                                                            unsigned long long *__restrict__ err_key) {
+__device__ __forceinline__ void sim_encode_cm_body(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                   const uint8_t *__restrict__ lut_g,
+                                                   const int32_t *__restrict__ gaps_w, uint8_t *__restrict__ codeT,
+                                                   int64_t ldk, int ncols_pad,
+                                                   unsigned long long *__restrict__ err_key, int bx, int by) {
     __shared__ uint8_t lut[256];
     __shared__ uint8_t tile[64][68];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int c = bx * 64 + tx;
     bool skipcol = true;
     if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
     for (int r = ty; r < 64; r += 4) {
-        const int row = blockIdx.y * 64 + r;
+        const int row = by * 64 + r;
         uint32_t code = BX_SKIP;
         if (row < m && c < n && !skipcol) {
             const uint32_t byte = raw[(size_t)row * ld + c];
@@ -940,11 +969,165 @@ __global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__res
         tile[r][tx] = (uint8_t)code;
     }
     __syncthreads();
-    const int64_t k = (int64_t)blockIdx.y * 64 + tx;
+    const int64_t k = (int64_t)by * 64 + tx;
     for (int q = ty; q < 64; q += 4) {
-        const int col = blockIdx.x * 64 + q;
+        const int col = bx * 64 + q;
         if (col < ncols_pad && k < ldk) codeT[(size_t)col * ldk + k] = tile[tx][q];
     }
+}
+
+__global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                            const uint8_t *__restrict__ lut_g,
+                                                            const int32_t *__restrict__ gaps_w, uint8_t *__restrict__ codeT,
+                                                            int64_t ldk, int ncols_pad,
+                                                            unsigned long long *__restrict__ err_key) {
+    sim_encode_cm_body(raw, m, n, ld, lut_g, gaps_w, codeT, ldk, ncols_pad, err_key, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- batches (msa_trim_batch): the kernels above for every alignment of a shard in one launch each -- a table of BAlign
+// descriptors, a block finds its alignment by bisection over the family's prefix sums of blocks (msastat_kernels.hip) ----
+__device__ __forceinline__ BAlign batch_desc(const BAlign *table, int a) {  // wave-uniform copy: scalar loads
+    cu32p src = (cu32p)(uint64_t)(table + a);
+    uint32_t words[sizeof(BAlign) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(BAlign) / 4); ++i) words[i] = src[i];
+    BAlign d;
+    __builtin_memcpy(&d, words, sizeof(BAlign));
+    return d;
+}
+__global__ __launch_bounds__(256) void w_row_means_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    w_row_means_body(d.w, d.m, d.ldw, d.wbar, local);
+}
+__global__ __launch_bounds__(256) void identity_rows_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    if (!d.gated) return;  // (only automated1 needs the identity statistics)
+    identity_rows_body(d.ident, d.m, d.ldw, d.row_avg, d.row_max, nullptr, local);
+}
+__global__ __launch_bounds__(128) void identity_final_batch_kernel(const BAlign *__restrict__ table) {  // a block per alignment
+    const BAlign d = batch_desc(table, (int)blockIdx.x);
+    if (!d.gated) return;
+    identity_final_body(d.row_avg, d.row_max, d.m, reinterpret_cast<float *>(d.flags + 4), d.flags + 6);
+}
+__global__ __launch_bounds__(256) void sim_encode_cm_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                  const uint8_t *__restrict__ lut_g) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int nbx = d.ncols_pad / 64;
+    sim_encode_cm_body(d.raw, d.m, d.n, d.ld, lut_g, d.gaps, d.codeT, d.ldk, d.ncols_pad,
+                       reinterpret_cast<unsigned long long *>(d.flags + 2), local % nbx, local / nbx);
+}
+// ---- small alignments in a batch: one LANE per column ---------------------------------------------------------------------
+// A column of 100 rows is a dozen binade crossings and a prologue around two rounds of 64 rows: the wave-per-column kernel
+// spends 50 us on it, nearly all of it in ordered rows.  With thousands of such columns in one launch (a batch of small
+// alignments: 10^5 - 10^6 columns) the statistic as the reference writes it is the better kernel: a lane per column, the two
+// nested loops, one add after the other -- W[j][k] is the same for the 64 columns of a wave (a scalar load), their codes of
+// row k are 64 consecutive bytes of a ROW-major code array, the {distance, valid} pair comes from the LDS table; 5 VALU
+// instructions per step for 64 pairs, no prologue, no stitching, and enough waves to hide the add latency.  m * m / 2 steps per
+// wave against ~170 000 cycles of fixed cost per column.  The wave's codes are staged in LDS (64 columns x m bytes, four codes
+// to a dword), the weights of a row arrive sixteen per scalar load: up to 128 rows (msa_trim_batch picks per group).
+__global__ __launch_bounds__(256) void sim_encode_rm_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                  const uint8_t *__restrict__ lut_g) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    // a block = 256 columns x 16 rows
+    const int nbx = (int)((d.ld + 255) / 256);
+    const int c = (local % nbx) * 256 + (int)threadIdx.x, r0 = (local / nbx) * 16;
+    if (c >= d.ld) return;
+    const bool skipcol = c >= d.n || (((float)d.gaps[c] / (float)d.m) >= 0.8f);
+    for (int r = r0; r < min(d.m, r0 + 16); ++r) {
+        uint32_t code = BX_SKIP;
+        if (!skipcol) {
+            const uint32_t byte = d.raw[(size_t)r * d.ld + c];
+            code = lut[byte];
+            if (code >= 0xFEu) {
+                const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)r << 16) |
+                                               ((unsigned long long)(code & 1u) << 8) | byte;
+                atomicMax(reinterpret_cast<unsigned long long *>(d.flags + 2), ~key);
+                code = BX_SKIP;
+            }
+        }
+        d.codeR[(size_t)r * d.ld + c] = (uint8_t)code;
+    }
+}
+
+constexpr int COLS_MAX_M = 128;  // rows of an alignment the lane-per-column kernel takes (its code tiles live in LDS)
+__global__ __launch_bounds__(256) void similarity_cols_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                    int total, const float *__restrict__ tab_g) {
+    __shared__ f2 tab[32 * 32];  // {distance, both valid}[row code][column code], rows 28.. zero
+    // the wave's 64 columns x m codes, [lane][k] packed four to a dword; 33 dwords per lane: lanes on different banks
+    __shared__ uint32_t tile[4][64][COLS_MAX_M / 4 + 1];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
+        f2 v = {0.0f, 0.0f};
+        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
+        tab[i] = v;
+    }
+    __syncthreads();
+    const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const int item = (int)blockIdx.x * 4 + wave;  // a wave = 64 columns of one alignment
+    if (item >= total) return;
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, item, local));
+    if (d.gated && d.flags[6]) return;  // (selectMethod took gappyout on the device)
+    const int c = local * 64 + lane, m = d.m;
+    const bool in = c < d.n;
+    const int64_t ld = d.ld;
+    const gu8p code = (gu8p)(uint64_t)(d.codeR + (in ? c : 0));
+    uint32_t *mine = tile[wave][lane];
+    for (int k4 = 0; k4 < COLS_MAX_M / 4 + 1; ++k4) {  // (rows behind m: codes that take no part)
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * k4 + i;
+            const uint32_t ck = (in && k < m) ? (uint32_t)code[(size_t)k * ld] : BX_SKIP;
+            packed |= ck << (8 * i);
+        }
+        mine[k4] = packed;
+    }
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) f16v *c16;
+    float num = 0.0f, den = 0.0f;
+    for (int j = 0; j + 1 < m; ++j) {
+        const uint32_t cj = (mine[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (cj == BX_SKIP) continue;
+        const float *wr = d.w + (size_t)j * d.ldw;  // the row's weights: the same for every column (scalar loads, 16 at a time)
+        const ldsp row = tabp + (cj << 5);
+        // (chunks of 16 partners from the one that holds row j + 1: W[j][k <= j] = 0, the upper triangle is strict, and a
+        // product with it adds +0 to either sum)
+        for (int kb = (j + 1) & ~15; kb < m; kb += 16) {
+            const f16v w = *(c16)(uint64_t)(wr + kb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c4 = mine[(kb >> 2) + q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t ck = (c4 >> (8 * i)) & 0xFFu;
+                    const f2 de = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(row + ck);
+                    const float wk = w[4 * q + i];
+                    const float x = wk * de.x, y = wk * de.y;
+                    num = num + x;
+                    den = den + y;
+                }
+            }
+        }
+    }
+    if (in) {
+        d.simnum[c] = num;
+        d.simden[c] = den;
+    }
+}
+
+__global__ __launch_bounds__(256) void bx_compact_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                               int skiprow, int big) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    bx_compact_body(d.codeT, d.ldk, d.m, d.ncols_pad, (uint32_t)d.ldw * 4u, d.off, d.trow, skiprow, d.nvalid, big, local);
 }
 
 }  // namespace
@@ -1003,7 +1186,7 @@ int lg_split(int m, int ncols, int cus) {
 
 // one alignment (`one.cols` lists the `one.ncols` columns to evaluate), or a batch (`table`, `items`: device memory).
 // *launches_out: kernel launches issued.
-static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, const int2 *items, int nitems, int max_m, int ldw_for_big,
+static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, const int32_t *items, int nitems, int max_m, int ldw_for_big,
                      int npos, const void *tab, bool with_state, int split, int *launches_out) {
     const int r0 = tuning().lg_r0 >= 0 ? tuning().lg_r0 : LG_R0;
     const int nr = npos + 1;  // table rows per wave in LDS: the alphabet + the zero row
@@ -1049,12 +1232,35 @@ int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void
     return launch_lg(s, one, nullptr, nullptr, one.ncols, one.m, one.ldw, npos, tab, one.state != nullptr, split, launches_out);
 }
 
-// every column of every alignment of a shard in one grid (a wave per column): `table` and `items` in device memory; the
-// alignments' m <= max_m, byte offsets in every list (the caller keeps alignments beyond 32768 rows out of a batch)
-int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int2 *items, int nitems, int max_m, int npos, const void *tab,
-                               bool with_state, int *launches_out) {
+// every column of every alignment of a shard in one grid (a wave per column, in the alignments' own column order: a
+// column the ">= 80 % gaps" rule cuts has no valid row and costs its wave a histogram pass): `table` and `colprefix` (K + 1
+// prefix sums of the alignments' column counts) in device memory; the alignments' m <= max_m, byte offsets in every list
+// (the caller keeps alignments beyond 32768 rows out of a batch)
+int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int32_t *colprefix, int K, int ncols_total, int max_m, int npos,
+                               const void *tab, bool with_state, int *launches_out) {
     LgAlign none = {};
-    return launch_lg(s, none, table, items, nitems, max_m, 64, npos, tab, with_state, 1, launches_out);
+    none.ncols = K;
+    return launch_lg(s, none, table, colprefix, ncols_total, max_m, 64, npos, tab, with_state, 1, launches_out);
+}
+
+void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) w_row_means_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) identity_rows_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+    if (K > 0) identity_final_batch_kernel<<<K, 128, 0, s>>>(table);
+}
+void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, const uint8_t *lut) {
+    if (blocks > 0) sim_encode_rm_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K, lut);
+}
+// prefix: 64-column groups per alignment; total = their number
+void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab) {
+    if (total > 0) similarity_cols_batch_kernel<<<(total + 3) / 4, 256, 0, s>>>(table, prefix, K, total, static_cast<const float *>(tab));
+}
+void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *prefix_encode, int blocks_encode, const int32_t *prefix_compact,
+                            int blocks_compact, int K, const uint8_t *lut, int npos) {
+    if (blocks_encode > 0) sim_encode_cm_batch_kernel<<<blocks_encode, 256, 0, s>>>(table, prefix_encode, K, lut);
+    if (blocks_compact > 0) bx_compact_batch_kernel<<<blocks_compact, 256, 0, s>>>(table, prefix_compact, K, npos, tuning().lg_big != 0 ? 1 : 0);
 }
 
 // mean weight of every row over its later partners (m + 64 floats): the similarity kernel's predictor reads it

@@ -142,8 +142,8 @@ class BaseTrimmer:
             # an alignment that is trimmed again (another trimmer, another setting): its rows are page-locked from the
             # second trim on -- every further upload is one DMA copy from where they lie -- until the matrix dies or the
             # process-wide budget needs the room (PYTRIMAL_AMD_PIN_MB, least recently uploaded first; 0 = never)
-            alignment._uploads = min(getattr(alignment, "_uploads", 0) + 1, 2)
-            if alignment._uploads == 2:
+            uploads = alignment._uploads = getattr(alignment, "_uploads", 0) + 1
+            if uploads == 2 or not uploads & 15:  # (and again now and then: the budget may have unpinned it since)
                 _lib.pin_array(dense)
         ty = alignment._alignment_type()
         indet = ord("X") if (ty & 4) else ord("N")
@@ -153,13 +153,22 @@ class BaseTrimmer:
                 matrix = _default_matrix("aa")
             else:
                 matrix = _default_matrix("ntdeg" if ty & 8 else "nt")
-        params = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
-        self._configure(params)
-        vhash, dist = matrix._device_arrays()
-        params.vhash = vhash.ctypes.data_as(ctypes.c_void_p)
-        params.dist = dist.ctypes.data_as(ctypes.c_void_p)
-        params.npos = len(matrix)
-        return alignment.names, dense, indet, params, (vhash, dist, matrix)
+        # the parameter block of this trimmer for this matrix: filled once, copied per alignment (trim_batch prepares
+        # thousands of small alignments per call)
+        cache = self.__dict__.setdefault("_params_cache", {})
+        entry = cache.get(id(matrix))
+        if entry is None or entry[2] is not matrix:
+            template = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
+            self._configure(template)
+            vhash, dist = matrix._device_arrays()
+            template.vhash = vhash.ctypes.data_as(ctypes.c_void_p)
+            template.dist = dist.ctypes.data_as(ctypes.c_void_p)
+            template.npos = len(matrix)
+            if len(cache) > 64:
+                cache.clear()
+            entry = cache[id(matrix)] = (bytes(template), (vhash, dist, matrix), matrix)
+        params = _lib.TrimParams.from_buffer_copy(entry[0])
+        return alignment.names, dense, indet, params, entry[1]
 
     @staticmethod
     def _finish(names, dense, datatype, keep_res, keep_seq, info, only_gaps_rows, gaps_w, params):

@@ -156,6 +156,44 @@ def test_native_batch_equals_one_by_one():
         assert [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)] == ["Removing sequence 'x' composed only by gaps"]
 
 
+@pytest.mark.parametrize("cols_max", ["", "0"])
+def test_batch_engine_against_single_trims(monkeypatch, cols_max):
+    """`msa_trim_batch`'s engine (one launch per kernel family for a whole group of alignments, the selection on host-only
+    views) on 60 alignments of random shapes up to 500 x 900 with gap-heavy rows and columns, four trimmers it takes --
+    against one trim at a time, which goes through an ordinary context.  cols_max: the row count up to which a group's
+    similarity statistic runs with a lane per column (default 128; 0: the wave-per-column kernel for every group)."""
+    import warnings
+
+    from pytrimal_amd import ManualTrimmer, _lib
+    from pytrimal_amd import batch as batch_mod
+    from pytrimal_amd.batch import trim_batch
+
+    if cols_max:
+        monkeypatch.setenv("MSA_BATCH_COLS_MAX", cols_max)
+    batch_mod.close_batches()  # (the library reads the switch when the batch object is created)
+    rng = np.random.default_rng(77)
+    alis = []
+    for k in range(60):
+        m, n = (int(rng.integers(2, 500)) if k % 2 else int(rng.integers(2, 130))), int(rng.integers(1, 900))
+        a = synth_msa(m, n, 3000 + k)
+        if k % 5 == 0:  # rows that are nearly all gaps: the trimming may leave them empty (the host-side pass over the rows)
+            a[rng.integers(0, m, max(1, m // 10)), :] = ord("-")
+            a[0, : max(1, n // 50)] = ord("A")
+        if k % 7 == 0:
+            a[:, rng.integers(0, n, max(1, n // 4))] = ord("-")
+        alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in np.ascontiguousarray(a)]))
+    for trimmer in (AutomaticTrimmer("strict", platform="hip"), AutomaticTrimmer("automated1", platform="hip"),
+                    AutomaticTrimmer("strictplus", platform="hip"), ManualTrimmer(similarity_threshold=0.3, platform="hip")):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(2):  # (the second call reuses the arenas: nothing of the first may leak into it)
+                out = trim_batch(trimmer, alis, threads=3)
+            single = [trimmer.trim(x) for x in alis]
+        for k, (t, s1) in enumerate(zip(out, single)):
+            assert t.residues_mask == s1.residues_mask and t.sequences_mask == s1.sequences_mask, (repr(trimmer), k)
+    batch_mod.close_batches()
+
+
 def test_two_ranks_share_one_gpu():
     """`trim_batch` under a two-rank process group, both ranks on this box's one GPU (gloo carries the gather: RCCL needs
     a GPU per rank): the sharding over ranks, a native batch object per rank and the gather of the masks, against the
