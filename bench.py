@@ -39,10 +39,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
-# the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane loads of L2-resident rows, measured with
-# tools/ubench_wstream.hip on an MI355X (profiles/r03_ubench_wstream.txt): global_load_dword 29 - 30 TB/s chip-wide
-# (5.3 CU-cycles per wave-load at the nominal clock; buffer_load_dword with an SGPR row offset: 18.3 TB/s, 8.6 cycles)
-W_STREAM_PEAK_GBS = 29700.0
+# the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane loads of L2-resident rows through a list of row
+# offsets, 16 in flight, in EXACTLY the form the kernel issues (row base in an SGPR pair by s_add_u32 / s_addc_u32, lane offset
+# in a VGPR, hand-counted vmcnt), five waves per SIMD, measured with tools/ubench_wform.hip on an MI355X
+# (profiles/r04_ubench_wform.txt): 29.0 TB/s chip-wide = 5.03 CU-cycles per wave-load at the 2.22 GHz the chip ran it at; every
+# other address form (constant base + VALU offset, 64-bit per-lane address by v_add_co / v_mad_u64_u32 / v_lshl_add_u64) measures
+# the same within 2 %; with the kernel's three VALU instructions per step beside the loads 27.7 TB/s
+W_STREAM_PEAK_GBS = 29000.0
+W_STREAM_PEAK_WITH_VALU_GBS = 27700.0
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 -> L1 bandwidth figure of the guide
 
 
 def similarity_w_stream_bytes(a, indet=ord("X")):
@@ -148,9 +153,22 @@ def host_info():
     return info
 
 
+def physical_cores():
+    """Physical cores of the host (lscpu: sockets x cores per socket), or None."""
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        vals = {}
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            vals[k.strip()] = v.strip()
+        return int(vals["Socket(s)"]) * int(vals["Core(s) per socket"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(a, trimmer_kw, ncols, value, with_similarity=True):
-    """The CPU oracle on one host core (scalar port, then the AVX2 flavour of its two pairwise passes), and the
-    scalar port on every host core, on the first `ncols` columns of the workload's alignment."""
+    """The CPU oracle on one host core (scalar port, then the AVX2 flavour of its two pairwise passes), and -- the
+    reference's own idiom for many cores, README.md:136-152 -- a thread pool over WHOLE alignments, one per thread."""
     import oracle
 
     m, n = a.shape
@@ -193,18 +211,23 @@ def cpu_baseline(a, trimmer_kw, ncols, value, with_similarity=True):
     speedups = {"speedup_vs_cpu_1core": round(value / (ncols / best[1]), 1)}
     cores = os.cpu_count() or 1
     if cores > 1:
+        # the reference's batch idiom (README.md:136-152: ThreadPool.map(trimmer.trim, alignments), the trim releases the
+        # interpreter lock): a pool over whole alignments, here one copy of the workload's first `per` columns per thread, as
+        # many threads as the host has physical cores (at most 64)
         from multiprocessing.pool import ThreadPool
 
-        per = min(256, n)
-        base = [np.ascontiguousarray(a[:, i * per:(i + 1) * per]) for i in range(max(1, n // per))]
-        threads = min(cores, 48)  # the port saturates there on the 2 x 64-core host (profiles/r01_cpu_port_scaling.txt)
-        slices = [base[i % len(base)] for i in range(threads)]
+        phys = physical_cores()
+        threads = max(2, min(phys or cores // 2, 64))
+        per = min(1000, n)
+        copies = [np.ascontiguousarray(a[:, :per]).copy() for _ in range(threads)]
         t0 = time.perf_counter()
         with ThreadPool(threads) as pool:
-            pool.map(lambda x: oracle.trim(x, **trimmer_kw), slices)
+            pool.map(lambda x: oracle.trim(x, **trimmer_kw), copies)
         all_s = time.perf_counter() - t0
         out["all_cores"] = {"value": round(threads * per / all_s, 2), "unit": "columns/s", "cores": threads, "kind": "port-scalar",
-                            "sample": f"{threads} threads x {per} columns each (host reports {cores} logical CPUs), {all_s:.1f} s"}
+                            "physical_cores": phys, "logical_cpus": cores,
+                            "sample": f"a thread pool over {threads} whole alignments ({m} sequences x the first {per} columns each), one per "
+                                      f"thread: the reference's ThreadPool.map(trimmer.trim, alignments) idiom; {all_s:.1f} s"}
         speedups["speedup_vs_cpu_all_cores"] = round(value / (threads * per / all_s), 1)
     return out, speedups
 
@@ -368,6 +391,11 @@ def main():
     ctx = _lib.Context(local_rank)
     params = params_for(args.workload)
     kernels, resident_s, public_api_s, info, units_per_step, single_gpu_s = {}, None, None, None, None, None
+    pageable_s, cold_s, ranks_seen = None, None, world
+    if dist is not None:  # the ranks that really take part in the timed process group
+        t = torch.ones(1, dtype=torch.float64, device="cpu" if args.share_gpu else device)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
 
     if args.workload == "C5":
         from pytrimal_amd.batch import trim_batch
@@ -503,6 +531,27 @@ def main():
         public_api_s = max_over_ranks(time.perf_counter() - t0)
         assert np.array_equal(api_masks._res_mask, keep_res) and np.array_equal(api_masks._seq_mask, keep_seq)
         kept = int(info.kept_residues)
+        # ... from PAGEABLE rows (a copy of the alignment that was never page-locked: what a load-then-trim-once pipeline hands
+        # over), and COLD: the first trim of a fresh Alignment through the public API (pageable rows, a context that last saw
+        # another alignment), one fresh object per sample
+        pageable = a.copy()
+        ctx.upload(pageable, ord("X"), pin=False, wait=False)
+        ctx.trim(params)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.upload(pageable, ord("X"), pin=False, wait=False)
+            ctx.trim(params)
+        fence()
+        pageable_s = max_over_ranks(time.perf_counter() - t0)
+        cold = []
+        for _ in range(5):
+            fresh = Alignment(ali.names, [bytes(r) for r in a])
+            fence()
+            t0 = time.perf_counter()
+            trimmer_obj.trim(fresh)
+            cold.append(time.perf_counter() - t0)
+        cold_s = max_over_ranks(float(np.median(cold)))
 
     for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "overlap", "cluster"):
         ms, launches = ctx.prof_get(name)
@@ -526,8 +575,13 @@ def main():
                     tj = json.load(f)
                 traffic = tj.get(f"{args.workload}:{dom}")
                 traffic_source = tj.get("_source", "profiles/traffic.json (builder PMC pass, not measured in this run)")
+            # what really bounds the dominant kernel (`achieved` / `peak` / `frac` stay the HBM figures of the contract:
+            # algorithmic bytes per pass over the pass's time against the HBM peak)
+            bound = {"sim": "vector-L1 / texture addresser (256-byte wave-loads of L2-resident W rows: roofline.w_stream); HBM carries "
+                            "0.2 % of its peak",
+                     "pairs": "VALU issue (bit-sliced compare + popcount: roofline.valu)"}.get(dom, "hbm")
             roofline = {
-                "kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": dom, "bound": bound, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": alg, "ms_avg": round(kernels[dom]["ms_avg"], 4),
             }
@@ -548,7 +602,10 @@ def main():
                              "(texture addresser 92 % busy at the clock the kernel runs at: profiles/r03_pmc_sq.txt)",
                     "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
-                    "peak_source": "tools/ubench_wstream.hip on one MI355X (profiles/r03_ubench_wstream.txt), not measured in this run",
+                    "frac_of_peak_with_the_loop_valu_work": round(rate / W_STREAM_PEAK_WITH_VALU_GBS, 4),
+                    "frac_of_l2_peak": round(rate / L2_PEAK_GBS, 4), "l2_peak": L2_PEAK_GBS,
+                    "peak_source": "tools/ubench_wform.hip, form 0 = the address form the kernel ships (SGPR row base + VGPR lane offset, "
+                                   "hand-issued), five waves per SIMD, on one MI355X (profiles/r04_ubench_wform.txt); not measured in this run",
                 }
             if dom in ("sim", "pairs"):
                 # the pairwise passes are VALU-issue work, not bandwidth: one "pair-column" = one (j, k, column) term
@@ -594,7 +651,7 @@ def main():
                 "selected_method": {1: "gappyout", 2: "strict"}.get(info.selected_method) if info is not None else None,
                 "avg_seq": round(float(info.avg_seq), 6) if info is not None else None,
                 "max_seq": round(float(info.max_seq), 6) if info is not None else None,
-                "kept_columns": kept, "ranks": world,
+                "kept_columns": kept, "ranks": world, "ranks_seen": ranks_seen,
                 "parallelism": (f"batch of {C5_BATCH} sharded over {world} rank(s) x 4 threads" if args.workload == "C5"
                                 else f"replicas x{world} (alignment per rank)"),
             },
@@ -614,6 +671,20 @@ def main():
         if public_api_s is not None:
             out["value_public_api"] = round(units_per_step * args.steps / public_api_s, 2)
             out["ms_per_step_public_api"] = round(public_api_s / args.steps * 1e3, 4)
+        if args.workload != "C5":
+            out["rows_page_locked"] = True  # (value / ms_per_step: the rows were registered once, before the timed steps)
+        if pageable_s is not None:
+            out["value_pageable_rows"] = round(units_per_step * args.steps / pageable_s, 2)
+            out["ms_per_step_pageable_rows"] = round(pageable_s / args.steps * 1e3, 4)
+        if cold_s is not None:
+            out["value_cold"] = round(units_per_step / cold_s, 2)
+            out["ms_cold"] = round(cold_s * 1e3, 4)
+            out["value_cold_note"] = ("median of five FIRST trims, each of a fresh Alignment object through the public API: pageable rows, no "
+                                      "registration (the Python layer page-locks an alignment's rows on its second trim: hipHostRegister, "
+                                      "0.1 - 0.6 ms for 4 - 20 MB, profiles/r03_upload.txt)")
+        if args.workload == "C5":
+            out["config"]["kept_columns_expected"] = 192501  # (tests/golden/configs.npz: the 64 masks of config 5)
+            out["config"]["kept_columns_ok"] = kept == 192501
         if not args.no_cpu_baseline and world == 1:
             sample = synth_msa(m, n, seed) if args.workload == "C5" else a
             ncols = args.cpu_sample_cols if args.workload != "C4" else min(args.cpu_sample_cols, 600)

@@ -387,18 +387,25 @@ class TrimmedAlignment(Alignment):
 
         ``Cleaner::removeOnlyTerminal`` (``/root/reference/src/pytrimal/_trimal.pyx:1144-1157``,
         ``include/trimal/cleaner.pxd:38``).  **Unverified**: the body is not in the reference tree and no fixture
-        of the reference exercises it; this follows the recalled upstream behaviour [R].  A
-        trimmed alignment shares the gap statistics of the alignment it was trimmed from, so the boundaries are the
-        first and the last column without gaps in the gap vector of the ORIGINAL alignment -- every sequence,
-        whatever the trimmer kept; the windowed vector of the trim that produced this object when it computed
-        one, the plain counts otherwise.  Every column between the two boundaries is restored, the columns outside
-        keep the trimmer's decision.  `RuntimeError` when no column is free of gaps (upstream reports an error).
-        No device work: the counts are the ones the trim fetched, or a host count over the bytes.
+        of the reference exercises it; this follows the recalled upstream behaviour [R].  The
+        boundaries are the first and the last column without gaps in the gap statistics of this object:
+
+        * a trim that computed gap statistics hands them on -- the trimmed alignment shares the statistics object of
+          the alignment it was trimmed from (``statistics.pxd:47-51``): the (windowed) gap vector of the ORIGINAL
+          alignment, every sequence, whatever the trimmer kept ("reading 2");
+        * a result without them (RepresentativeTrimmer, OverlapTrimmer, ``noduplicateseqs``, the results of
+          `trim_batch`, an object built from masks) computes them when asked, over the sequences it still holds --
+          upstream's lazily built ``Gaps`` skips the sequences a trim removed ("reading 0").
+
+        Every column between the two boundaries is restored, the columns outside keep the trimmer's decision.
+        `RuntimeError` when no column is free of gaps (upstream reports an error).  No device work: the counts are
+        the ones the trim fetched, or a host count over the bytes.
         """
         gaps = getattr(self, "_gaps_w", None)
         if gaps is None:
-            m, n = self._matrix.shape
-            gaps = (self._matrix == _GAP).sum(axis=0, dtype=np.int32) if m else np.zeros(n, dtype=np.int32)
+            kept = self._matrix[self._seq_mask] if not self._seq_mask.all() else self._matrix
+            n = self._matrix.shape[1]
+            gaps = (kept == _GAP).sum(axis=0, dtype=np.int32) if kept.shape[0] else np.zeros(n, dtype=np.int32)
             hw = getattr(self, "_gap_hw", 0)
             if hw > 0 and n:  # the window of the trim that produced this object (pure host function of the library)
                 from . import _lib

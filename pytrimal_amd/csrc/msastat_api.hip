@@ -1615,7 +1615,14 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
 
 int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
-    const int rc = trim_impl(c, p, keep_res, keep_seq, info);
+    int rc;
+    try {  // (no exception crosses the C boundary: trim_impl sizes std::vectors by m, n and m * m)
+        rc = trim_impl(c, p, keep_res, keep_seq, info);
+    } catch (const std::bad_alloc &) {
+        rc = MSA_E_NOMEM;
+    } catch (...) {
+        rc = MSA_E_INVALID;
+    }
     if (rc != MSA_OK) {
         // an error return is a return with nothing in flight as well (an upload enqueued by msa_upload_packed_async included)
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);

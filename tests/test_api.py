@@ -523,22 +523,26 @@ def test_native_clustal_ingest_matches_the_python_parser(tmp_path):
 
 def test_terminal_only_mask_logic_without_a_device():
     """`TrimmedAlignment.terminal_only` (Cleaner::removeOnlyTerminal, [R] unverified): boundaries = first / last column
-    without gaps in the gap vector of the ORIGINAL alignment (every sequence, kept or not), everything between them
-    restored, the outside untouched -- against the oracle's restatement (reading 2), on masks built by hand.  No
+    without gaps, everything between them restored, the outside untouched -- against the oracle's restatement, on masks
+    built by hand.  An object that carries no gap statistics of a trim counts over the sequences it holds (reading 0);
+    one that carries the trim's vector uses it as it is: the ORIGINAL alignment's, every sequence (reading 2).  No
     device: the counts are host counts over the bytes."""
     import oracle
 
     seqs = ["-AC-DE-", "-A--DEF", "--C-DEF", "-ACGDE-"]
     a = oracle.pack(seqs)
     names = [b"a", b"b", b"c", b"d"]
-    for seq_mask in ([True] * 4, [True, False, True, True], [False] * 4):
+    for seq_mask in ([True] * 4, [True, False, True, True], [True, False, False, True]):
         for res_mask in ([False] * 7, [c % 2 == 0 for c in range(7)], [True] * 7):
             t = TrimmedAlignment(names, seqs, sequences_mask=seq_mask, residues_mask=res_mask)
-            want = oracle.terminal_only(a, res_mask, seq_mask, reading=2)
+            want = oracle.terminal_only(a, res_mask, seq_mask, reading=0)
             got = t.terminal_only()
             assert got.residues_mask == [bool(x) for x in want] and got.sequences_mask == list(seq_mask)
-            # columns 4 and 5 (D, E) are the only ones without a gap: restored, like everything between them
-            assert got.residues_mask[4] and got.residues_mask[5] and got.residues_mask[:4] == list(res_mask[:4])
+            # columns 4 and 5 (D, E) have no gap in any sequence: restored, like everything between them
+            assert got.residues_mask[4] and got.residues_mask[5] and got.residues_mask[:1] == list(res_mask[:1])
+    # rows a and d alone: column 3 (-, G) still holds a gap, columns 1 and 2 do not any more
+    t = TrimmedAlignment(names, seqs, sequences_mask=[True, False, False, True], residues_mask=[False] * 7)
+    assert t.terminal_only().residues_mask == [False, True, True, True, True, True, False]
     # a windowed gap vector cached by the trim that produced the object takes the place of the host count
     t = TrimmedAlignment(names, seqs, residues_mask=[False] * 7)
     t._gaps_w = np.array([4, 1, 0, 3, 0, 0, 2], dtype=np.int32)

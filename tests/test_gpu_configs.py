@@ -232,6 +232,29 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert rec["strong_scaling_reference_1gpu"]["value"] > 0 and rec["value"] > 0
 
 
+def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 8 --share-gpu --steps 2`: what the driver's 8-GPU scaling run starts, on this box's one GPU --
+    the launcher, eight ranks x four worker contexts, config 5 sharded 8 x 8, the gather of the masks, the max-over-ranks
+    timing, ONE JSON line, a clean exit of every rank -- in well under the time such a run may take.  (RCCL itself needs a
+    GPU per rank; the process group runs over gloo and the line says so.)"""
+    import json
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    seconds = time.perf_counter() - t0
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["steps"] == 2 and "C5" in rec["config"]["workload"]
+    assert rec["config"]["ranks_seen"] == 8 and rec["config"]["kept_columns"] == 192501 and rec["config"]["kept_columns_ok"] is True
+    assert rec["strong_scaling_reference_1gpu"]["value"] > 0 and rec["value"] > 0
+    assert seconds < 180, f"the eight-rank run took {seconds:.0f} s"
+
+
 def test_batch_module_in_a_fresh_process():
     """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
     package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`
