@@ -184,14 +184,64 @@ def test_batch_engine_against_single_trims(monkeypatch, cols_max):
         alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in np.ascontiguousarray(a)]))
     for trimmer in (AutomaticTrimmer("strict", platform="hip"), AutomaticTrimmer("automated1", platform="hip"),
                     AutomaticTrimmer("strictplus", platform="hip"), ManualTrimmer(similarity_threshold=0.3, platform="hip")):
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            for _ in range(2):  # (the second call reuses the arenas: nothing of the first may leak into it)
-                out = trim_batch(trimmer, alis, threads=3)
+        with warnings.catch_warnings(record=True) as from_batch:
+            warnings.simplefilter("always")
+            trim_batch(trimmer, alis, threads=3)
+        with warnings.catch_warnings(record=True) as from_batch2:
+            warnings.simplefilter("always")
+            out = trim_batch(trimmer, alis, threads=3)  # (the second call reuses the arenas: nothing of the first may leak into it)
+        with warnings.catch_warnings(record=True) as from_single:
+            warnings.simplefilter("always")
             single = [trimmer.trim(x) for x in alis]
         for k, (t, s1) in enumerate(zip(out, single)):
             assert t.residues_mask == s1.residues_mask and t.sequences_mask == s1.sequences_mask, (repr(trimmer), k)
+        # the sequences the trimming left with gaps only are reported one by one, in both paths alike
+        said = [sorted(str(w.message) for w in ws if issubclass(w.category, RuntimeWarning)) for ws in (from_batch, from_batch2, from_single)]
+        assert said[0] == said[1] == said[2]
+    # a residue the matrix does not know, in the middle of a batch: the batch raises what the single trim raises
+    # (a byte that is not ASCII never gets this far: `Alignment` refuses it)
+    weird = Alignment([b"a", b"b", b"c"], ["MKKBO", "MKKAY", "MKRAY"])
+    strict = AutomaticTrimmer("strict", platform="hip")
+    with pytest.raises(ValueError):
+        strict.trim(weird)
+    with pytest.raises(ValueError):
+        trim_batch(strict, alis[:5] + [weird] + alis[5:9], threads=2)
     batch_mod.close_batches()
+
+
+def test_batch_engine_return_codes_through_the_c_abi():
+    """`msa_trim_batch` on raw matrices (no `Alignment` in front to refuse them): a byte that is not ASCII in one alignment
+    of a group gives that alignment MSA_E_NON_ASCII and leaves its neighbours alone -- from the engine's host-only view as
+    from an ordinary context."""
+    from pytrimal_amd import _lib
+    from pytrimal_amd.matrix import SimilarityMatrix
+
+    mat = SimilarityMatrix.aa()
+    vhash, dist = mat._device_arrays()
+    params = _lib.TrimParams(_lib.METHOD_CODES["strict"], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0,
+                             vhash.ctypes.data, dist.ctypes.data, len(mat))
+    mats = [np.ascontiguousarray(synth_msa(30 + 7 * k, 200 + 31 * k, 50 + k)) for k in range(12)]
+    mats[4][3, 17] = 0xC3
+    batch = _lib.Batch(0, 2)
+    try:
+        out = batch.trim([(a, ord("X"), params) for a in mats])
+    finally:
+        batch.close()
+    ctx = _lib.Context(0)
+    try:
+        for k, (a, (res, seq, info, rc, rows)) in enumerate(zip(mats, out)):
+            if k == 4:
+                assert rc == _lib.E_NON_ASCII
+                continue
+            assert rc == _lib.OK
+            ctx.upload(a, ord("X"))
+            keep_res, keep_seq, _ = ctx.trim(params)
+            assert np.array_equal(res, keep_res.astype(bool)) and np.array_equal(seq, keep_seq.astype(bool))
+        ctx.upload(mats[4], ord("X"))
+        with pytest.raises(ValueError):
+            ctx.trim(params)
+    finally:
+        ctx.close()
 
 
 def test_two_ranks_share_one_gpu():

@@ -24,6 +24,20 @@ timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_A
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1_C4 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload C4 > $OUT/sq1_C4.log 2>&1
 cd $ROOT
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wstream tools/ubench_wstream.hip && timeout 120 /tmp/ubench_wstream > $OUT/ubench_wstream.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/ubench_wform tools/ubench_wform.hip && timeout 120 /tmp/ubench_wform > $OUT/ubench_wform.txt 2>&1
+# round 4: the similarity kernel by shape (tall alignments: a workgroup per column), the batch engine on small alignments
+timeout 600 python tools/sim_shapes.py > $OUT/sim_shapes.jsonl 2>/dev/null
+MSA_LG_SPLIT=1 CHECK=0 REPS=2 timeout 600 python tools/sim_shapes.py 20000 500 3 40000 300 4 5000 1000 9 > $OUT/sim_shapes_one_wave_per_column.jsonl 2>/dev/null
+for shape in "1024 100 1000" "1024 60 600" "4096 40 300" "512 128 2000" "256 300 1200" "128 500 2000"; do
+  timeout 300 python tools/small_batch.py $shape 2>/dev/null; MSA_BATCH_ENGINE=0 timeout 300 python tools/small_batch.py $shape 2>/dev/null
+done > $OUT/small_batch.jsonl
+MSA_BATCH_COLS_MAX=0 timeout 300 python tools/small_batch.py 1024 100 1000 2>/dev/null >> $OUT/small_batch.jsonl
+MSA_BATCH_FETCH_KB=0 timeout 300 python tools/small_batch.py 1024 100 1000 2>/dev/null >> $OUT/small_batch.jsonl
+for g in 1 4 16; do MSA_BATCH_ENGINE_MAX=1e12 MSA_BATCH_GROUPS=$g timeout 300 python tools/c5_engine.py 2>/dev/null; done > $OUT/c5_engine.jsonl
+MSA_BATCH_ENGINE=0 timeout 300 python tools/c5_engine.py 2>/dev/null >> $OUT/c5_engine.jsonl
+timeout 300 python tools/c5_counts.py > $OUT/c5_counts.jsonl 2>/dev/null
+timeout 300 python tools/small_latency.py > $OUT/small_latency.jsonl 2>/dev/null
+timeout 120 python tools/cold_upload.py > $OUT/cold_upload.jsonl 2>/dev/null
 for sw in MSA_PIPELINE=1,0 MSA_UPLOAD_DIRECT=1,0; do timeout 300 python tools/step_overheads.py C3 C2 C4 C5 --switch $sw 2>/dev/null | grep "ms/step"; done > $OUT/ab_switches.txt
 timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms > $OUT/bx_stamps.jsonl
 timeout 120 python tools/bx_stamps.py 1000 4000 2000 2>/dev/null | grep sim_ms >> $OUT/bx_stamps.jsonl
