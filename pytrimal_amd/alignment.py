@@ -398,9 +398,9 @@ class TrimmedAlignment(Alignment):
         * a trim that computed gap statistics hands them on -- the trimmed alignment shares the statistics object of
           the alignment it was trimmed from (``statistics.pxd:47-51``): the (windowed) gap vector of the ORIGINAL
           alignment, every sequence, whatever the trimmer kept ("reading 2");
-        * a result without them (RepresentativeTrimmer, OverlapTrimmer, ``noduplicateseqs``, the results of
-          `trim_batch`, an object built from masks) computes them when asked, over the sequences it still holds --
-          upstream's lazily built ``Gaps`` skips the sequences a trim removed ("reading 0").
+        * a result without them (RepresentativeTrimmer, OverlapTrimmer, ``noduplicateseqs``, an object built from
+          masks) computes them when asked, over the sequences it still holds -- upstream's lazily built ``Gaps``
+          skips the sequences a trim removed ("reading 0").
 
         Every column between the two boundaries is restored, the columns outside keep the trimmer's decision.
         `RuntimeError` when no column is free of gaps (upstream reports an error).  No device work: the counts are
@@ -408,7 +408,10 @@ class TrimmedAlignment(Alignment):
         """
         gaps = getattr(self, "_gaps_w", None)
         if gaps is None:
-            kept = self._matrix[self._seq_mask] if not self._seq_mask.all() else self._matrix
+            # (a column trimmer's result whose vector was not kept -- `trim_batch` -- counts over every sequence, as the cached
+            # vector would; a sequence trimmer's result, or an object built from masks, over the sequences it holds)
+            shared = getattr(self, "_gap_stats", False)
+            kept = self._matrix[self._seq_mask] if not (shared or self._seq_mask.all()) else self._matrix
             n = self._matrix.shape[1]
             gaps = (kept == _GAP).sum(axis=0, dtype=np.int32) if kept.shape[0] else np.zeros(n, dtype=np.int32)
             hw = getattr(self, "_gap_hw", 0)
@@ -425,12 +428,12 @@ class TrimmedAlignment(Alignment):
             raise RuntimeError("the alignment has no column without gaps: terminal-only trimming is not possible")
         res[free[0]:free[-1] + 1] = True
         out = TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, res)
-        out._gaps_w, out._gap_hw = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0)
+        out._gaps_w, out._gap_hw, out._gap_stats = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0), getattr(self, "_gap_stats", False)
         return out
 
     def copy(self):
         out = TrimmedAlignment._from_parts(self._names, self._matrix.copy(), self._datatype, self._seq_mask, self._res_mask)
-        out._gaps_w, out._gap_hw = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0)
+        out._gaps_w, out._gap_hw, out._gap_stats = getattr(self, "_gaps_w", None), getattr(self, "_gap_hw", 0), getattr(self, "_gap_stats", False)
         return out
 
 

@@ -160,7 +160,7 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     if not distributed or world == 1:
         # (what the workers produced, as it is: rebuilding 64 results from their masks in the calling thread was a serial
         # tail of ~4 ms behind a 35 ms batch)
-        return [t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], r, s) for i, (r, s, t) in zip(mine, local)]
+        return [t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], r, s, _gap_stats(trimmer)) for i, (r, s, t) in zip(mine, local)]
     mine_trimmed = {i: t for i, (_, _, t) in zip(mine, local)}
     local = [(r, s) for r, s, _ in local]
 
@@ -192,11 +192,20 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
                 out[i] = (res, seq)
                 continue
             t = mine_trimmed.get(i) if r == rank else None
-            out[i] = t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], res, seq)
+            out[i] = t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], res, seq, _gap_stats(trimmer))
     return out
 
 
-def _rebuild(alignment, keep_res, keep_seq):
+def _gap_stats(trimmer):
+    """Does this trimmer compute gap statistics (what its results' `terminal_only` shares with the source alignment)?"""
+    from .trimmer import AutomaticTrimmer, ManualTrimmer
+
+    return isinstance(trimmer, ManualTrimmer) or (isinstance(trimmer, AutomaticTrimmer) and trimmer.method != "noduplicateseqs")
+
+
+def _rebuild(alignment, keep_res, keep_seq, gap_stats=False):
     dense = alignment._dense()
     whole = len(alignment._seq_idx) == len(alignment._names)  # (every sequence visible: the list of names is shared, not copied)
-    return TrimmedAlignment._from_parts(alignment._names if whole else alignment.names, dense, alignment._datatype, keep_seq, keep_res)
+    out = TrimmedAlignment._from_parts(alignment._names if whole else alignment.names, dense, alignment._datatype, keep_seq, keep_res)
+    out._gap_stats = gap_stats  # (what `terminal_only` counts over: trimmer._finish)
+    return out

@@ -1612,6 +1612,9 @@ struct TrimTrace {
 }  // namespace
 
 static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info);
+namespace {
+int engine_needs(const msa_trim_params *p);
+}
 
 int msa_trim(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info) {
     if (!c || !c->raw || !p || !keep_res || !keep_seq) return MSA_E_INVALID;
@@ -1716,10 +1719,11 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
                             (method == MSA_METHOD_NONE && p->similarity_threshold != -1);
     const bool pipelined = column_mode && (sim_always || method == MSA_METHOD_AUTOMATED1) && sim_pipeline_applies(c, p, sim_hw);
     if (c->prefetched) {
-        if (!pipelined || gap_hw != 0 || (int)c->h_gaps.size() != n) return MSA_E_FALLBACK;  // (the engine only takes these)
+        // (the engine only takes these: the similarity pipeline, or a trim that needs the gap statistics alone; no windows)
+        if (gap_hw != 0 || (int)c->h_gaps.size() != n || !(pipelined || engine_needs(p) == 1)) return MSA_E_FALLBACK;
         gaps_w = c->h_gaps;
-        c->pipe_active = true;
-        c->pipe_gated = method == MSA_METHOD_AUTOMATED1;
+        c->pipe_active = pipelined;
+        c->pipe_gated = pipelined && method == MSA_METHOD_AUTOMATED1;
     } else if (pipelined) {
         rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
         if (rc) {  // (nothing of a half-built pipeline may stay in flight over the staging buffers)
@@ -1990,19 +1994,33 @@ inline size_t align_up(size_t x, size_t q) { return (x + q - 1) / q * q; }
 
 // Can the engine take alignment k?  (the similarity pipeline's conditions, one pair-pass regime, 32-bit list offsets, rows the
 // copy engine takes in one piece or that are small enough to pack on the way)
+// what a column-mode trim needs of the device: 0 not a column-mode trim the engine knows, 1 the gap statistics alone (gappyout,
+// nogaps, noallgaps, a manual gap threshold), 2 the similarity pipeline as well
+int engine_needs(const msa_trim_params *p) {
+    const int method = p->method;
+    const bool column_mode = method != MSA_METHOD_NODUPLICATESEQS && p->clusters == -1 && p->max_identity == -1 &&
+                             !(p->residue_overlap != -1 && p->sequence_overlap != -1);
+    if (!column_mode) return 0;
+    if (method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS || method == MSA_METHOD_AUTOMATED1 ||
+        (method == MSA_METHOD_NONE && p->similarity_threshold != -1))
+        return 2;
+    if (method == MSA_METHOD_GAPPYOUT || method == MSA_METHOD_NOGAPS || method == MSA_METHOD_NOALLGAPS ||
+        (method == MSA_METHOD_NONE && (p->gap_threshold != -1 || p->gap_absolute_threshold != -1)))
+        return 1;
+    return 0;
+}
+
 bool engine_takes(const msa_batch *b, int32_t k, const msa_trim_params *ref) {
     const msa_trim_params *p = b->params + k;
     const int m = b->m[k], n = b->n[k];
     if (m < 2 || n < 1 || m > 32768 || !b->data[k] || b->ld[k] < n) return false;
-    const int method = p->method;
-    const bool column_mode = method != MSA_METHOD_NODUPLICATESEQS && p->clusters == -1 && p->max_identity == -1 &&
-                             !(p->residue_overlap != -1 && p->sequence_overlap != -1);
-    const bool sim = method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS || method == MSA_METHOD_AUTOMATED1 ||
-                     (method == MSA_METHOD_NONE && p->similarity_threshold != -1);
-    if (!column_mode || !sim) return false;
+    const int needs = engine_needs(p);
+    if (!needs) return false;
     int gap_hw = p->gap_window, sim_hw = p->similarity_window;
     if (p->window != -1) gap_hw = sim_hw = p->window;
-    if (gap_hw > 0 || sim_hw > n / 4) return false;
+    if (gap_hw > 0) return false;
+    if (needs == 1) return (double)m * n <= 4e6;  // (the gap statistics alone: small alignments, where launches are the cost)
+    if (sim_hw > n / 4) return false;
     if (!p->vhash || !p->dist || p->npos < 1 || p->npos > 28) return false;
     // one set of tables per call: the first taken alignment's
     if (ref && (ref->npos != p->npos || b->indet[k] != b->indet[ref - b->params] ||
@@ -2042,7 +2060,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     std::vector<EngineLayout> lay(K);
     L.items.resize(K);
     size_t res_words = 0, stage_bytes = 0;
-    int max_m = 0;
+    int max_m = 0, any_sim = -1;  // (over the alignments that run the similarity pipeline)
     uint64_t sig = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
     for (int i = 0; i < K; ++i) {
@@ -2053,9 +2071,10 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         it.mpad = round_up(m + 64, 64);
         it.res_word = res_words;
         res_words += 16 + (size_t)2 * it.npad + it.mpad + (size_t)2 * it.npad;
-        max_m = std::max(max_m, m);
+        if (engine_needs(b->params + k) == 2) max_m = std::max(max_m, m), any_sim = i;
         mix(((uint64_t)(uint32_t)m << 32) | (uint32_t)n);
         mix(b->params[k].method == MSA_METHOD_AUTOMATED1);
+        mix(engine_needs(b->params + k));
     }
     const bool multi = msak::lg_rounds_per_launch(max_m) > 0;  // (the similarity kernel in several launches: per-column state)
     // groups of small alignments: the similarity statistic with a lane per column (similarity_cols_batch_kernel) -- no
@@ -2106,6 +2125,12 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         const size_t ld = round_up(n, 64), nchunk = (n + 31) / 32, m_pad = round_up(m, 128), ldw = round_up(m, 64);
         const size_t ncp = msak::bx_cols_pad(n), ldk = msak::bx_ldk(m);
         EngineLayout &y = lay[i];
+        if (engine_needs(b->params + k) < 2) {  // the gap statistics alone: the rows are all it needs on the device
+            y.planes = y.ident = y.w = y.wlow = y.wbar = y.row_avg = y.row_max = y.codeT = y.codeR = y.off = y.trow = y.nvalid = y.simnum =
+                y.simden = y.simstate = 0;
+            y.end = off;
+            continue;
+        }
         y.planes = take(((size_t)msak::planes_total() * nchunk * m_pad + 64) * 4);
         y.ident = take(((size_t)m * ldw + 512) * 4);
         y.w = take(((size_t)m * ldw + 512) * 4);
@@ -2152,7 +2177,6 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     const int32_t *pf_d = reinterpret_cast<const int32_t *>(reinterpret_cast<const uint8_t *>(lt_d) + align_up((size_t)K * sizeof(msak::LgAlign), 256));
     for (int f = 0; f < F_COUNT; ++f) pf[(size_t)f * (K + 1)] = 0;
     int32_t *res_d = reinterpret_cast<int32_t *>(A);
-    const uint8_t indet = b->indet[ks[0]];
     for (int i = 0; i < K; ++i) {
         const int k = ks[i], m = b->m[k], n = b->n[k];
         const Engine::Item &it = L.items[i];
@@ -2185,7 +2209,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         d.simden = reinterpret_cast<float *>(A + y.simden);
         d.m = m, d.n = n, d.nchunk = (n + 31) / 32, d.m_pad = round_up(m, 128), d.ldw = round_up(m, 64);
         d.ncols_pad = msak::bx_cols_pad(n);
-        d.indet4 = 0x01010101u * indet;
+        d.indet4 = 0x01010101u * b->indet[k];
         bt[i] = d;
         msak::LgAlign g = {};
         g.voff = d.off, g.vtrow = d.trow, g.nvalid = d.nvalid, g.codeT = d.codeT;
@@ -2195,7 +2219,8 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         g.cols = nullptr;
         g.ldk = d.ldk, g.m = m, g.n = n, g.ldw = d.ldw, g.ncols = n;
         lt[i] = g;
-        auto add = [&](int f, int blocks) { pf[(size_t)f * (K + 1) + i + 1] = pf[(size_t)f * (K + 1) + i] + blocks; };
+        const bool sim = engine_needs(b->params + k) == 2;
+        auto add = [&](int f, int blocks) { pf[(size_t)f * (K + 1) + i + 1] = pf[(size_t)f * (K + 1) + i] + ((sim || f <= F_ROWTOT) ? blocks : 0); };
         add(F_FETCH, fetch[i] ? (int)(((int64_t)m * (d.ld / 16) + 255) / 256) : 0);
         add(F_GAPS, (int)((d.ld / 4 + 255) / 256) * ((m + 63) / 64));
         add(F_ROWTOT, (m + 3) / 4);
@@ -2261,7 +2286,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     msak::launch_pair_counts_batch(st, bt_d, PF(F_PAIRS), K, NB(F_PAIRS));
     msak::launch_w_row_means_batch(st, bt_d, PF(F_WMEANS), K, NB(F_WMEANS));
     msak::launch_identity_stats_batch(st, bt_d, PF(F_IDROWS), K, NB(F_IDROWS));
-    const int npos = b->params[ks[0]].npos;
+    const int npos = any_sim >= 0 ? b->params[ks[any_sim]].npos : 0;
     if (cols_mode) msak::launch_sim_encode_rm_batch(st, bt_d, PF(F_ENCODE), K, NB(F_ENCODE), tc->lut.p);
     else msak::launch_sim_lists_batch(st, bt_d, PF(F_ENCODE), NB(F_ENCODE), PF(F_COMPACT), NB(F_COMPACT), K, tc->lut.p, npos);
     HIPCHK(tc, hipEventRecord(L.prepared, st));
@@ -2421,10 +2446,14 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
     msa_ctx *tc = e->tables;
     HIPCHK(tc, hipSetDevice(b->device));
     TuneScope tune(tc);
-    const msa_trim_params *p0 = b->params + ks[0];
-    tc->indet = b->indet[ks[0]];
-    int rc = ensure_tables(tc, p0->vhash, p0->dist, p0->npos);
-    if (rc) return rc;
+    int rc = MSA_OK;
+    for (int32_t k : ks)
+        if (engine_needs(b->params + k) == 2) {  // the one set of tables of the call (engine_takes: every such alignment shares it)
+            const msa_trim_params *p0 = b->params + k;
+            tc->indet = b->indet[k];
+            if ((rc = ensure_tables(tc, p0->vhash, p0->dist, p0->npos))) return rc;
+            break;
+        }
     // groups: about a quarter of the call each (at least two groups in flight whenever there are two alignments), bounded
     // by the arena (~8 GB) and by 256 alignments
     const int total = (int)ks.size();
@@ -2617,7 +2646,7 @@ int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, cons
         const msa_trim_params *ref = nullptr;
         for (int32_t k : all) {
             if (b->use_engine && engine_takes(b, k, ref)) {
-                if (!ref) ref = params + k;
+                if (!ref && engine_needs(params + k) == 2) ref = params + k;
                 engine_ks.push_back(k);
             } else {
                 b->order.push_back(k);

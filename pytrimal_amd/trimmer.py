@@ -180,6 +180,10 @@ class BaseTrimmer:
         # statistics object of its source): the half window, and the windowed vector itself when the trim fetched it
         out._gap_hw = max(params.window if params.window != -1 else params.gap_window, 0)
         out._gaps_w = gaps_w
+        # did this trim compute gap statistics (every column trimmer does; the sequence trimmers do not)?  `terminal_only`
+        # shares them with the source alignment when it did, and counts over the kept sequences when it did not
+        out._gap_stats = (params.method != _lib.METHOD_CODES["noduplicateseqs"] and params.clusters == -1 and params.max_identity == -1
+                          and not (params.residue_overlap != -1 and params.sequence_overlap != -1))
         return out
 
     def trim(self, alignment, matrix=None):

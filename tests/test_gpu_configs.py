@@ -159,7 +159,8 @@ def test_native_batch_equals_one_by_one():
 @pytest.mark.parametrize("cols_max", ["", "0"])
 def test_batch_engine_against_single_trims(monkeypatch, cols_max):
     """`msa_trim_batch`'s engine (one launch per kernel family for a whole group of alignments, the selection on host-only
-    views) on 60 alignments of random shapes up to 500 x 900 with gap-heavy rows and columns, four trimmers it takes --
+    views) on 60 alignments of random shapes up to 500 x 900 with gap-heavy rows and columns, the trimmers it takes (the
+    similarity pipeline, and the trims that need the gap statistics alone) --
     against one trim at a time, which goes through an ordinary context.  cols_max: the row count up to which a group's
     similarity statistic runs with a lane per column (default 128; 0: the wave-per-column kernel for every group)."""
     import warnings
@@ -183,7 +184,10 @@ def test_batch_engine_against_single_trims(monkeypatch, cols_max):
             a[:, rng.integers(0, n, max(1, n // 4))] = ord("-")
         alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in np.ascontiguousarray(a)]))
     for trimmer in (AutomaticTrimmer("strict", platform="hip"), AutomaticTrimmer("automated1", platform="hip"),
-                    AutomaticTrimmer("strictplus", platform="hip"), ManualTrimmer(similarity_threshold=0.3, platform="hip")):
+                    AutomaticTrimmer("strictplus", platform="hip"), ManualTrimmer(similarity_threshold=0.3, platform="hip"),
+                    AutomaticTrimmer("gappyout", platform="hip"), AutomaticTrimmer("nogaps", platform="hip"),
+                    AutomaticTrimmer("noallgaps", platform="hip"), ManualTrimmer(gap_threshold=0.7, platform="hip"),
+                    ManualTrimmer(gap_threshold=0.6, similarity_threshold=0.2, conservation_percentage=40, platform="hip")):
         with warnings.catch_warnings(record=True) as from_batch:
             warnings.simplefilter("always")
             trim_batch(trimmer, alis, threads=3)
