@@ -40,13 +40,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 3.9e13  # 256 CUs x 64 lanes x 2.4 GHz (the ceiling of the pairwise passes)
 # the similarity kernel's real ceiling: 256-byte coalesced dword-per-lane loads of L2-resident rows through a list of row
-# offsets, 16 in flight, in EXACTLY the form the kernel issues (row base in an SGPR pair by s_add_u32 / s_addc_u32, lane offset
-# in a VGPR, hand-counted vmcnt), five waves per SIMD, measured with tools/ubench_wform.hip on an MI355X
-# (profiles/r04_ubench_wform.txt): 29.0 TB/s chip-wide = 5.03 CU-cycles per wave-load at the 2.22 GHz the chip ran it at; every
-# other address form (constant base + VALU offset, 64-bit per-lane address by v_add_co / v_mad_u64_u32 / v_lshl_add_u64) measures
-# the same within 2 %; with the kernel's three VALU instructions per step beside the loads 27.7 TB/s
-W_STREAM_PEAK_GBS = 29000.0
-W_STREAM_PEAK_WITH_VALU_GBS = 27700.0
+# offsets, 16 in flight, in EXACTLY the form the kernel issues (matrix base in an SGPR pair, list offset + lane offset by one
+# v_add_u32 in a VGPR, hand-counted vmcnt), five waves per SIMD, measured with tools/ubench_wform.hip on an MI355X
+# (profiles/r04_ubench_wform.txt, form 1): 29.4 TB/s chip-wide = 4.95 CU-cycles per wave-load at the 2.22 GHz the chip ran it at;
+# every other address form (row base in SGPRs, 64-bit per-lane address by v_add_co / v_mad_u64_u32 / v_lshl_add_u64) measures
+# the same within 2 %; with the kernel's three VALU instructions per step beside the loads 27.9 TB/s
+W_STREAM_PEAK_GBS = 29400.0
+W_STREAM_PEAK_WITH_VALU_GBS = 27900.0
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 -> L1 bandwidth figure of the guide
 
 
@@ -604,8 +604,9 @@ def main():
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
                     "frac_of_peak_with_the_loop_valu_work": round(rate / W_STREAM_PEAK_WITH_VALU_GBS, 4),
                     "frac_of_l2_peak": round(rate / L2_PEAK_GBS, 4), "l2_peak": L2_PEAK_GBS,
-                    "peak_source": "tools/ubench_wform.hip, form 0 = the address form the kernel ships (SGPR row base + VGPR lane offset, "
-                                   "hand-issued), five waves per SIMD, on one MI355X (profiles/r04_ubench_wform.txt); not measured in this run",
+                    "peak_source": "tools/ubench_wform.hip, form 1 = the address form the kernel ships (constant SGPR base + list offset added to the "
+                                   "lane offset by v_add_u32, hand-issued), five waves per SIMD, on one MI355X (profiles/r04_ubench_wform.txt); "
+                                   "not measured in this run",
                 }
             if dom in ("sim", "pairs"):
                 # the pairwise passes are VALU-issue work, not bandwidth: one "pair-column" = one (j, k, column) term

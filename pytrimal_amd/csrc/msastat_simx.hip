@@ -376,8 +376,8 @@ __device__ __forceinline__ void lg_wait_rows(LgD &D) {
                  : "memory");
 }
 
-// W rows by global_load_dword with the row address in an SGPR pair and the lane offset in a VGPR (s_add_u32 /
-// s_addc_u32: two SALU, no VALU), hand-issued, so the loop counts VMCNT itself: 16 loads are in flight at every step
+// W rows by global_load_dword with the matrix base in an SGPR pair and list offset + lane offset in a VGPR (one v_add_u32;
+// until round 4 the row address in an SGPR pair: two SALU), hand-issued, so the loop counts VMCNT itself: 16 loads are in flight at every step
 // and nothing else of the loop is a vector-memory instruction.  (Measured against it in round 2, tools/ubench_wstream.hip:
 // buffer_load_dword with the list offset as SGPR offset costs the texture addresser 8.6 instead of 5.3 CU-cycles per
 // 256-byte wave-load -- 4.03 instead of 3.13 ms at C3; a 64-bit per-lane address left to the compiler one more VALU
@@ -401,7 +401,18 @@ __device__ __forceinline__ void round_loop_lds(const float *wlow_g, uint32_t row
     // (every list offset + lane offset lies inside wlow: rows 0 .. m, columns below ldw)
     const uint64_t wuni = (uint64_t)uniform_ptr((const __attribute__((address_space(1))) char *)(uint64_t)wlow_g);
     auto wrow = [&](float &dst, uint32_t o) {
-        const uint64_t row = BIG ? wuni + (uint64_t)o * (uint64_t)rowbytes : wuni + o;
+        if constexpr (!BIG) {
+            // the list offset added to the lane offset on the VALU, the matrix base in an SGPR pair: one VALU instruction per
+            // step instead of two scalar ones.  The addresser charges every address form the same (profiles/r04_ubench_wform.txt);
+            // what differs is who computes the address, and the scalar unit -- one instruction per CU-cycle for all of its
+            // waves -- was 75 % busy with 4.4 instructions per step while the VALU had room: 2.67 -> 2.57 ms at C3, 0.443 ->
+            // 0.412 at 1000 x 4000, 8.14 -> 7.70 at 5000 x 5000 (the table row's address moved over as well -- v_add_u32_sdwa +
+            // ds_read_b32 instead of M0 + ds_read_addtid_b32 -- tips it the other way: 2.80 ms, the VALU becomes the wall)
+            uint32_t vo;
+            asm volatile("v_add_u32 %1, %2, %3\n\tglobal_load_dword %0, %1, %4" : "=v"(dst), "=&v"(vo) : "s"(o), "v"(joff), "s"(wuni) : "memory");
+            return;
+        }
+        const uint64_t row = wuni + (uint64_t)o * (uint64_t)rowbytes;  // (BIG: the row index multiplied out on the scalar unit)
         asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(joff), "s"(row) : "memory");
     };
     auto bload = [&](float(&w)[16], const LgEntries &en) {

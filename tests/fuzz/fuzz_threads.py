@@ -75,14 +75,17 @@ def worker(k):
         elif expect is None and (t.residues_mask != [bool(x) for x in res] or t.sequences_mask != [bool(x) for x in seq]):
             failures.append({"thread": k, "shape": [m, n], "settings": kw})
         elif expect is None and rng.random() < 0.3:
-            # TrimmedAlignment.terminal_only against the oracle's reading 2: the gap vector of the original alignment --
-            # the windowed counts of the trim when it fetched them (checked against the oracle's own window), else the counts
+            # TrimmedAlignment.terminal_only against the oracle: reading 2 -- the gap vector of the original alignment, the windowed
+            # counts of the trim when it fetched them (checked against the oracle's own window), else the counts --
             hw = kw.get("window", kw.get("gap_window", 0))
             ogw = oracle.gaps_window(oracle.gaps(a)[0], hw)
             cached = getattr(t, "_gaps_w", None)
             if cached is not None and not np.array_equal(cached, ogw):
                 failures.append({"thread": k, "shape": [m, n], "settings": kw, "cached_gap_vector": True})
-            want = oracle.terminal_only(a, res, seq, reading=2, gaps_w=ogw if cached is not None else None)
+            # (a result without gap statistics -- a sequence trimmer's whose trim fetched no counts -- counts over the sequences
+            # it holds: reading 0)
+            shared = cached is not None or getattr(t, "_gap_stats", False)
+            want = oracle.terminal_only(a, res, seq, reading=2 if shared else 0, gaps_w=ogw if cached is not None else None)
             try:
                 have = t.terminal_only().residues_mask
             except RuntimeError:
