@@ -19,14 +19,15 @@ AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a strict trim must raise where the oracle does
 
 CONTEXTS = [dict(), dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq"),
-            dict(MSA_MDK_HOST="1", MSA_UPLOAD_DIRECT="0"), dict(MSA_LG_ROUNDS="1")]
+            dict(MSA_MDK_HOST="1", MSA_UPLOAD_DIRECT="0"), dict(MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="3"),
+            dict(MSA_LG_SPLIT="8", MSA_LG_ROUNDS="2")]
 ctxs = []
 for env in CONTEXTS:
-    for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS"):
+    for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctxs.append(_lib.Context(0))
-for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS"):
+for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT"):
     os.environ.pop(k, None)
 
 mx = SimilarityMatrix.aa()

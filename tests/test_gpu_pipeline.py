@@ -219,3 +219,21 @@ def test_public_api_from_threads_against_the_oracle():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["mismatch"] is False and min(line["trims_per_thread"]) > 20, line
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_random_batches_against_the_oracle(seed):
+    """tests/fuzz/fuzz_batch.py: random batches of 2 .. 300 alignments with a trimmer setting each through `msa_trim_batch` (the
+    batched-kernel engine for the small alignments whose trim it takes, worker contexts for the others) against the oracle's
+    trim, alignment by alignment: masks and return codes."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_batch.py"), "10", str(seed)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mismatch"] is False and line["alignments"] > 50, line

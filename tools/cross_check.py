@@ -37,7 +37,7 @@ def make(m, n):
 
 
 def run(kernel, a):
-    for k in ("MSA_SIM_KERNEL", "MSA_LG_BIG", "MSA_LG_ROUNDS"):
+    for k in ("MSA_SIM_KERNEL", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT"):
         os.environ.pop(k, None)
     if kernel == "seq":
         os.environ["MSA_SIM_KERNEL"] = "seq"
@@ -45,6 +45,8 @@ def run(kernel, a):
         os.environ["MSA_LG_BIG"] = "1"
     elif kernel == "lg-rounds":  # one round per launch, the columns' state through memory (by itself: six from 1800 rows on)
         os.environ["MSA_LG_ROUNDS"] = "1"
+    elif kernel.startswith("lg-split-"):  # a workgroup of S waves per column (by itself: tall alignments)
+        os.environ["MSA_LG_SPLIT"] = kernel.rsplit("-", 1)[1]
     ctx = _lib.Context(0)
     try:
         ctx.upload(a, ord("X"))
@@ -62,7 +64,7 @@ for i in range(cases):
         n = min(n, 100)
     a = make(m, n)
     ref = run("seq", a)  # the reference's two loops, one lane per column
-    for k in ("lg", "lg-big", "lg-rounds"):
+    for k in ("lg", "lg-big", "lg-rounds", "lg-split-2", "lg-split-5", "lg-split-16"):
         got = run(k, a)
         ok = np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
         if not ok:

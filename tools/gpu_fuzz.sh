@@ -8,4 +8,5 @@ run python tests/fuzz/fuzz_trim.py ${1:-200} 707
 run python tests/fuzz/fuzz_trim.py ${1:-200} 808
 run python tools/cross_check.py 600 13
 run python tests/fuzz/fuzz_threads.py ${2:-150} 4
+run python tests/fuzz/fuzz_batch.py ${2:-150} 505
 cat $OUT
