@@ -1942,6 +1942,7 @@ struct msa_batch {
     int32_t sel_total = 0;
     std::atomic<int32_t> sel_next{0};
     std::vector<int32_t> sel_redo;
+    std::vector<uint8_t> sel_finished;  // per alignment of the call: the engine has delivered its result
     bool use_engine = true;                       // MSA_BATCH_ENGINE=0: every alignment through the workers (diagnostics, tests)
     double engine_max_work = 8e8;                 // m * m * n up to which the engine takes an alignment (MSA_BATCH_ENGINE_MAX)
     bool in_call = false;
@@ -2343,6 +2344,7 @@ void engine_select_item(msa_batch *b, Engine::Lane &L, const Engine::Item &it, m
     }
     b->only_gaps[k] = v->only_gaps_rows;
     b->rc[k] = rc;
+    b->sel_finished[k] = 1;
 }
 
 // items of the job in flight until none is left (the calling thread and every idle worker)
@@ -2479,6 +2481,7 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
         if (!cur.empty()) groups.push_back(cur);
     }
     b->sel_redo.clear();
+    b->sel_finished.assign((size_t)b->count, 0);
     const int G = (int)groups.size();
     int first_error = MSA_OK;
     for (int g = 0; g < G && first_error == MSA_OK; ++g) {
@@ -2501,7 +2504,8 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
             if (L.stream) (void)hipStreamSynchronize(L.stream);
             L.busy = false;
         }
-        for (int32_t k : ks) b->rc[k] = first_error;
+        for (int32_t k : ks)
+            if (!b->sel_finished[k]) b->rc[k] = first_error;  // (the groups that were through keep their results)
         return first_error;
     }
     // the selection of these needs another pass over the rows: an ordinary context
@@ -2670,7 +2674,7 @@ int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, cons
     }
     if (engine_rc != MSA_OK)
         for (int32_t k : engine_ks)
-            if (rc[k] == MSA_OK) rc[k] = engine_rc;
+            if (rc[k] == MSA_OK && !(k < (int32_t)b->sel_finished.size() && b->sel_finished[k])) rc[k] = engine_rc;
     {
         std::unique_lock<std::mutex> lk(b->mu);
         b->cv_done.wait(lk, [&] { return b->running == 0; });
