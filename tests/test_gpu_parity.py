@@ -410,7 +410,7 @@ KERNEL_IDS = ["lg", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "l
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
-@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (113, 200), (225, 96), (337, 130), (640, 257)])
+@pytest.mark.parametrize("shape", [(2, 70), (9, 33), (65, 64), (113, 200), (127, 1), (128, 300), (129, 70), (225, 96), (337, 130), (640, 257)])
 def test_similarity_kernel_variants(ctx_with, kernel, shape):
     """Every similarity path against the oracle, at row counts on both sides of the round boundaries (64 rows per
     round) and with ragged numbers of columns."""
