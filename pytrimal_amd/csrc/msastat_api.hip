@@ -2284,7 +2284,10 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     msak::launch_gap_counts_batch(st, bt_d, PF(F_GAPS), K, NB(F_GAPS));
     msak::launch_row_nongap_batch(st, bt_d, PF(F_ROWTOT), K, NB(F_ROWTOT));
     msak::launch_prep_planes_batch(st, bt_d, PF(F_PLANES), K, NB(F_PLANES));
-    msak::launch_pair_counts_batch(st, bt_d, PF(F_PAIRS), K, NB(F_PAIRS));
+    int min_nchunk = 1 << 30;
+    for (int i = 0; i < K; ++i)
+        if (engine_needs(b->params + ks[i]) == 2) min_nchunk = std::min(min_nchunk, (b->n[ks[i]] + 31) / 32);
+    msak::launch_pair_counts_batch(st, bt_d, PF(F_PAIRS), K, NB(F_PAIRS), min_nchunk);
     msak::launch_w_row_means_batch(st, bt_d, PF(F_WMEANS), K, NB(F_WMEANS));
     msak::launch_identity_stats_batch(st, bt_d, PF(F_IDROWS), K, NB(F_IDROWS));
     const int npos = any_sim >= 0 ? b->params[ks[any_sim]].npos : 0;

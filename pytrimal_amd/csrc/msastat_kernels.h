@@ -98,7 +98,7 @@ void launch_fetch_rows_batch(hipStream_t s, const BAlign *table, const int32_t *
 void launch_gap_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_row_nongap_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
-void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, int min_nchunk);  // min_nchunk: over the group
 void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);

@@ -362,6 +362,12 @@ __global__ __launch_bounds__(64) void pair_counts_kernel(const uint32_t *__restr
 //     each group is requested at the start of the phase BEFORE the one that uses it, right behind the wait for the
 //     other group -- one phase of the wave (and of the SIMD's other waves) covers its latency.
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+//
+// The waves of a workgroup share a tile (round 4): wave w of K walks the chunks [nchunk w / K, nchunk (w + 1) / K), the partial
+// counts meet in LDS and wave 0 writes the tile.  A tile's wave used to walk ALL chunks alone, and below ~4000 sequences there are
+// fewer tiles than the chip has room for waves (2000 sequences: 4000 tiles, all resident from the start, the fullest SIMD sets
+// the time; 1000 sequences: 1000 tiles for 1024 SIMDs; 500: 252): K = 2 at 2000 rows, 8 at 1000 and below (launch_pair_counts).
+constexpr int PAIR_KMAX = 8;
 template <int TJ>
 __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
                                                       int m, int ldw, uint32_t *__restrict__ hit_out,
@@ -370,7 +376,10 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
                                                       int *__restrict__ undef_flag, int n_iblocks, int tile) {
     constexpr int TI = 8;
     typedef const __attribute__((address_space(4))) u32x8 *c8;
-    const int lane = threadIdx.x;
+    extern __shared__ uint32_t pair_part[];  // [K - 1][2][TI][64]: the partial counts of the waves 1 .. K-1
+    const int lane = threadIdx.x & 63;
+    const int K = (int)(blockDim.x >> 6), kw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cbeg = (int)((long)nchunk * kw / K), cend = (int)((long)nchunk * (kw + 1) / K);
     int ib, jb;
     pair_tile<TI, TJ>(n_iblocks, tile, ib, jb);
     const int i0 = ib * TI;  // uniform
@@ -427,7 +436,7 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
     auto step = [&](int c, uint32_t (&b)[TJ][8], uint32_t (&bn)[TJ][8]) {
         arrived(ga, miss);  // group A of chunk c
         request_b(gb, c);
-        request_j(bn, c + 1 < nchunk ? c + 1 : c);
+        request_j(bn, c + 1 < cend ? c + 1 : c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TI; ++t) {
@@ -442,7 +451,7 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
         }
         __builtin_amdgcn_sched_barrier(0);  // (the first phase must not sink below the wait: the wait would then follow its request at once)
         arrived(gb, d);  // group B of chunk c
-        request_a(ga, c + 1 < nchunk ? c + 1 : c);
+        request_a(ga, c + 1 < cend ? c + 1 : c);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TI; ++t)
@@ -456,20 +465,37 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    request_a(ga, 0);
-    request_j(b0, 0);
-    int c = 0;
+    if (cbeg < cend) {
+        request_a(ga, cbeg);
+        request_j(b0, cbeg);
+        int c = cbeg;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (; c + 1 < nchunk; c += 2) {  // (no branch inside the body: one basic block, the order above is the order issued)
-        step(c, b0, b1);
-        step(c + 1, b1, b0);
+        for (; c + 1 < cend; c += 2) {  // (no branch inside the body: one basic block, the order above is the order issued)
+            step(c, b0, b1);
+            step(c + 1, b1, b0);
+        }
+        if (c < cend) step(c, b0, b1);
+        arrived(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
     }
-    if (c < nchunk) step(c, b0, b1);
-    arrived(ga, miss);  // (the last request, a repeat of the last chunk, is not used)
+    if (K > 1) {
+        static_assert(TJ == 1, "the waves of a workgroup share a tile in the one-row-per-lane regime only");
+        if (kw > 0) {
+            uint32_t *mine = pair_part + (size_t)(kw - 1) * 2 * TI * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) mine[t * 64] = miss[0][t], mine[(TI + t) * 64] = dst[0][t];
+        }
+        __syncthreads();
+        if (kw > 0) return;
+        for (int w = 0; w < K - 1; ++w) {
+            const uint32_t *theirs = pair_part + (size_t)w * 2 * TI * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) miss[0][t] += theirs[t * 64], dst[0][t] += theirs[(TI + t) * 64];
+        }
+    }
     pair_epilogue<TI, TJ>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag);
 }
 template <int TJ>
-__global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
+__global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_pipe_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad,
                                                               int m, int ldw, uint32_t *__restrict__ hit_out,
                                                               uint32_t *__restrict__ dst_out, float *__restrict__ ident,
                                                               float *__restrict__ wmat, float *__restrict__ wlow,
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(64) void pair_counts_pipe_kernel(const uint32_t *__
     pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, n_iblocks, (int)blockIdx.x);
 }
 // (a batch holds alignments of the one-row-per-lane regime only -- below ~4100 sequences: pair_tiles_pipe)
-__global__ __launch_bounds__(64) void pair_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+__global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
     int local;
     const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
     pair_counts_pipe_body<1>(d.planes, d.nchunk, d.m_pad, d.m, d.ldw, nullptr, nullptr, d.ident, d.w, d.wlow, d.flags + 1,
@@ -869,6 +895,17 @@ void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 // Both on a one-dimensional grid over the tiles that hold pairs (j > i).  (A third loop on dense residue codes -- 8
 // instead of 11 VALU instructions per pair and word -- was built in round 2 and removed in round 3: collecting the byte
 // values and writing two more sets of planes ate what it gained, 3.22 -> 3.19 ms per trim at best.)
+// waves per tile (pair_counts_pipe_body): from ~8 waves per SIMD on (8192 tiles) a wave per tile is best -- the grid refills the
+// slots as tiles finish; below, up to eight waves per tile, at least eight chunks each (measured at 2000 x 10000, 4000 tiles:
+// 0.350 / 0.349 / 0.320 / 0.313 ms with 1 / 2 / 4 / 8 waves; 1000 x 4000: 0.074 -> 0.040; 500 x 2000: 0.033 -> 0.016; 3000 x 8000,
+// 8800 tiles: 0.514 with one wave, 0.530 with two)
+static int pair_split(long tiles, int nchunk) {
+    int k = 1;
+    if (tiles >= 8192) return k;
+    while (2 * k <= PAIR_KMAX && tiles * (2 * k) <= 32768 && nchunk >= 16 * k) k *= 2;
+    return k;
+}
+
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
                         uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag) {
     const long waves2 = (long)((m + PAIR_TI - 1) / PAIR_TI) * (m_pad / 128) / 2;
@@ -877,7 +914,11 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     const int R = 64 * (two ? 2 : 1) / PAIR_TI, jc = (nib + R - 1) / R - 1;
     const unsigned tiles = (unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib);
     if (two) pair_counts_kernel<PAIR_TI, 2><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
-    else pair_counts_pipe_kernel<1><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
+    else {
+        const int K = pair_split(tiles, nchunk);
+        pair_counts_pipe_kernel<1><<<tiles, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
+                                                                                                                wlow, undef_flag, nib);
+    }
 }
 
 // tiles of the pair pass in its one-row-per-lane regime (launch_pair_counts; what a batch uses for every alignment)
@@ -900,8 +941,9 @@ void launch_row_nongap_batch(hipStream_t s, const BAlign *table, const int32_t *
 void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
     if (blocks > 0) prep_planes_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
 }
-void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
-    if (blocks > 0) pair_counts_batch_kernel<<<blocks, 64, 0, s>>>(table, prefix, K);
+void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, int min_nchunk) {
+    const int W = pair_split(blocks, min_nchunk);  // (one value for the launch: by the tiles of the whole group)
+    if (blocks > 0) pair_counts_batch_kernel<<<blocks, 64 * W, (size_t)(W - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(table, prefix, K);
 }
 void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
     if (blocks > 0) sim_finish_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K, tuning().mdk_host);
