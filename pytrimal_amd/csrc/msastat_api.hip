@@ -120,6 +120,11 @@ struct msa_ctx {
     // flags: 16 words of flags (ST_*), then the gap counts and the indetermination counts (state_npad words each).
     DevBuf<int32_t> state;
     int state_npad = 0;
+    int state_rpad = 0;
+    DevBuf<int32_t> cscratch;    // the compact pipeline of small alignments (compact_begin): scratch words (msak::compact_scratch_words)
+    PinBuf<int32_t> h_cres;      // ... and its results, written by the kernels themselves into pinned host memory: the state block's
+                                 // layout, then the residues per sequence (state_rpad words), MDK and Q (state_npad floats each) and
+                                 // the verdict slots of the front kernel's blocks
     bool state_zeroed = false;   // for the current alignment
     bool errkey_dirty = false;   // an encode kernel may have written the first-bad-residue key since the state was zeroed
     bool flags_dirty = false;    // a kernel that may raise a flag was enqueued since the flags were last fetched
@@ -314,17 +319,27 @@ void invalidate(msa_ctx *c) {
 }
 
 // the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)
-int ensure_state(msa_ctx *c) {
-    if (c->state_zeroed) return MSA_OK;
+// the block and the views into it (no memset: ensure_state zeroes the flags and the counts, the compact pipeline writes every word)
+size_t state_words(const msa_ctx *c) { return ST_WORDS + (size_t)2 * c->state_npad; }
+// (the compact pipeline's mirror of the block in pinned host memory: behind the counts the residues per sequence, MDK, Q, the slots)
+size_t mirror_words(const msa_ctx *c) { return ST_WORDS + (size_t)4 * c->state_npad + c->state_rpad + msak::compact_slot_words(c->n); }
+int layout_state(msa_ctx *c) {
     c->state_npad = round_up(std::max(c->n, 1) + 64, 64);
-    const size_t words = ST_WORDS + (size_t)2 * c->state_npad;
-    HIPCHK(c, c->state.reserve(words));
+    c->state_rpad = round_up(std::max(c->m, 1) + 64, 64);
+    HIPCHK(c, c->state.reserve(state_words(c)));
     c->errflag.p = c->state.p + ST_ERRFLAG;
     c->pairflag.p = c->state.p + ST_PAIRFLAG;
     c->errkey.p = reinterpret_cast<unsigned long long *>(c->state.p + ST_ERRKEY);
     c->stats2.p = reinterpret_cast<float *>(c->state.p + ST_STATS);
     c->gaps.p = c->state.p + ST_WORDS;
     c->indets.p = c->gaps.p + c->state_npad;
+    return MSA_OK;
+}
+int ensure_state(msa_ctx *c) {
+    if (c->state_zeroed) return MSA_OK;
+    int rc = layout_state(c);
+    if (rc) return rc;
+    const size_t words = ST_WORDS + (size_t)2 * c->state_npad;
     HIPCHK(c, hipMemsetAsync(c->state.p, 0, words * sizeof(int32_t), c->stream));
     c->state_zeroed = true;
     c->errkey_dirty = false;
@@ -414,12 +429,9 @@ int stage_gaps(msa_ctx *c) {
     return MSA_OK;
 }
 
-// pair pass; want_* select which float matrices / integer matrices are produced
-int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
-    int rc = ensure_planes(c);
-    if (rc) return rc;
-    const bool need_ident = want_ident && !c->have_ident, need_w = want_w && !c->have_w;
-    if (!need_ident && !need_w && !want_counts) return MSA_OK;
+// the float matrices of the pair pass, sized, their padding zeroed
+int pair_buffers(msa_ctx *c, bool need_ident, bool need_w) {
+    int rc;
     const size_t fsz = (size_t)c->m * c->ldw + 512;  // slack: the similarity kernels read W a round past a row end
     // The pair pass writes every entry (i, j < m) of the float matrices and nothing else; the padding (columns m..ldw,
     // the rows and the slack behind row m, the diagonal and the unused triangle of W) must read as zero.  It is zeroed
@@ -438,7 +450,18 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
     if (need_w) {
         if ((rc = zero_for_shape(c->wmat, fsz))) return rc;
         if ((rc = zero_for_shape(c->wlow, lsz))) return rc;
+        HIPCHK(c, c->wbar.reserve((size_t)c->m + 128));
     }
+    return MSA_OK;
+}
+
+// pair pass; want_* select which float matrices / integer matrices are produced
+int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
+    int rc = ensure_planes(c);
+    if (rc) return rc;
+    const bool need_ident = want_ident && !c->have_ident, need_w = want_w && !c->have_w;
+    if (!need_ident && !need_w && !want_counts) return MSA_OK;
+    if ((rc = pair_buffers(c, need_ident, need_w))) return rc;
     if (want_counts) {
         HIPCHK(c, c->hit.reserve((size_t)c->m * c->m + 1));
         HIPCHK(c, c->dst.reserve((size_t)c->m * c->m + 1));
@@ -452,10 +475,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
                                  need_ident ? c->ident.p : nullptr, need_w ? c->wmat.p : nullptr, need_w ? c->wlow.p : nullptr,
                                  c->pairflag.p);
     }
-    if (need_w) {
-        HIPCHK(c, c->wbar.reserve((size_t)c->m + 128));
-        msak::launch_w_row_means(c->stream, c->wmat.p, c->m, c->ldw, c->wbar.p);
-    }
+    if (need_w) msak::launch_w_row_means(c->stream, c->wmat.p, c->m, c->ldw, c->wbar.p);
     HIPCHK(c, hipGetLastError());
     c->flags_dirty = true;
     c->pairflag_state = 1;  // (its flag word arrives with the next flag fetch: sync_stream)
@@ -657,9 +677,21 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
     return MSA_OK;
 }
 
+bool compact_sim_applies(const msa_ctx *c, int gap_hw);
+int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, bool gated);
+
 int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed,
                float *mdk_out, float *q_out, msa_err_detail *detail) {
     if (npos < 1 || npos > 28) return MSA_E_INVALID;
+    if (!gaps_windowed && !c->order_ready && compact_sim_applies(c, 0)) {  // a small alignment: three launches (compact_begin)
+        int rc = compact_begin(c, vhash, dist, npos, false);
+        c->pipe_active = false;
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        return fetch_similarity_finish(c, c->n, mdk_out, q_out, detail);
+    }
     const auto t_begin = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {  // MSA_TRACE=1: host time since the call began
         if (c->tuning.trace)
@@ -1171,6 +1203,181 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
     return MSA_OK;
 }
 
+
+// ---- the compact pipeline of a small alignment -------------------------------------------------------------------------
+// A trim of 46 x 1181 residues spends 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
+// 0.08 ms of kernels (profiles/r04_small_latency.jsonl).  Below `compact_max_m` sequences, with every column's wave resident at
+// once (no column order needed) and no gap window, the same statistics take THREE launches and one copy (msak::CompactArgs):
+//   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes and lists (the ">= 80 % gaps" cut
+//             from the block's own counts), all from one pass over the rows by independent blocks; no memset in front of it;
+//   pairs  -- the tiles of the pair pass; the workgroup that finishes last adds the mean weights, the identity statistics with
+//             the selectMethod gate, and folds the front kernel's verdicts into the flag words;
+//   sim    -- the similarity kernel over the columns in their own order, each wave writing its column's MDK and Q;
+//   ONE copy of the state block (flags, counts, row totals, MDK, Q), one wait.
+// The kernels' arithmetic is the ordinary path's (the same device functions); MSA_COMPACT=0 switches the pipeline off.
+bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
+    const msak::Tuning &t = c->tuning;
+    return t.compact != 0 && gap_hw == 0 && t.sim_kernel == 0 && (t.sim_mode & 64) == 0 && t.lg_rounds < 0 && t.lg_split == 0 &&
+           t.lg_big == 0 && c->m >= 2 && c->m <= std::min(t.compact_max_m, 512) && c->n <= c->cus * 20 &&
+           msak::pair_pipe_regime(c->m, c->m_pad);
+}
+bool compact_gaps_applies(const msa_ctx *c) {
+    return c->tuning.compact != 0 && !c->have_gaps && c->m >= 1 && c->m <= 4096 && (size_t)c->m * (size_t)c->ld <= ((size_t)4 << 20);
+}
+msak::CompactArgs compact_args(msa_ctx *c) {
+    msak::CompactArgs a = {};
+    a.raw = c->raw, a.ld = c->ld, a.m = c->m, a.n = c->n;
+    a.indet4 = 0x01010101u * c->indet;
+    a.flags = c->state.p;
+    a.gaps = c->gaps.p, a.indets = c->indets.p;
+    a.hres = c->h_cres.p;
+    a.h_gaps = ST_WORDS, a.h_indets = ST_WORDS + c->state_npad, a.h_rowtot = ST_WORDS + 2 * c->state_npad;
+    a.h_slots = ST_WORDS + 4 * c->state_npad + c->state_rpad;
+    a.scratch = c->cscratch.p;
+    a.wsum = reinterpret_cast<uint32_t *>(c->cscratch.p + 2);
+    a.ncols_pad = msak::bx_cols_pad(c->n);
+    return a;
+}
+// sizes the state block and its host mirror; the mirror's flag words start at zero (the kernels only ever raise them)
+int compact_prepare(msa_ctx *c) {
+    int rc = layout_state(c);
+    if (rc) return rc;
+    HIPCHK(c, c->cscratch.reserve(msak::compact_scratch_words(c->m, c->n)));
+    HIPCHK(c, c->h_cres.reserve(mirror_words(c)));
+    std::memset(c->h_cres.p, 0, ST_WORDS * sizeof(int32_t));
+    return MSA_OK;
+}
+// the one wait, and every host-side cache a pipelined trim reads filled from the mirror
+int compact_fetch(msa_ctx *c, bool sim) {
+    const int m = c->m, n = c->n;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->upload_pending = false;
+    int32_t *H = c->h_cres.p;
+    if (sim) {
+        // the verdicts of the front kernel's blocks -> the two flag words (what atomicOr / atomicMax leave there in the ordinary path)
+        const int32_t *S = H + ST_WORDS + 4 * c->state_npad + c->state_rpad;
+        const int ncb = msak::bx_cols_pad(n) / 64;
+        int bad = 0;
+        unsigned long long key = 0;
+        for (int i = 0; i < ncb; ++i) {
+            unsigned long long k;
+            std::memcpy(&k, S + 2 * i, sizeof(k));
+            key = std::max(key, k);
+            bad |= S[2 * ncb + i];
+        }
+        H[ST_ERRFLAG] = bad ? 1 : 0;
+        std::memcpy(H + ST_ERRKEY, &key, sizeof(key));
+    }
+    HIPCHK(c, c->h_flags.reserve(ST_FLAGS));
+    std::memcpy(c->h_flags.p, H, ST_FLAGS * sizeof(int32_t));
+    c->h_gaps.assign(H + ST_WORDS, H + ST_WORDS + n);
+    c->h_indets.assign(H + ST_WORDS + c->state_npad, H + ST_WORDS + c->state_npad + n);
+    HIPCHK(c, c->h_rowtot.reserve((size_t)m + 4));
+    std::memcpy(c->h_rowtot.p, H + ST_WORDS + 2 * c->state_npad, sizeof(int32_t) * m);
+    c->rowtot_staged = 2;
+    c->gaps_staged = 0;
+    c->have_gaps = true;
+    c->state_zeroed = true;  // (the front kernel wrote the device's flag words and both count vectors)
+    c->flags_dirty = false;
+    if (sim) {
+        HIPCHK(c, c->h_f32.reserve(std::max<size_t>((size_t)2 * 29 * 32 + 64, (size_t)2 * n + 64)));
+        const int32_t *F = H + ST_WORDS + 2 * c->state_npad + c->state_rpad;
+        std::memcpy(c->h_f32.p, F, sizeof(float) * n);
+        std::memcpy(c->h_f32.p + n, F + c->state_npad, sizeof(float) * n);
+    }
+    return MSA_OK;
+}
+// the gap statistics alone: one launch
+int compact_gaps(msa_ctx *c) {
+    int rc = compact_prepare(c);
+    if (rc) return rc;
+    msak::CompactArgs a = compact_args(c);
+    {
+        ProfScope ps(c, "gaps");
+        msak::launch_compact_front(c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->errkey_dirty = false;
+    return compact_fetch(c, false);
+}
+int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, bool gated) {
+    const int m = c->m, n = c->n;
+    int rc = ensure_tables(c, vhash, dist, npos);
+    if (rc) return rc;
+    if ((rc = compact_prepare(c))) return rc;
+    if ((rc = pair_buffers(c, gated, true))) return rc;
+    const size_t lsz = (size_t)msak::bx_cols_pad(n) * msak::bx_ldk(m) + 64;
+    HIPCHK(c, c->planes.reserve((size_t)msak::planes_total() * c->nchunk * c->m_pad + 64));
+    HIPCHK(c, c->codeT.reserve(lsz));
+    HIPCHK(c, c->bx_off.reserve(lsz));
+    HIPCHK(c, c->bx_trow.reserve(lsz));
+    HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
+    HIPCHK(c, c->simnum.reserve((size_t)n + 64));
+    HIPCHK(c, c->simden.reserve((size_t)n + 64));
+    if (gated) {
+        HIPCHK(c, c->row_avg.reserve(m + 64));
+        HIPCHK(c, c->row_max.reserve(m + 64));
+    }
+    msak::CompactArgs a = compact_args(c);
+    a.sim = 1;
+    a.lut = c->lut.p;
+    a.planes = c->planes.p, a.nchunk = c->nchunk, a.m_pad = c->m_pad;
+    a.codeT = c->codeT.p, a.ldk = msak::bx_ldk(m);
+    a.voff = c->bx_off.p, a.vtrow = c->bx_trow.p, a.nvalid = c->bx_nvalid.p;
+    a.ldw = c->ldw, a.skiprow = npos, a.big = 0;
+    a.ident = c->ident.p, a.row_avg = c->row_avg.p, a.row_max = c->row_max.p;
+    a.gated = gated ? 1 : 0;
+    float *mdk = reinterpret_cast<float *>(c->h_cres.p + ST_WORDS + 2 * c->state_npad + c->state_rpad);  // (the host mirror)
+    msak::LgAlign L = {};
+    L.voff = a.voff, L.vtrow = a.vtrow, L.nvalid = a.nvalid, L.codeT = a.codeT;
+    L.wlow = c->wlow.p, L.wup = c->wmat.p, L.wbar = c->wbar.p, L.wsum = a.wsum;
+    L.num_out = c->simnum.p, L.den_out = c->simden.p;
+    L.gate = gated ? c->state.p + ST_GATE : nullptr;
+    L.mdk_out = mdk, L.q_out = mdk + c->state_npad, L.mdk_host = c->tuning.mdk_host;
+    L.ldk = a.ldk, L.m = m, L.n = n, L.ldw = c->ldw, L.ncols = n;  // (cols = null: every column, in its own order)
+    const bool flat = m <= std::min(c->tuning.flat_max_m, msak::flat_rows_max());
+    a.lists = flat ? 0 : 1;
+    if (!flat && !msak::lg_finishes(L, c->cus)) return MSA_E_INVALID;  // (compact_sim_applies keeps such shapes and switches out)
+    {
+        ProfScope ps(c, "front");
+        msak::launch_compact_front(c->stream, a);
+    }
+    {
+        ProfScope ps(c, "pairs");
+        msak::launch_pair_counts(c->stream, c->planes.p, c->nchunk, c->m_pad, m, c->ldw, nullptr, nullptr, gated ? c->ident.p : nullptr,
+                                 c->wmat.p, c->wlow.p, c->h_cres.p + ST_PAIRFLAG, a.wsum);
+    }
+    if (gated) {
+        ProfScope ps(c, "idstats");
+        msak::launch_compact_identity(c->stream, a);
+    }
+    {
+        ProfScope ps(c, "sim");
+        if (flat) {
+            msak::launch_similarity_flat(c->stream, L, c->tab.p);
+            c->sim_launches = 1;
+        } else {
+            const int e = msak::launch_similarity_lg(c->stream, L, npos, c->tab.p, c->cus, &c->sim_launches);
+            if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    c->errkey_dirty = true;
+    if ((rc = compact_fetch(c, true))) return rc;
+    c->have_planes = true;
+    c->planes_pending = false;
+    c->have_w = true;
+    if (gated) c->have_ident = true;
+    c->pairflag_state = 2;  // (the flag words are on the host)
+    if (c->h_flags.p[ST_ERRFLAG]) {
+        c->have_planes = false;
+        return MSA_E_NON_ASCII;
+    }
+    c->pipe_active = true;
+    c->pipe_gated = gated;
+    return MSA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1231,7 +1438,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
     c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
-    c->gaps_w.release();
+    c->gaps_w.release(); c->cscratch.release(); c->h_cres.release();
     c->mdk.release(); c->simnum.release(); c->simden.release(); c->simstate.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
     c->equal.release(); c->keep_res_d.release(); c->keep_seq_d.release(); c->hashes.release();
@@ -1393,6 +1600,25 @@ int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
     pool.retire(job);
     return rc;
 }
+
+// Small alignments are not copied to the device at all: the rows are packed into the context's pinned staging area and the
+// kernels read them there, over the link (a copy costs the queue ~8 us whatever its size; the compact pipeline reads the rows
+// three times, 54 KB each at 46 x 1181).  Nothing is enqueued: no event, nothing for msa_trim to wait for.
+bool zero_copy_rows(const msa_ctx *c, int m, int n) {
+    return m > 0 && n > 0 && c->tuning.zerocopy_kb > 0 && (size_t)m * (size_t)c->ld <= ((size_t)c->tuning.zerocopy_kb << 10);
+}
+template <typename RowAt>
+int stage_rows_zero_copy(msa_ctx *c, int m, int n, RowAt row) {
+    // (every entry point returns with nothing in flight on the context's stream: no kernel still reads the staging area)
+    HIPCHK(c, c->h_raw.reserve((size_t)m * c->ld + 256));
+    for (int i = 0; i < m; ++i) {
+        uint8_t *dst = c->h_raw.p + (size_t)i * c->ld;
+        std::memcpy(dst, row(i), (size_t)n);
+        std::memset(dst + n, 0, (size_t)(c->ld - n));
+    }
+    c->raw = c->h_raw.p;  // (hipHostMalloc memory: the device reads it at the same address)
+    return MSA_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1424,6 +1650,7 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
     int rc = set_shape(c, m, n, indet);
     if (rc) return rc;
     c->ld = round_up(std::max(n, 1), 64);
+    if (zero_copy_rows(c, m, n)) return stage_rows_zero_copy(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {
@@ -1487,6 +1714,7 @@ int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n
     int rc = set_shape(c, m, n, indet);
     if (rc) return rc;
     c->ld = round_up(std::max(n, 1), 64);
+    if (zero_copy_rows(c, m, n)) return stage_rows_zero_copy(c, m, n, [&](int i) { return rows[i]; });
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {  // (straight from the row pointers into the pinned pieces: no packed copy in between)
@@ -1724,6 +1952,15 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
         gaps_w = c->h_gaps;
         c->pipe_active = pipelined;
         c->pipe_gated = pipelined && method == MSA_METHOD_AUTOMATED1;
+    } else if (pipelined && compact_sim_applies(c, gap_hw)) {
+        rc = compact_begin(c, p->vhash, p->dist, p->npos, method == MSA_METHOD_AUTOMATED1);
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        gaps_w = c->h_gaps;  // (no window)
+        pipe_waited = true;  // (compact_begin waits itself: there is nothing for the host to do in between)
+        trace.mark("compact pipeline");
     } else if (pipelined) {
         rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
         if (rc) {  // (nothing of a half-built pipeline may stay in flight over the staging buffers)
@@ -1733,8 +1970,11 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
         }
         trace.mark("pipeline enqueued");
     } else {
-        // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps
-        if ((rc = stage_row_totals(c))) return rc;
+        // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps -- a small alignment
+        // gets them together with its gap counts in one launch and one copy
+        if (compact_gaps_applies(c)) rc = compact_gaps(c);
+        else rc = stage_row_totals(c);
+        if (rc) return rc;
     }
     bool seq_mode = false, have_gap_cut = false;
     if (method == MSA_METHOD_NODUPLICATESEQS) {
@@ -1875,7 +2115,7 @@ int msa_trim_only_gaps_rows(msa_ctx *c, int32_t *rows, int32_t cap) {
 
 int msa_prof_get(msa_ctx *c, const char *kernel, float *ms_total, int32_t *launches) {
     if (!c || !kernel) return MSA_E_INVALID;
-    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster"};
+    static const char *names[] = {"gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster", "front"};
     bool known = false;
     for (const char *nm : names) known |= (std::strcmp(nm, kernel) == 0);
     if (!known) return MSA_E_INVALID;

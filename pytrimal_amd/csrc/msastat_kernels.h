@@ -20,6 +20,10 @@ struct Tuning {
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int lg_rounds = -1;        // MSA_LG_ROUNDS: rounds of the similarity kernel per launch (-1: by size, 0: one launch; tests: any)
     int lg_split = 0;          // MSA_LG_SPLIT: waves of a workgroup that share one column of the similarity kernel (0: by shape; tests: 1, 2, 4, 8, 16)
+    int compact = 1;           // MSA_COMPACT=0: small alignments through the ordinary launch sequence (tests, A/B); 1: the compact pipeline
+    int compact_max_m = 512;   // MSA_COMPACT_MAX_M: sequences up to which the similarity pipeline runs compact
+    int flat_max_m = 128;      // MSA_FLAT_MAX_M: sequences up to which the compact pipeline runs the flat similarity kernel (0: never)
+    int zerocopy_kb = 96;      // MSA_ZEROCOPY_KB: rows up to this size stay in pinned host memory and the kernels read them over the link
     int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
 };
 Tuning tuning_from_env();
@@ -36,7 +40,7 @@ void launch_prep_planes(hipStream_t s, const uint8_t *raw, int m, int n, int64_t
 void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, int32_t *gaps,
                        int32_t *indets);
 void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m_pad, int m, int ldw, uint32_t *hit,
-                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag);
+                        uint32_t *dst, float *ident, float *wmat, float *wlow, int *undef_flag, uint32_t *wsum = nullptr);
 int planes_total();  // planes in the plane array (seven symbol bits + validity)
 // the similarity kernel and its layouts (msastat_simx.hip)
 int64_t bx_ldk(int m);
@@ -57,14 +61,18 @@ struct LgAlign {
     const int32_t *nvalid;   // entries per column
     const uint8_t *codeT;    // column-major codes
     const float *wlow, *wup, *wbar;
+    const uint32_t *wsum;    // (with mdk_out) the pair pass's fixed-point row sums of W instead of wbar
     float *num_out, *den_out;
     float *state;            // lg_state_floats(n) floats: per-column state between launches (null: always one launch)
     const int *gate;         // device word that, when non-zero, turns the alignment's columns into no-ops (or null)
-    const int32_t *cols;     // single alignment: the columns to evaluate (ncols entries)
+    const int32_t *cols;     // single alignment: the columns to evaluate (ncols entries); null: the columns 0 .. ncols-1 themselves
+    float *mdk_out, *q_out;  // the compact pipeline: the wave that finishes a column also writes its MDK and Q (else null: sim_finish)
     int64_t ldk;
     int32_t m, n, ldw, ncols;
+    int32_t mdk_host;        // (with mdk_out) MSA_MDK_HOST: every exponential goes to the host as a NaN
 };
 int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out);
+bool lg_finishes(const LgAlign &one, int cus);  // launch_similarity_lg will honour one.mdk_out (else the caller runs sim_finish)
 int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int32_t *colprefix, int K, int ncols_total, int max_m, int npos,
                                const void *tab, bool with_state, int *launches_out);
 int lg_split(int m, int ncols, int cus);  // waves per column the launcher picks
@@ -92,6 +100,45 @@ struct BAlign {
     uint32_t indet4;
     int32_t gated;            // automated1: the identity statistics decide on the device whether the similarity values are needed
 };
+// The compact pipeline of one small alignment (msa_trim): THREE launches -- everything that reads the rows (gap counts, row
+// totals, planes, codes + lists), the pair pass (which also sums the rows' weights), the similarity kernel with the MDK values
+// (automated1: a fourth, the identity statistics) -- and one copy back, instead of a dozen launches, two memsets and four
+// copies: at 46 x 1181 a trim is 0.15 ms of queue operations around 0.08 ms of kernels (profiles/r04_small_latency.jsonl).  No
+// memset either: every word a kernel accumulates into is zeroed by the kernel in front of it (device pointers;
+// msastat_simx.hip: compact_front_kernel).
+struct CompactArgs {
+    const uint8_t *raw;       // [m][ld] residues (device memory, or pinned host memory read over the link: MSA_ZEROCOPY_KB)
+    int64_t ld;
+    int32_t m, n;
+    uint32_t indet4;
+    int32_t *flags;           // the context's 32 state words (ST_*) on the device: zeroed by the front kernel
+    int32_t *gaps, *indets;   // the device's copies of the two count vectors
+    int32_t *hres;            // the state block's mirror in pinned host memory, written by the kernels themselves (no copy back):
+    int32_t h_gaps, h_indets, h_rowtot, h_slots;  // ... word offsets of the count vectors, the residues per sequence and the slots
+                              // (per column block a first-bad-residue key, two words; then per column block a non-ASCII word)
+    int32_t *scratch;         // compact_scratch_words(): [0] the ticket of the identity statistics; from [2]: wsum
+    uint32_t *wsum;           // [m_pad + 64] fixed-point sums of W[i][j] over j > i (pair_epilogue), zeroed by the front kernel
+    int32_t sim;              // 0: the gap statistics only (gaps, indets, rowtot; one launch)
+    const uint8_t *lut;
+    uint32_t *planes;
+    int32_t nchunk, m_pad;
+    uint8_t *codeT;
+    int64_t ldk;
+    int32_t ncols_pad;
+    uint32_t *voff;
+    uint16_t *vtrow;
+    int32_t *nvalid;
+    int32_t ldw, skiprow, big;
+    int32_t lists;            // 0: codes only (the flat similarity kernel follows), 1: the compacted lists as well
+    float *ident, *row_avg, *row_max;
+    int32_t gated;            // automated1: the identity statistics + the selectMethod gate (compact_identity_kernel)
+};
+size_t compact_scratch_words(int m, int n);
+size_t compact_slot_words(int n);
+void launch_compact_front(hipStream_t s, const CompactArgs &a);
+void launch_compact_identity(hipStream_t s, const CompactArgs &a);
+int flat_rows_max();
+void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab);  // a wave per column: the column's pairs as one sequence
 int pair_tiles_pipe(int m, int m_pad);    // tiles of the pair pass in its one-row-per-lane regime
 bool pair_pipe_regime(int m, int m_pad);  // ... which launch_pair_counts picks for this shape (a batch holds no other)
 void launch_fetch_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);

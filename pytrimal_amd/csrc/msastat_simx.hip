@@ -39,6 +39,7 @@
 #include <algorithm>
 
 #include "msastat_kernels.h"
+#include "msastat_device.h"
 
 namespace msak {
 namespace {
@@ -474,7 +475,7 @@ constexpr int LG_STATE = 40;      // floats of per-column state between launches
 // The accumulators of every segment start at {B, B + u}: if the composed increments stay below B (the commit test of the
 // stitching), no segment's accumulator left the binade either, and a composed sum that reaches 2B is seen exactly as
 // before (all terms >= 0: a partial sum >= B stays >= B).
-template <bool STAMP, bool BIG, bool SPLIT>
+template <bool STAMP, bool BIG, bool SPLIT, bool FIN>
 __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, int ci, int nr, int r0_,
                                                    const float *__restrict__ tab_g, int jbegin, int jend) {
     const int S = SPLIT ? (int)(blockDim.x >> 6) : 1;  // waves that share the column
@@ -507,7 +508,12 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
     cv.m = m;
     const __attribute__((address_space(1))) uint16_t *vtrow =
         uniform_ptr((const __attribute__((address_space(1))) uint16_t *)(uint64_t)A.vtrow + (size_t)col * A.ldk);
-    const float *__restrict__ wbar = A.wbar;
+    // the mean weight of row j over its later partners: w_row_means' vector, or (FIN: the compact pipeline) the pair pass's
+    // fixed-point row sums divided here
+    auto wmean = [&](int j) -> float {
+        if constexpr (FIN) return j < m - 1 ? (float)A.wsum[j] * (1.0f / 65536.0f) / (float)(m - 1 - j) : 0.0f;
+        else return A.wbar[j];
+    };
     const int nv = cv.nvalid;
     unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0, n_both = 0;
     if (STAMP) {
@@ -555,7 +561,7 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
                     if (cj != BX_SKIP) {
                         ++tb;
                         seen = true;
-                        const float rem = (float)(nv - tb) * unif(wbar[jstart]);
+                        const float rem = (float)(nv - tb) * unif(wmean(jstart));
                         qd0 += rem;
                         qn0 += rem * gtab[wave][cj >> 3];
                         s2 = exact_row(cv, wup, tabp, jstart, cj, 3, s2);
@@ -621,7 +627,7 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
         const int behind = nv - (tbase + __builtin_popcountll(vall & ((2ull << lane) - 1ull)));
         const bool takes = cj8 != BX_SKIP;
         // (the row's mean weight over its partners, a property of the alignment: rows of a tight family add less)
-        const float qd = takes ? (float)behind * wbar[j0 + lane] : 0.0f;
+        const float qd = takes ? (float)behind * wmean(j0 + lane) : 0.0f;
         const float qn = takes ? qd * gtab[wave][cj8 >> 3] : 0.0f;
         float Bn, Bd, Qn, Qd;
         {
@@ -738,6 +744,11 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
     if (col < n && lane == 0) {
         A.num_out[col] = sn;
         A.den_out[col] = sd;
+        if constexpr (FIN) {  // (a column the ">= 80 % gaps" rule cuts has no valid row: den = 0, MDK = Q = 0 as sim_finish writes them)
+            float q;
+            A.mdk_out[col] = mdk_value(sn, sd, false, A.mdk_host, q);
+            A.q_out[col] = q;
+        }
     }
 }
 
@@ -745,7 +756,7 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
 // 32-bit byte offsets in the lists or row indices (BIG, m > 32768); a wave per column, four per workgroup, or (SPLIT) a
 // workgroup of blockDim / 64 waves per column.  One alignment (`one`, by value: no table to upload) or a batch: `table` + `items`
 // ({alignment, column} per work item -- msa_trim_batch's launch over every column of every alignment of a shard).
-template <bool STAMP, bool BIG, bool SPLIT>
+template <bool STAMP, bool BIG, bool SPLIT, bool FIN>
 __global__ __launch_bounds__(SPLIT ? 64 * LG_SPLIT_MAX : 64 * LG_WAVES_MAX) __attribute__((amdgpu_waves_per_eu(5, 5)))
 void similarity_lg_kernel(LgAlign one, const LgAlign *__restrict__ table, const int32_t *__restrict__ items, int nitems, int nr, int r0,
                           const float *__restrict__ tab_g, int jbegin, int jend) {
@@ -763,12 +774,12 @@ void similarity_lg_kernel(LgAlign one, const LgAlign *__restrict__ table, const 
             __builtin_memcpy(&one, words, sizeof(LgAlign));
         }
     } else if (ci < nitems) {
-        col = uni(one.cols[ci]);
+        col = one.cols ? uni(one.cols[ci]) : ci;
     }
     // (automated1 enqueues this kernel before the host knows which method the identity statistics select: the
     // kernel that computes them raises the gate when the similarity values will not be used)
     if (col >= 0 && one.gate && *one.gate) col = -1;
-    similarity_lg_body<STAMP, BIG, SPLIT>(one, col, ci, nr, r0, tab_g, jbegin, jend);
+    similarity_lg_body<STAMP, BIG, SPLIT, FIN>(one, col, ci, nr, r0, tab_g, jbegin, jend);
 }
 
 // ---- the statistic as the reference writes it ------------------------------------------------------------------------
@@ -877,25 +888,27 @@ __global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restr
 // selects gappyout, i.e. the similarity kernel enqueued behind this one has nothing to do; the host takes the same
 // decision from the same two numbers when they arrive)
 __device__ __forceinline__ void identity_final_body(const float *__restrict__ row_avg, const float *__restrict__ row_max,
-                                                    int m, float *__restrict__ out2, int *__restrict__ gate) {
+                                                    int m, float *__restrict__ out2, int *__restrict__ gate, int *__restrict__ gate_host = nullptr) {
     __shared__ float res[2];
     const int lane = threadIdx.x & 63;
     const int which = uni((int)(threadIdx.x >> 6));
-    const float *src = which ? row_max : row_avg;
-    float a = 0.0f;
-    for (int base = 0; base < m; base += 256) {
-        float xa[4];
+    if (which < 2) {  // (the compact pipeline calls this from a workgroup of eight waves)
+        const float *src = which ? row_max : row_avg;
+        float a = 0.0f;
+        for (int base = 0; base < m; base += 256) {
+            float xa[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int t = base + 64 * c + lane;
-            xa[c] = t < m ? src[t] : 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                const int t = base + 64 * c + lane;
+                xa[c] = t < m ? src[t] : 0.0f;
+            }
+            a = chunk_step(a, xa);
         }
-        a = chunk_step(a, xa);
-    }
-    if (lane == 0) {
-        a = a / (float)m;
-        out2[which] = a;
-        res[which] = a;
+        if (lane == 0) {
+            a = a / (float)m;
+            out2[which] = a;
+            res[which] = a;
+        }
     }
     __syncthreads();
     if (gate && threadIdx.x == 0) {
@@ -907,6 +920,7 @@ __device__ __forceinline__ void identity_final_body(const float *__restrict__ ro
         else if (mx >= 0.5 && mx <= 0.65) sel = 1;
         else sel = 2;
         *gate = sel == 1 ? 1 : 0;
+        if (gate_host) *gate_host = sel == 1 ? 1 : 0;
     }
 }
 __global__ __launch_bounds__(128) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
@@ -1143,6 +1157,330 @@ __global__ __launch_bounds__(256) void bx_compact_batch_kernel(const BAlign *__r
     bx_compact_body(d.codeT, d.ldk, d.m, d.ncols_pad, (uint32_t)d.ldw * 4u, d.off, d.trow, skiprow, d.nvalid, big, local);
 }
 
+
+// ---- small alignments, one at a time: the FLAT similarity kernel ---------------------------------------------------------
+// The binade-exact kernel above spends ~35 us on a column of 46 rows and ~100 us on one of 200: a prologue, a predictor,
+// ordered rows at every binade crossing -- fixed costs that m^2 / 2 terms per column repay only from a few hundred rows on.
+// Below that the terms of a column are few enough to be taken as ONE sequence: the pairs (j, k > j) of the column's valid
+// rows in the reference's order, 256 at a time through scan_lanes (flat_add_chunk below).  Its valid rows (index, code) are compacted into LDS from the
+// column-major codes; W[j][k] a gather from the (L2-resident) upper triangle; the distance from the LDS table.  No lists, no
+// predictor, no per-row state.  Two waves per column (one per sum); the numerator's wave writes MDK and Q itself (mdk_value).
+constexpr int FLAT_ROWS_MAX = 512;
+// 256 consecutive terms, FOUR CONSECUTIVE ones per lane (x[i]: term 4 lane + i), added to s in order.  A lane is to its four
+// terms what a lane of the kernel above is to its row: accumulators started at B and at B + u give its increments for an
+// even and an odd sum in front of it, scan_lanes composes the lanes (ties by parity, exact prefix sums) and names the first
+// lane whose sum would leave the binade; that lane's four terms are then added one by one, as the reference does, and the
+// lanes behind it start over on the new grid.  Every commit passes scan_lanes' test (sum < 2B), which also vouches for the
+// accumulators of the lanes it commits (terms >= 0: an increment below B means the accumulator never left [B, 2B)).
+__device__ __forceinline__ float flat_add_chunk(float s, const float (&x)[4], int lane) {
+    if (__ballot((x[0] != 0.0f) | (x[1] != 0.0f) | (x[2] != 0.0f) | (x[3] != 0.0f)) == 0ull) return s;
+    unsigned long long live = ~0ull;
+    while (live) {
+        float B, u;
+        int f;
+        if (grid_of(s, B, u)) {
+            const float Bo = B + u;
+            float ae = B, ao = Bo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ae = ae + x[i], ao = ao + x[i];
+            const float sp = scan_lanes(s, 2.0f * B, ae - B, ao - Bo, live, lane, f);
+            if (f >= 64) return rl(sp, 63);  // (live always ends at lane 63)
+            const unsigned long long before = live & ((1ull << f) - 1ull);
+            if (before) s = rl(sp, 63 - __builtin_clzll(before));
+        } else {
+            f = __builtin_ctzll(live);  // zero / tiny sum: the next lane's terms as the reference adds them
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = s + rl(x[i], f);
+        live &= ~((2ull << f) - 1ull);
+    }
+    return s;
+}
+__global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const float *__restrict__ tab_g) {
+    __shared__ f2 tab[32 * 32];                    // {distance, both valid}[row code][column code], rows 28.. zero
+    __shared__ uint32_t rows[4][FLAT_ROWS_MAX];    // per wave: the column's valid rows, index | table row << 16
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
+        f2 v = {0.0f, 0.0f};
+        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
+        tab[i] = v;
+    }
+    __syncthreads();
+    // TWO waves per column, one per sum: the chains are independent, and a lone wave on its SIMD issues an instruction of a
+    // dependent chain every ten cycles or so -- a second wave costs the walk over the pairs twice and still halves the time
+    __shared__ float sums[4];
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const int col = (int)blockIdx.x * 2 + (wave >> 1);
+    const bool denominator = (wave & 1) != 0;
+    // (automated1: selectMethod may have taken gappyout on the device)
+    const bool active = col < A.n && !(A.gate && *A.gate);
+    float sum = 0.0f;
+    if (active) {
+    const int m = A.m;
+    uint32_t *mine = rows[wave];
+    const gu8p code = (gu8p)(uint64_t)(A.codeT + (size_t)col * A.ldk);
+    int nv = 0;
+    for (int kb = 0; kb < m; kb += 64) {
+        const int k = kb + lane;
+        const uint32_t ck = k < m ? (uint32_t)code[k] : BX_SKIP;
+        const unsigned long long mask = __ballot(ck != BX_SKIP);
+        if (ck != BX_SKIP) mine[nv + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k | ((ck >> 3) << 16);
+        nv += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int T = nv * (nv - 1) / 2;  // pairs (a < b) of list positions, lexicographic: row a holds the nv - 1 - a pairs (a, b > a)
+    const gf32p wup = (gf32p)(uint64_t)A.wup;
+    const int ldw = A.ldw;
+    // Eight terms per lane and pass (two chunks of 256, four consecutive terms of each), requested a pass ahead: with one or
+    // two waves per SIMD (a wave per column, ~1000 columns) nothing else hides the gather's latency.  A lane walks its terms
+    // by (a, p) = the pair's row and its place in the row, advanced by carrying places into the next (shorter) rows -- no
+    // division, no root.
+    constexpr int U = 8;
+    int ra = 0, rp = 4 * lane, rt = 4 * lane;  // the lane's next term: row, place in the row, index
+    auto request = [&](float (&w)[U], uint32_t (&ti)[U]) {
+        uint32_t ea[U], eb[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            // (terms behind the last one: the last row's only pair, counted as zero by the caller)
+            while (__ballot(rt < T && rp >= nv - 1 - ra)) {
+                if (rt < T && rp >= nv - 1 - ra) rp -= nv - 1 - ra, ++ra;
+            }
+            const bool in = rt < T;
+            const int a = in ? ra : nv - 2, b = in ? ra + 1 + rp : nv - 1;
+            ea[i] = mine[a], eb[i] = mine[b];
+            const int step = (i & 3) == 3 ? 253 : 1;  // to the lane's first term of the next chunk
+            rp += step, rt += step;
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            w[i] = wup[(size_t)(ea[i] & 0xFFFFu) * ldw + (eb[i] & 0xFFFFu)];
+            ti[i] = (ea[i] >> 16) * 32 + (eb[i] >> 16);
+        }
+    };
+    if (T > 0) {
+        float w[U];
+        uint32_t ti[U];
+        request(w, ti);
+        for (int t0 = 0; t0 < T; t0 += 64 * U) {
+            float wn[U];
+            uint32_t tn[U];
+            request(wn, tn);
+            float x[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                if (t0 + 256 * (i >> 2) + 4 * lane + (i & 3) >= T) w[i] = 0.0f;
+                x[i] = denominator ? w[i] : w[i] * tab[ti[i]].x;
+            }
+#pragma unroll
+            for (int h = 0; h < U; h += 4) {
+                if (t0 + 64 * h >= T) break;  // (the pass's second chunk starts at term t0 + 256)
+                const float xs[4] = {x[h], x[h + 1], x[h + 2], x[h + 3]};
+                sum = flat_add_chunk(sum, xs, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < U; ++i) w[i] = wn[i], ti[i] = tn[i];
+        }
+    }
+    }
+    if (lane == 0) sums[wave] = sum;
+    __syncthreads();
+    if (active && !denominator && lane == 0) {
+        const float sn = sums[wave], sd = sums[wave + 1];
+        if (A.num_out) A.num_out[col] = sn, A.den_out[col] = sd;
+        float q;
+        A.mdk_out[col] = mdk_value(sn, sd, false, A.mdk_host, q);
+        A.q_out[col] = q;
+    }
+}
+
+// ---- the compact pipeline of a small alignment (CompactArgs, msastat_kernels.h) -------------------------------------------
+// Front kernel, one launch for everything that reads the rows.  Blocks by role:
+//   * a COLUMN block owns 64 columns over all rows, read once (64 consecutive bytes of a row per wave and load): their gap and
+//     indetermination counts (plain stores: no atomics, hence no memset), the bit planes of the pair pass (a thread per row on
+//     the 64 x 64 tile in LDS: planes_of_row), and -- the ">= 80 % gaps" cut follows from the block's own counts -- the
+//     column-major codes and the compacted lists.  The block's codes live in LDS ([column][row] bytes) between the pass over
+//     the rows and the pass that writes them out: nothing is read back from memory.  A bad residue counts only in a column
+//     that is not cut: the first bad row of every column by an LDS minimum, the block's first bad residue and its non-ASCII
+//     verdict into the block's own slots;
+//   * a ROW block: the residues of four sequences (row_nongap_body).
+// Block 0 zeroes the device's flag words, the identity statistics' ticket and the pair pass's row sums (nothing of this launch
+// touches them).  Results go to the state block's mirror in pinned host memory as well (`hres`: same offsets; the rows' totals,
+// the slots, MDK and Q only there): no copy back, the host folds the slots into the two flag words after the wait.
+constexpr int COMPACT_ROWS_MAX = 512;  // rows of the LDS code array of a column block
+template <bool SIM>
+__device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b) {
+    constexpr int LDC = COMPACT_ROWS_MAX + 4;  // bytes per column (4 past a multiple of 128: consecutive columns on different banks)
+    __shared__ uint8_t lut[256];
+    __shared__ uint8_t codes[SIM ? 64 * LDC : 4];
+    __shared__ uint32_t rawt[SIM ? 64 * 17 : 1];  // a tile's bytes, [row][64 columns + 4]
+    __shared__ uint32_t cnt[2][4][64];
+    __shared__ uint32_t firstbad[64];
+    __shared__ uint8_t skipc[64];
+    __shared__ int anybad;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int m = a.m, n = a.n;
+    const int64_t ld = a.ld, ldk = a.ldk;
+    const int c = b * 64 + tx;
+    const bool inb = c < n;
+    if (SIM) {
+        lut[threadIdx.x] = a.lut[threadIdx.x];
+        if (threadIdx.x < 64) firstbad[threadIdx.x] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) anybad = 0;
+        __syncthreads();
+    }
+    const uint32_t indet = a.indet4 & 0xFFu;
+    const uint8_t *col0 = a.raw + (inb ? c : 0);
+    const int mtiles = (m + 63) / 64;
+    uint32_t g = 0, x = 0;
+    for (int by = 0; by < mtiles; ++by) {
+        uint32_t bytes[16];  // (sixteen rows requested before the first is looked at)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = by * 64 + ty + 4 * i;
+            bytes[i] = (row < m && inb) ? (uint32_t)col0[(size_t)row * ld] : 0x100u;  // 0x100: outside, counts as nothing
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t byte = bytes[i];
+            g += byte == (uint32_t)'-';
+            x += byte == indet;
+            if (SIM) {
+                const int row = by * 64 + ty + 4 * i;
+                uint32_t code = BX_SKIP;
+                if (byte < 0x100u) {
+                    code = lut[byte];  // 8 x table row, 224 = skipped, 0xFE / 0xFF = bad symbol
+                    if (code >= 0xFEu) {
+                        atomicMin(&firstbad[tx], ((uint32_t)row << 16) | ((code & 1u) << 8) | byte);
+                        code = BX_SKIP;
+                    }
+                }
+                codes[tx * LDC + row] = (uint8_t)code;
+                reinterpret_cast<uint8_t *>(rawt)[(ty + 4 * i) * 68 + tx] = (uint8_t)(byte < 0x100u ? byte : (uint32_t)'-');
+            }
+        }
+        if (SIM) {
+            __syncthreads();
+            if (ty == 0) {  // a thread per row of the tile: its two chunk words of every plane
+                const int row = by * 64 + tx;
+                uint32_t out[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) out[h][p] = 0;
+                uint32_t bad = 0;
+                if (row < m) {
+                    uint32_t w[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) w[q] = rawt[tx * 17 + q];
+                    bad = planes_of_row(w, b * 64, n, a.indet4, out);
+                }
+                if (row < a.m_pad) planes_store(a.planes, a.nchunk, a.m_pad, b, row, out);
+                if (bad) anybad = 1;
+            }
+            __syncthreads();
+        }
+    }
+    if (SIM && ty == 1) {  // the rows between the last tile and m_pad: zero in every plane
+        const uint32_t zero[2][8] = {};
+        for (int row = mtiles * 64 + tx; row < a.m_pad; row += 64) planes_store(a.planes, a.nchunk, a.m_pad, b, row, zero);
+    }
+    cnt[0][ty][tx] = g;
+    cnt[1][ty][tx] = x;
+    __syncthreads();
+    if (ty == 0) {
+        const uint32_t G = cnt[0][0][tx] + cnt[0][1][tx] + cnt[0][2][tx] + cnt[0][3][tx];
+        const uint32_t X = cnt[1][0][tx] + cnt[1][1][tx] + cnt[1][2][tx] + cnt[1][3][tx];
+        if (inb) {
+            a.gaps[c] = (int32_t)G;
+            a.indets[c] = (int32_t)X;
+            a.hres[a.h_gaps + c] = (int32_t)G;
+            a.hres[a.h_indets + c] = (int32_t)X;
+        }
+        if (SIM) {
+            const bool skip = !inb || (((float)(int32_t)G / (float)m) >= 0.8f);
+            skipc[tx] = skip ? 1 : 0;
+            // the block's first bad residue: smallest column, then smallest row -- the key of sim_encode_cm, complemented
+            unsigned long long key = ~0ull;
+            if (!skip && firstbad[tx] != 0xFFFFFFFFu) key = ((unsigned long long)c << 40) | firstbad[tx];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = other < key ? other : key;
+            }
+            if (tx == 0) {
+                key = key == ~0ull ? 0ull : ~key;
+                a.hres[a.h_slots + 2 * b] = (int32_t)(uint32_t)key;
+                a.hres[a.h_slots + 2 * b + 1] = (int32_t)(uint32_t)(key >> 32);
+                a.hres[a.h_slots + 2 * (a.ncols_pad / 64) + b] = anybad;
+            }
+        }
+    }
+    if (SIM) {
+        __syncthreads();
+        // a wave per column, lane = row: the codes (coalesced) and the compacted lists, as sim_encode_cm and bx_compact write them
+        const int lane = tx;
+        const uint32_t ldw4 = (uint32_t)a.ldw * 4u;
+        for (int q = ty; q < 64; q += 4) {
+            const size_t col = (size_t)b * 64 + q;
+            const bool skip = skipc[q] != 0;
+            uint8_t *ct = a.codeT + col * ldk;
+            uint32_t *po = a.voff + col * ldk;
+            uint16_t *pt = a.vtrow + col * ldk;
+            int count = 0;
+            for (int kb = 0; kb < mtiles * 64; kb += 64) {
+                const int k = kb + lane;
+                const uint32_t code = (k < m && !skip) ? (uint32_t)codes[q * LDC + k] : BX_SKIP;
+                ct[k] = (uint8_t)code;
+                if (!a.lists) continue;  // (the flat similarity kernel reads the codes alone)
+                const unsigned long long mask = __ballot(code != BX_SKIP);
+                if (code != BX_SKIP) {
+                    const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    po[pos] = a.big ? (uint32_t)k : (uint32_t)k * ldw4;
+                    pt[pos] = (uint16_t)((code >> 3) * 256u);
+                }
+                count += __builtin_popcountll(mask);
+            }
+            if (!a.lists) continue;
+            for (int64_t k = (int64_t)mtiles * 64 + lane; k < ldk; k += 64) ct[k] = (uint8_t)BX_SKIP;
+            for (int64_t t = count + lane; t < ldk; t += 64) {
+                po[t] = a.big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+                pt[t] = (uint16_t)(a.skiprow * 256);               // the table's zero row
+            }
+            if (lane == 0) a.nvalid[col] = count;
+        }
+    }
+}
+template <bool SIM>
+__global__ __launch_bounds__(256) void compact_front_kernel(CompactArgs a) {
+    const int b = (int)blockIdx.x;
+    const int ncb = a.ncols_pad / 64;
+    if (b == 0) {
+        if (threadIdx.x < 32) a.flags[threadIdx.x] = 0;
+        if (SIM) {
+            if (threadIdx.x == 0) a.scratch[0] = 0;  // the ticket of the identity statistics
+            for (int i = threadIdx.x; i < a.m_pad + 64; i += 256) a.wsum[i] = 0u;
+        }
+    }
+    if (b < ncb) compact_column_block<SIM>(a, b);
+    else row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
+}
+
+// automated1: the identity statistics -- a wave per sequence (identity_rows_body), and in the workgroup that finishes last (a
+// ticket) the two means and Cleaner::selectMethod's decision (identity_final_body): one launch for the ordinary path's two.
+__global__ __launch_bounds__(256) void compact_identity_kernel(CompactArgs a) {
+    identity_rows_body(a.ident, a.m, a.ldw, a.row_avg, a.row_max, nullptr, (int)blockIdx.x);
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // (release: the workgroup's four rows, device-wide -- its waves' stores are complete behind the barrier)
+        last = atomicAdd(a.scratch, 1) == (int)gridDim.x - 1;
+        __threadfence();  // (acquire)
+    }
+    __syncthreads();
+    if (!last) return;
+    identity_final_body(a.row_avg, a.row_max, a.m, reinterpret_cast<float *>(a.hres + 4), a.flags + 6, a.hres + 6);
+}
+
 }  // namespace
 
 // leading dimension of the per-column lists: the valid rows, then >= 192 padding entries (a block of the ordered
@@ -1214,9 +1552,10 @@ static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, co
     const int launches = per > 0 && per < rounds ? (rounds + per - 1) / per : 1;
     LgAlign a1 = one;
     if (launches == 1) a1.state = nullptr;  // (nothing to carry over)
+    const bool fin = one.mdk_out && !table && !stamp && !big && split == 1 && launches == 1;
 #define LG_LAUNCH(STAMP_, BIG_, SPLIT_)                                                                                \
     do {                                                                                                               \
-        auto kernel = similarity_lg_kernel<STAMP_, BIG_, SPLIT_>;                                                      \
+        auto kernel = similarity_lg_kernel<STAMP_, BIG_, SPLIT_, false>;                                               \
         const size_t dyn = (size_t)(SPLIT_ ? 1 : waves) * nr * 256;                                                    \
         const unsigned grid = SPLIT_ ? (unsigned)nitems : (unsigned)((nitems + waves - 1) / waves);                    \
         const int e = set_max_lds_once((const void *)kernel, (int)dyn);                                                \
@@ -1230,7 +1569,13 @@ static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, co
         if (big) LG_LAUNCH(STAMP_, true, SPLIT_);    \
         else LG_LAUNCH(STAMP_, false, SPLIT_);       \
     } while (0)
-    if (stamp && split > 1) LG_BY_BIG(true, true);
+    if (fin) {  // (lg_finishes: no stamps, 32-bit offsets, a wave per column, one launch)
+        auto kernel = similarity_lg_kernel<false, false, false, true>;
+        const size_t dyn = (size_t)waves * nr * 256;
+        const int e = set_max_lds_once((const void *)kernel, (int)dyn);
+        if (e) return e;
+        kernel<<<(unsigned)((nitems + waves - 1) / waves), 64 * waves, dyn, s>>>(a1, table, items, nitems, nr, r0, t, 0, 0x7FFFFFFF);
+    } else if (stamp && split > 1) LG_BY_BIG(true, true);
     else if (stamp) LG_BY_BIG(true, false);
     else if (split > 1) LG_BY_BIG(false, true);
     else LG_BY_BIG(false, false);
@@ -1240,6 +1585,11 @@ static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, co
     return 0;
 }
 
+bool lg_finishes(const LgAlign &one, int cus) {
+    const int rounds = (std::max(one.m, 2) - 1 + 63) / 64, per = one.state ? lg_rounds_per_launch(one.m) : 0;
+    return one.mdk_out && (tuning().sim_mode & 64) == 0 && !lg_big(one.m, one.ldw) && lg_split(one.m, one.ncols, cus) == 1 &&
+           !(per > 0 && per < rounds);
+}
 int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out) {
     const int split = lg_split(one.m, one.ncols, cus);
     return launch_lg(s, one, nullptr, nullptr, one.ncols, one.m, one.ldw, npos, tab, one.state != nullptr, split, launches_out);
@@ -1274,6 +1624,24 @@ void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *p
                             int blocks_compact, int K, const uint8_t *lut, int npos) {
     if (blocks_encode > 0) sim_encode_cm_batch_kernel<<<blocks_encode, 256, 0, s>>>(table, prefix_encode, K, lut);
     if (blocks_compact > 0) bx_compact_batch_kernel<<<blocks_compact, 256, 0, s>>>(table, prefix_compact, K, npos, tuning().lg_big != 0 ? 1 : 0);
+}
+
+
+// words of the slots behind the state block's mirror: a first-bad-residue key (two words) and a non-ASCII word per column block
+size_t compact_slot_words(int n) { return (size_t)3 * (bx_cols_pad(n) / 64) + 2; }
+size_t compact_scratch_words(int m, int n) { return (size_t)2 + (std::max(m, 1) + 127) / 128 * 128 + 64 + 8; }
+void launch_compact_front(hipStream_t s, const CompactArgs &a) {
+    const unsigned blocks = (unsigned)(a.ncols_pad / 64 + (a.m + 3) / 4);
+    if (a.sim) compact_front_kernel<true><<<blocks, 256, 0, s>>>(a);
+    else compact_front_kernel<false><<<blocks, 256, 0, s>>>(a);
+}
+// the flat similarity kernel: any alignment of up to FLAT_ROWS_MAX rows whose codes exist (A.codeT, A.wup, A.mdk_out, A.q_out)
+int flat_rows_max() { return FLAT_ROWS_MAX; }
+void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab) {
+    if (one.n > 0) similarity_flat_kernel<<<(unsigned)((one.n + 1) / 2), 256, 0, s>>>(one, static_cast<const float *>(tab));
+}
+void launch_compact_identity(hipStream_t s, const CompactArgs &a) {
+    compact_identity_kernel<<<(unsigned)((a.m + 3) / 4), 256, 0, s>>>(a);
 }
 
 // mean weight of every row over its later partners (m + 64 floats): the similarity kernel's predictor reads it

@@ -143,7 +143,8 @@ class BaseTrimmer:
             # second trim on -- every further upload is one DMA copy from where they lie -- until the matrix dies or the
             # process-wide budget needs the room (PYTRIMAL_AMD_PIN_MB, least recently uploaded first; 0 = never)
             uploads = alignment._uploads = getattr(alignment, "_uploads", 0) + 1
-            if uploads == 2 or not uploads & 15:  # (and again now and then: the budget may have unpinned it since)
+            # (rows of less than 96 KB are packed into the context's own pinned area and read there by the kernels: nothing to lock)
+            if (uploads == 2 or not uploads & 15) and dense.nbytes > (96 << 10):  # (and again now and then: the budget may have unpinned it since)
                 _lib.pin_array(dense)
         ty = alignment._alignment_type()
         indet = ord("X") if (ty & 4) else ord("N")

@@ -34,7 +34,8 @@ def ctx_with(monkeypatch):
     made = []
 
     def make(**env):
-        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT"):
+        for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT",
+                     "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -404,9 +405,13 @@ def _sim_parity(ctx, a, indet=ord("X")):
 # rounds per launch), the columns' state passed through memory
 # lg-split-S: S waves of a workgroup share one column, each on a segment of every round's partner list (what the launcher
 # picks by itself for tall alignments: fewer columns than wave slots); the increment pairs of the segments compose exactly
-KERNELS = [dict(), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="2"), dict(MSA_LG_SPLIT="4", MSA_LG_ROUNDS="1"),
-           dict(MSA_LG_SPLIT="8"), dict(MSA_LG_SPLIT="16", MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq")]
-KERNEL_IDS = ["lg", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8", "lg-split-16-big", "seq"]
+# (the default path of a small alignment is the compact pipeline -- three launches -- with the flat similarity kernel up to 128
+# rows and the wave-per-column kernel from there to 512; MSA_COMPACT=0 is the ordinary launch sequence at every size)
+KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLAT_MAX_M="512"), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"),
+           dict(MSA_LG_SPLIT="2"), dict(MSA_LG_SPLIT="4", MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="8"), dict(MSA_LG_SPLIT="16", MSA_LG_BIG="1"),
+           dict(MSA_SIM_KERNEL="seq")]
+KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
+              "lg-split-16-big", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)

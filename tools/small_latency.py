@@ -40,7 +40,7 @@ for m, n in SIZES:
             ctx.upload(dense, indet)
             ctx.trim(params)
         kern = {}
-        for k in ("gaps", "prep", "pairs", "idstats", "encode", "sim"):
+        for k in ("front", "gaps", "prep", "pairs", "idstats", "encode", "sim"):
             ms, cnt = ctx.prof_get(k)
             if cnt:
                 kern[k] = round(ms / cnt, 4)

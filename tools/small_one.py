@@ -1,0 +1,28 @@
+"""One small alignment trimmed again and again through the C ABI (upload + msa_trim): the command a profiler is pointed at.
+   python tools/small_one.py [m n [method [count]]]      e.g.  rocprofv3 --kernel-trace --stats -d out -- python3 tools/small_one.py 46 1181 strict 300"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401
+from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
+from pytrimal_amd.synth import synth_msa
+
+m, n = (int(x) for x in sys.argv[1:3]) if len(sys.argv) > 2 else (46, 1181)
+method = sys.argv[3] if len(sys.argv) > 3 else "strict"
+count = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+a = synth_msa(m, n, 77 + m)
+ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+tr = AutomaticTrimmer(method, platform="hip")
+for _ in range(5):
+    tr.trim(ali)
+names, dense, indet, params, keep = tr._prepare(ali)
+ctx = _lib.thread_context()
+best = 1e9
+for rep in range(3):
+    t = time.perf_counter()
+    for _ in range(count):
+        ctx.upload(dense, indet)
+        ctx.trim(params)
+    best = min(best, (time.perf_counter() - t) / count)
+print(f"{m} x {n} {method}: {best * 1e3:.4f} ms per upload + msa_trim", flush=True)
+ctx.close()  # (not at interpreter exit: under a profiler the runtime may be gone by then)
