@@ -1205,15 +1205,18 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 
 
 // ---- the compact pipeline of a small alignment -------------------------------------------------------------------------
-// A trim of 46 x 1181 residues spends 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
-// 0.08 ms of kernels (profiles/r04_small_latency.jsonl).  Below `compact_max_m` sequences, with every column's wave resident at
-// once (no column order needed) and no gap window, the same statistics take THREE launches and one copy (msak::CompactArgs):
-//   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes and lists (the ">= 80 % gaps" cut
+// A trim of 46 x 1181 residues spent 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
+// 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to `compact_max_m` sequences, with every
+// column's wave resident at once (no column order needed) and no gap window, the same statistics take THREE launches and no copy
+// (msak::CompactArgs):
+//   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes (+ lists; the ">= 80 % gaps" cut
 //             from the block's own counts), all from one pass over the rows by independent blocks; no memset in front of it;
-//   pairs  -- the tiles of the pair pass; the workgroup that finishes last adds the mean weights, the identity statistics with
-//             the selectMethod gate, and folds the front kernel's verdicts into the flag words;
-//   sim    -- the similarity kernel over the columns in their own order, each wave writing its column's MDK and Q;
-//   ONE copy of the state block (flags, counts, row totals, MDK, Q), one wait.
+//   pairs  -- the ordinary pair pass, whose tiles also add up the rows' weight sums (the predictor's input);
+//   [automated1: the identity statistics with the selectMethod gate, one launch]
+//   sim    -- up to `flat_max_m` sequences the flat kernel, else the wave-per-column kernel over the columns in their own order;
+//             the wave that finishes a column writes its MDK and Q;
+//   every result is stored by the kernels into a mirror of the state block in pinned host memory (h_cres): one wait, then the
+//   host folds the front kernel's per-block verdicts into the two flag words.
 // The kernels' arithmetic is the ordinary path's (the same device functions); MSA_COMPACT=0 switches the pipeline off.
 bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
     const msak::Tuning &t = c->tuning;

@@ -22,28 +22,38 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
 
 // prep_planes: raw bytes -> bit-sliced planes.  One thread = one row x 64 columns (a full 64-B line of that row); lanes of a
 // wave own consecutive rows so the plane stores coalesce.
-// The sixteen dwords of a row's 64-column group -> its two chunk words of every plane; returns the non-ASCII bits seen.
+// Four dwords (16 columns from col0 on) of a row -> 16 bits of every plane (bit = column - col0); returns the non-ASCII bits seen.
+__device__ __forceinline__ uint32_t planes_of_quarter(const uint32_t *w, int col0, int n, uint32_t indet4, uint32_t (&out)[8]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int col = col0 + e * 4;  // first column of this dword
+        uint32_t x = w[e];
+        // mask columns >= n (undefined bytes) to '-' so they are invalid everywhere
+        uint32_t keep = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) keep |= (col + k < n) ? (0xFFu << (8 * k)) : 0u;
+        x = (x & keep) | (0x2d2d2d2du & ~keep);
+        bad |= x & 0x80808080u;
+        uint32_t inval = zero_bytes(x ^ 0x2d2d2d2du) | zero_bytes(x ^ indet4);  // 0x80 flags
+        uint32_t vbits = gather_bit4(~inval, 7);
+#pragma unroll
+        for (int p = 0; p < 7; ++p) out[p] |= gather_bit4(x, p) << (e * 4);
+        out[7] |= vbits << (e * 4);
+    }
+    return bad;
+}
+// The sixteen dwords of a row's 64-column group -> its two chunk words of every plane.
 __device__ __forceinline__ uint32_t planes_of_row(const uint32_t (&w)[16], int col0, int n, uint32_t indet4, uint32_t (&out)[2][8]) {
     uint32_t bad = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        uint32_t o[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int col = col0 + q * 16 + e * 4;  // first column of this dword
-            uint32_t x = w[q * 4 + e];
-            // mask columns >= n (undefined bytes) to '-' so they are invalid everywhere
-            uint32_t keep = 0;
+        for (int p = 0; p < 8; ++p) o[p] = 0;
+        bad |= planes_of_quarter(w + q * 4, col0 + q * 16, n, indet4, o);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) keep |= (col + k < n) ? (0xFFu << (8 * k)) : 0u;
-            x = (x & keep) | (0x2d2d2d2du & ~keep);
-            bad |= x & 0x80808080u;
-            uint32_t inval = zero_bytes(x ^ 0x2d2d2d2du) | zero_bytes(x ^ indet4);  // 0x80 flags
-            uint32_t vbits = gather_bit4(~inval, 7);
-            const int h = q >> 1, sh = ((q & 1) * 4 + e) * 4;
-#pragma unroll
-            for (int p = 0; p < 7; ++p) out[h][p] |= gather_bit4(x, p) << sh;
-            out[h][7] |= vbits << sh;
-        }
+        for (int p = 0; p < 8; ++p) out[q >> 1][p] |= o[p] << ((q & 1) * 16);
     }
     return bad;
 }

@@ -1306,37 +1306,56 @@ __global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const f
 // touches them).  Results go to the state block's mirror in pinned host memory as well (`hres`: same offsets; the rows' totals,
 // the slots, MDK and Q only there): no copy back, the host folds the slots into the two flag words after the wait.
 constexpr int COMPACT_ROWS_MAX = 512;  // rows of the LDS code array of a column block
+constexpr int COMPACT_TEAMS_MAX = 4;  // 64-row tiles a column block works on at once (a team of four waves each)
 template <bool SIM>
 __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b) {
     constexpr int LDC = COMPACT_ROWS_MAX + 4;  // bytes per column (4 past a multiple of 128: consecutive columns on different banks)
+    constexpr int TM = COMPACT_TEAMS_MAX;
     __shared__ uint8_t lut[256];
     __shared__ uint8_t codes[SIM ? 64 * LDC : 4];
-    __shared__ uint32_t rawt[SIM ? 64 * 17 : 1];  // a tile's bytes, [row][64 columns + 4]
-    __shared__ uint32_t cnt[2][4][64];
+    __shared__ uint32_t rawt[SIM ? TM * 64 * 17 : 1];  // per team a tile's bytes, [row][64 columns + 4]
+    __shared__ uint32_t cnt[2][4 * TM][64];
     __shared__ uint32_t firstbad[64];
     __shared__ uint8_t skipc[64];
     __shared__ int anybad;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // The workgroup is `teams` teams of four waves; team t takes the tiles t, t + teams, ...: a tile is a chain of small
+    // latencies (loads, LDS, two barriers), and a column block of 500 rows that walked its eight tiles one after the other
+    // took 58 us where the whole alignment's pair pass takes 18.
+    const int teams = (int)(blockDim.x >> 8), team = (int)(threadIdx.x >> 8), tid = (int)(threadIdx.x & 255);
+    const int tx = threadIdx.x & 63, ty = tid >> 6, wave = (int)(threadIdx.x >> 6), nwaves = 4 * teams;
     const int m = a.m, n = a.n;
     const int64_t ld = a.ld, ldk = a.ldk;
     const int c = b * 64 + tx;
     const bool inb = c < n;
+    uint8_t lutbyte = 0;
     if (SIM) {
-        lut[threadIdx.x] = a.lut[threadIdx.x];
+        if (threadIdx.x < 256) lutbyte = a.lut[threadIdx.x];  // (requested with the first tile's rows; stored behind them)
         if (threadIdx.x < 64) firstbad[threadIdx.x] = 0xFFFFFFFFu;
         if (threadIdx.x == 0) anybad = 0;
-        __syncthreads();
     }
     const uint32_t indet = a.indet4 & 0xFFu;
     const uint8_t *col0 = a.raw + (inb ? c : 0);
-    const int mtiles = (m + 63) / 64;
+    const int mtiles = (m + 63) / 64, passes = (mtiles + teams - 1) / teams;
     uint32_t g = 0, x = 0;
-    for (int by = 0; by < mtiles; ++by) {
-        uint32_t bytes[16];  // (sixteen rows requested before the first is looked at)
+    uint32_t next[16];  // (sixteen rows requested before the first is looked at, and a pass ahead of the one being worked on)
+    auto request = [&](int by) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = by * 64 + ty + 4 * i;
-            bytes[i] = (row < m && inb) ? (uint32_t)col0[(size_t)row * ld] : 0x100u;  // 0x100: outside, counts as nothing
+            next[i] = (row < m && inb) ? (uint32_t)col0[(size_t)row * ld] : 0x100u;  // 0x100: outside, counts as nothing
+        }
+    };
+    request(team);
+    uint32_t *myraw = rawt + (SIM ? team * 64 * 17 : 0);
+    for (int ps = 0; ps < passes; ++ps) {
+        const int by = ps * teams + team;  // (a team without a tile in the last pass walks rows behind m: nothing counts)
+        uint32_t bytes[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bytes[i] = next[i];
+        if (ps + 1 < passes) request(by + teams);
+        if (SIM && ps == 0) {
+            if (threadIdx.x < 256) lut[threadIdx.x] = lutbyte;
+            __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1353,42 +1372,43 @@ __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b
                         code = BX_SKIP;
                     }
                 }
-                codes[tx * LDC + row] = (uint8_t)code;
-                reinterpret_cast<uint8_t *>(rawt)[(ty + 4 * i) * 68 + tx] = (uint8_t)(byte < 0x100u ? byte : (uint32_t)'-');
+                if (row < mtiles * 64) codes[tx * LDC + row] = (uint8_t)code;
+                reinterpret_cast<uint8_t *>(myraw)[(ty + 4 * i) * 68 + tx] = (uint8_t)(byte < 0x100u ? byte : (uint32_t)'-');
             }
         }
         if (SIM) {
             __syncthreads();
-            if (ty == 0) {  // a thread per row of the tile: its two chunk words of every plane
-                const int row = by * 64 + tx;
-                uint32_t out[2][8];
+            {  // four threads per row of the team's tile, 16 columns each: the row's two chunk words of every plane
+                const int r = tid >> 2, q = tid & 3;
+                const int row = by * 64 + r;
+                uint32_t o[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) out[h][p] = 0;
+                for (int p = 0; p < 8; ++p) o[p] = 0;
                 uint32_t bad = 0;
-                if (row < m) {
-                    uint32_t w[16];
+                if (row < m) bad = planes_of_quarter(myraw + r * 17 + q * 4, b * 64 + q * 16, n, a.indet4, o);
+                const int chunk = b * 2 + (q >> 1);
+                const size_t pstride = (size_t)a.nchunk * a.m_pad;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) w[q] = rawt[tx * 17 + q];
-                    bad = planes_of_row(w, b * 64, n, a.indet4, out);
+                for (int p = 0; p < 8; ++p) {
+                    uint32_t v = o[p] << ((q & 1) * 16);
+                    v |= (uint32_t)__shfl_xor((int)v, 1, 64);  // (the other half of the chunk word: the neighbouring lane)
+                    if ((q & 1) == 0 && row < a.m_pad && chunk < a.nchunk) a.planes[p * pstride + (size_t)chunk * a.m_pad + row] = v;
                 }
-                if (row < a.m_pad) planes_store(a.planes, a.nchunk, a.m_pad, b, row, out);
                 if (bad) anybad = 1;
             }
             __syncthreads();
         }
     }
-    if (SIM && ty == 1) {  // the rows between the last tile and m_pad: zero in every plane
+    if (SIM && wave == 1) {  // the rows between the last pass and m_pad: zero in every plane
         const uint32_t zero[2][8] = {};
-        for (int row = mtiles * 64 + tx; row < a.m_pad; row += 64) planes_store(a.planes, a.nchunk, a.m_pad, b, row, zero);
+        for (int row = passes * teams * 64 + tx; row < a.m_pad; row += 64) planes_store(a.planes, a.nchunk, a.m_pad, b, row, zero);
     }
-    cnt[0][ty][tx] = g;
-    cnt[1][ty][tx] = x;
+    cnt[0][wave][tx] = g;
+    cnt[1][wave][tx] = x;
     __syncthreads();
-    if (ty == 0) {
-        const uint32_t G = cnt[0][0][tx] + cnt[0][1][tx] + cnt[0][2][tx] + cnt[0][3][tx];
-        const uint32_t X = cnt[1][0][tx] + cnt[1][1][tx] + cnt[1][2][tx] + cnt[1][3][tx];
+    if (wave == 0) {
+        uint32_t G = 0, X = 0;
+        for (int w = 0; w < nwaves; ++w) G += cnt[0][w][tx], X += cnt[1][w][tx];
         if (inb) {
             a.gaps[c] = (int32_t)G;
             a.indets[c] = (int32_t)X;
@@ -1420,7 +1440,7 @@ __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b
         // a wave per column, lane = row: the codes (coalesced) and the compacted lists, as sim_encode_cm and bx_compact write them
         const int lane = tx;
         const uint32_t ldw4 = (uint32_t)a.ldw * 4u;
-        for (int q = ty; q < 64; q += 4) {
+        for (int q = wave; q < 64; q += nwaves) {
             const size_t col = (size_t)b * 64 + q;
             const bool skip = skipc[q] != 0;
             uint8_t *ct = a.codeT + col * ldk;
@@ -1451,18 +1471,18 @@ __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b
     }
 }
 template <bool SIM>
-__global__ __launch_bounds__(256) void compact_front_kernel(CompactArgs a) {
+__global__ __launch_bounds__(256 * COMPACT_TEAMS_MAX) void compact_front_kernel(CompactArgs a) {
     const int b = (int)blockIdx.x;
     const int ncb = a.ncols_pad / 64;
     if (b == 0) {
         if (threadIdx.x < 32) a.flags[threadIdx.x] = 0;
         if (SIM) {
             if (threadIdx.x == 0) a.scratch[0] = 0;  // the ticket of the identity statistics
-            for (int i = threadIdx.x; i < a.m_pad + 64; i += 256) a.wsum[i] = 0u;
+            for (int i = threadIdx.x; i < a.m_pad + 64; i += (int)blockDim.x) a.wsum[i] = 0u;
         }
     }
     if (b < ncb) compact_column_block<SIM>(a, b);
-    else row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
+    else if (threadIdx.x < 256) row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
 }
 
 // automated1: the identity statistics -- a wave per sequence (identity_rows_body), and in the workgroup that finishes last (a
@@ -1632,8 +1652,9 @@ size_t compact_slot_words(int n) { return (size_t)3 * (bx_cols_pad(n) / 64) + 2;
 size_t compact_scratch_words(int m, int n) { return (size_t)2 + (std::max(m, 1) + 127) / 128 * 128 + 64 + 8; }
 void launch_compact_front(hipStream_t s, const CompactArgs &a) {
     const unsigned blocks = (unsigned)(a.ncols_pad / 64 + (a.m + 3) / 4);
-    if (a.sim) compact_front_kernel<true><<<blocks, 256, 0, s>>>(a);
-    else compact_front_kernel<false><<<blocks, 256, 0, s>>>(a);
+    const int teams = std::min(COMPACT_TEAMS_MAX, std::max(1, (a.m + 63) / 64));  // a team of four waves per 64-row tile, up to four
+    if (a.sim) compact_front_kernel<true><<<blocks, 256 * teams, 0, s>>>(a);
+    else compact_front_kernel<false><<<blocks, 256 * teams, 0, s>>>(a);
 }
 // the flat similarity kernel: any alignment of up to FLAT_ROWS_MAX rows whose codes exist (A.codeT, A.wup, A.mdk_out, A.q_out)
 int flat_rows_max() { return FLAT_ROWS_MAX; }

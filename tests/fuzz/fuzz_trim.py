@@ -18,16 +18,22 @@ rng = np.random.default_rng(seed)
 AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a strict trim must raise where the oracle does
 
-CONTEXTS = [dict(), dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq"),
+# (the default context takes small alignments through the compact pipeline with the flat similarity kernel up to 128 sequences;
+# the others: the flat kernel at every size it takes, the compact pipeline with the wave-per-column kernel, the ordinary launch
+# sequence with the rows copied to the device, and the switches of the wave-per-column kernel)
+CONTEXTS = [dict(), dict(MSA_FLAT_MAX_M="512"), dict(MSA_FLAT_MAX_M="0", MSA_MDK_HOST="1"), dict(MSA_COMPACT="0", MSA_ZEROCOPY_KB="0"),
+            dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq"),
             dict(MSA_MDK_HOST="1", MSA_UPLOAD_DIRECT="0"), dict(MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="3"),
             dict(MSA_LG_SPLIT="8", MSA_LG_ROUNDS="2")]
+SWITCHES = ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_COMPACT",
+            "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB")
 ctxs = []
 for env in CONTEXTS:
-    for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT"):
+    for k in SWITCHES:
         os.environ.pop(k, None)
     os.environ.update(env)
     ctxs.append(_lib.Context(0))
-for k in ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT"):
+for k in SWITCHES:
     os.environ.pop(k, None)
 
 mx = SimilarityMatrix.aa()

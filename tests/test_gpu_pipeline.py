@@ -17,8 +17,8 @@ ALPHA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 
 @pytest.fixture
 def contexts(monkeypatch):
-    """(pipelined, serial, pipelined with the side stream at any size, row-index lists at any size) contexts: the
-    switches are read when a context is created"""
+    """(pipelined, serial, pipelined with the side stream at any size, row-index lists at any size, and the three other
+    ways a small alignment can go) contexts: the switches are read when a context is created"""
     made = []
     for value in ("1", "0", "3"):
         monkeypatch.setenv("MSA_PIPELINE", value)
@@ -27,6 +27,15 @@ def contexts(monkeypatch):
     monkeypatch.setenv("MSA_LG_BIG", "1")  # (and one with the similarity kernel's row-index lists at any size)
     made.append(_lib.Context(0))
     monkeypatch.delenv("MSA_LG_BIG")
+    # small alignments (the first context runs them through the compact pipeline -- three launches, the flat similarity kernel up
+    # to 128 sequences, rows of less than 96 KB read in place): the ordinary launch sequence with the rows copied; the compact
+    # pipeline with the flat kernel wherever it applies; the compact pipeline with the wave-per-column kernel
+    for env in (dict(MSA_COMPACT="0", MSA_ZEROCOPY_KB="0"), dict(MSA_FLAT_MAX_M="512"), dict(MSA_FLAT_MAX_M="0")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        made.append(_lib.Context(0))
+        for k in env:
+            monkeypatch.delenv(k)
     yield made
     for c in made:
         c.close()
@@ -108,6 +117,32 @@ def test_pipelined_methods(contexts, kw, shape):
     a = family(m, n, 11 + m, keep)
     trimmer = AutomaticTrimmer(kw["method"], platform="hip") if "method" in kw else ManualTrimmer(platform="hip", **kw)
     run_both(contexts, a, trimmer, **kw)
+
+
+@pytest.mark.parametrize("method", ["strict", "automated1", "gappyout"])
+def test_every_path_reports_the_same_about_a_trim(contexts, method):
+    """What a trim says beside its masks -- the warnings (two sequences of gaps only: no identity between them is defined, and
+    the trimming drops them), the row it names, both cut points and selectMethod's two statistics -- from every way a small
+    alignment can go (the compact pipeline with either similarity kernel, the ordinary launch sequence, the serial flow)."""
+    for m, n in ((40, 300), (150, 700)):
+        a = family(m, n, 90 + m, 0.5).copy()
+        a[3, :] = ord("-")
+        a[m - 2, :] = ord("-")
+        p, keepalive = params_of(AutomaticTrimmer(method, platform="hip"))
+        seen = []
+        for ctx in contexts:
+            ctx.upload(a, ord("X"))
+            keep_res, keep_seq, info = ctx.trim(p)
+            seen.append((keep_res.tobytes(), keep_seq.tobytes(), info.warnings, info.warn_row, info.gap_cut,
+                         np.float32(info.sim_cut).view(np.uint32).item(), np.float32(info.avg_seq).view(np.uint32).item(),
+                         np.float32(info.max_seq).view(np.uint32).item(), info.selected_method, info.kept_residues, info.kept_sequences))
+        assert all(x == seen[0] for x in seen), (method, m, n)
+        assert seen[0][2] & _lib.W_ONLY_GAPS_SEQUENCES and seen[0][3] == 3
+        if method != "gappyout":
+            assert seen[0][2] & _lib.W_UNDEFINED_IDENTITY
+        res, seq, _ = oracle.trim(a, method=method)
+        assert seen[0][0] == np.asarray(res, dtype=np.uint8).tobytes() and seen[0][1] == np.asarray(seq, dtype=np.uint8).tobytes()
+        del keepalive
 
 
 def test_shapes_alternate_on_one_context(contexts):

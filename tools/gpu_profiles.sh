@@ -37,6 +37,17 @@ for g in 1 4 16; do MSA_BATCH_ENGINE_MAX=1e12 MSA_BATCH_GROUPS=$g timeout 300 py
 MSA_BATCH_ENGINE=0 timeout 300 python tools/c5_engine.py 2>/dev/null >> $OUT/c5_engine.jsonl
 timeout 300 python tools/c5_counts.py > $OUT/c5_counts.jsonl 2>/dev/null
 timeout 300 python tools/small_latency.py > $OUT/small_latency.jsonl 2>/dev/null
+# round 4, late: the compact pipeline of small alignments against the ordinary launch sequence, the flat similarity kernel by size,
+# and the kernels of two small trims as the profiler sees them
+MSA_COMPACT=0 MSA_ZEROCOPY_KB=0 timeout 300 python tools/small_latency.py > $OUT/small_latency_ordinary_launch_sequence.jsonl 2>/dev/null
+timeout 300 python tools/flat_sweep.py > $OUT/flat_sweep.jsonl 2>/dev/null
+( cd /tmp; : > $OUT/small_kernel_stats.txt
+  for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict"; do
+    rm -rf /tmp/small_prof
+    timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/small_prof -- python3 $ROOT/tools/small_one.py $a 200 > /tmp/small_prof.log 2>&1
+    grep "per upload" /tmp/small_prof.log >> $OUT/small_kernel_stats.txt
+    f=$(find /tmp/small_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 $f | cut -d, -f1-4 | cut -c1-160 >> $OUT/small_kernel_stats.txt
+  done )
 timeout 120 python tools/cold_upload.py > $OUT/cold_upload.jsonl 2>/dev/null
 for sw in MSA_PIPELINE=1,0 MSA_UPLOAD_DIRECT=1,0; do timeout 300 python tools/step_overheads.py C3 C2 C4 C5 --switch $sw 2>/dev/null | grep "ms/step"; done > $OUT/ab_switches.txt
 timeout 120 python tools/bx_stamps.py 2>/dev/null | grep sim_ms > $OUT/bx_stamps.jsonl
