@@ -163,6 +163,61 @@ __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
     return s;
 }
 
+// scan_rows over an arbitrary set of lanes
+__device__ __forceinline__ float scan_lanes(float s, float top, float ie, float io, unsigned long long segm, int lane, int &cross) {
+    const bool in = ((segm >> lane) & 1ull) != 0ull;
+    const float a = in ? ie : 0.0f;
+    const float P = wave_prefix(a);
+    unsigned long long ties = __ballot(in && ie != io);
+    float corr = 0.0f;
+    while (ties) {
+        const int t = __builtin_ctzll(ties);
+        ties &= ties - 1;
+        const float at = rl(a, t);
+        const float st = s + ((rl(P, t) - at) + rl(corr, t));
+        if (!(st < top)) break;
+        const float chosen = (__float_as_uint(st) & 1u) ? rl(io, t) : at;
+        const float delta = chosen - at;
+        if (lane >= t) corr += delta;
+    }
+    const float sp = s + (P + corr);
+    const unsigned long long x = __ballot(in && !(sp < top));
+    cross = x ? __builtin_ctzll(x) : 64;
+    return sp;
+}
+
+
+// 256 consecutive terms, FOUR CONSECUTIVE ones per lane (x[i]: term 4 lane + i), added to s in order.  A lane is to its four
+// terms what a lane of the kernel above is to its row: accumulators started at B and at B + u give its increments for an
+// even and an odd sum in front of it, scan_lanes composes the lanes (ties by parity, exact prefix sums) and names the first
+// lane whose sum would leave the binade; that lane's four terms are then added one by one, as the reference does, and the
+// lanes behind it start over on the new grid.  Every commit passes scan_lanes' test (sum < 2B), which also vouches for the
+// accumulators of the lanes it commits (terms >= 0: an increment below B means the accumulator never left [B, 2B)).
+__device__ __forceinline__ float flat_add_chunk(float s, const float (&x)[4], int lane) {
+    if (__ballot((x[0] != 0.0f) | (x[1] != 0.0f) | (x[2] != 0.0f) | (x[3] != 0.0f)) == 0ull) return s;
+    unsigned long long live = ~0ull;
+    while (live) {
+        float B, u;
+        int f;
+        if (grid_of(s, B, u)) {
+            const float Bo = B + u;
+            float ae = B, ao = Bo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ae = ae + x[i], ao = ao + x[i];
+            const float sp = scan_lanes(s, 2.0f * B, ae - B, ao - Bo, live, lane, f);
+            if (f >= 64) return rl(sp, 63);  // (live always ends at lane 63)
+            const unsigned long long before = live & ((1ull << f) - 1ull);
+            if (before) s = rl(sp, 63 - __builtin_clzll(before));
+        } else {
+            f = __builtin_ctzll(live);  // zero / tiny sum: the next lane's terms as the reference adds them
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = s + rl(x[i], f);
+        live &= ~((2ull << f) - 1ull);
+    }
+    return s;
+}
+
 // Row j of one column in the reference's order: its partners are the rows k > j, 64 per block (lane = partner), 256 per
 // chunk.  Dense: EVERY row behind j is read -- W[j][k] from the row-major upper triangle (coalesced), the column's code
 // of row k (coalesced bytes) -- and a row that takes no part contributes W x 0 = 0, which changes no float32 sum; the
@@ -180,35 +235,35 @@ __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, uin
     if (cj == BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
     float s0 = s.x, s1 = s.y;
-    auto request = [&](int kb, float(&w)[4], uint32_t(&c)[4]) {  // (reads at most 255 entries past row m: W's slack, the code padding)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            w[i] = wr[kb + 64 * i + lane];
-            c[i] = cv.colcode[kb + 64 * i + lane];
-        }
+    // A lane holds FOUR CONSECUTIVE partners of a chunk (k = kb + 4 lane + i: one 16-byte load of W, one dword of codes) and
+    // the chunk goes through flat_add_chunk: ties and the crossing are settled by the scan over the lanes, where the block
+    // test of rounds 2-3 (chunk_step: lane = partner 64 i + lane) fell back to 64 adds one after the other for every block
+    // that held a tie or the crossing -- and a row is here BECAUSE it holds a crossing.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto request = [&](int kb, f4 &w, uint32_t &c) {  // (reads at most 255 entries past row m: W's slack, the code padding)
+        w = *reinterpret_cast<const __attribute__((address_space(1))) f4 *>(wr + kb + 4 * lane);
+        c = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(cv.colcode + kb + 4 * lane);
     };
-    float w[4], wn[4];
-    uint32_t c[4], cn[4];
+    f4 w, wn;
+    uint32_t c, cn;
     int kb = (j + 1) & ~63;
     request(kb, w, c);
     for (; kb < cv.m; kb += 256) {
         request(kb + 256 < cv.m ? kb + 256 : kb, wn, cn);  // the next chunk (a repeat behind the last: not used)
         f2 de[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + c[i]));
+        for (int i = 0; i < 4; ++i)
+            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + ((c >> (8 * i)) & 0xFFu)));
         if (which & 1) {
             const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
-            s0 = chunk_step(s0, x);
+            s0 = flat_add_chunk(s0, x, lane);
         }
         if (which & 2) {
             const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
-            s1 = chunk_step(s1, x);
+            s1 = flat_add_chunk(s1, x, lane);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            w[i] = wn[i];
-            c[i] = cn[i];
-        }
+        w = wn;
+        c = cn;
     }
     return f2{s0, s1};
 }
@@ -240,29 +295,6 @@ constexpr int LG_R0 = 1;  // rows evaluated in order before the first round (at 
 
 __device__ __forceinline__ float unif(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
-}
-
-// scan_rows over an arbitrary set of lanes
-__device__ __forceinline__ float scan_lanes(float s, float top, float ie, float io, unsigned long long segm, int lane, int &cross) {
-    const bool in = ((segm >> lane) & 1ull) != 0ull;
-    const float a = in ? ie : 0.0f;
-    const float P = wave_prefix(a);
-    unsigned long long ties = __ballot(in && ie != io);
-    float corr = 0.0f;
-    while (ties) {
-        const int t = __builtin_ctzll(ties);
-        ties &= ties - 1;
-        const float at = rl(a, t);
-        const float st = s + ((rl(P, t) - at) + rl(corr, t));
-        if (!(st < top)) break;
-        const float chosen = (__float_as_uint(st) & 1u) ? rl(io, t) : at;
-        const float delta = chosen - at;
-        if (lane >= t) corr += delta;
-    }
-    const float sp = s + (P + corr);
-    const unsigned long long x = __ballot(in && !(sp < top));
-    cross = x ? __builtin_ctzll(x) : 64;
-    return sp;
 }
 
 // One chain at the end of a round: s before the round's first row; per lane the grid it accumulated on (Bl; 0 =
@@ -1166,36 +1198,6 @@ __global__ __launch_bounds__(256) void bx_compact_batch_kernel(const BAlign *__r
 // column-major codes; W[j][k] a gather from the (L2-resident) upper triangle; the distance from the LDS table.  No lists, no
 // predictor, no per-row state.  Two waves per column (one per sum); the numerator's wave writes MDK and Q itself (mdk_value).
 constexpr int FLAT_ROWS_MAX = 512;
-// 256 consecutive terms, FOUR CONSECUTIVE ones per lane (x[i]: term 4 lane + i), added to s in order.  A lane is to its four
-// terms what a lane of the kernel above is to its row: accumulators started at B and at B + u give its increments for an
-// even and an odd sum in front of it, scan_lanes composes the lanes (ties by parity, exact prefix sums) and names the first
-// lane whose sum would leave the binade; that lane's four terms are then added one by one, as the reference does, and the
-// lanes behind it start over on the new grid.  Every commit passes scan_lanes' test (sum < 2B), which also vouches for the
-// accumulators of the lanes it commits (terms >= 0: an increment below B means the accumulator never left [B, 2B)).
-__device__ __forceinline__ float flat_add_chunk(float s, const float (&x)[4], int lane) {
-    if (__ballot((x[0] != 0.0f) | (x[1] != 0.0f) | (x[2] != 0.0f) | (x[3] != 0.0f)) == 0ull) return s;
-    unsigned long long live = ~0ull;
-    while (live) {
-        float B, u;
-        int f;
-        if (grid_of(s, B, u)) {
-            const float Bo = B + u;
-            float ae = B, ao = Bo;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ae = ae + x[i], ao = ao + x[i];
-            const float sp = scan_lanes(s, 2.0f * B, ae - B, ao - Bo, live, lane, f);
-            if (f >= 64) return rl(sp, 63);  // (live always ends at lane 63)
-            const unsigned long long before = live & ((1ull << f) - 1ull);
-            if (before) s = rl(sp, 63 - __builtin_clzll(before));
-        } else {
-            f = __builtin_ctzll(live);  // zero / tiny sum: the next lane's terms as the reference adds them
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s = s + rl(x[i], f);
-        live &= ~((2ull << f) - 1ull);
-    }
-    return s;
-}
 __global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const float *__restrict__ tab_g) {
     __shared__ f2 tab[32 * 32];                    // {distance, both valid}[row code][column code], rows 28.. zero
     __shared__ uint32_t rows[4][FLAT_ROWS_MAX];    // per wave: the column's valid rows, index | table row << 16
