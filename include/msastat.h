@@ -72,7 +72,8 @@ int msa_upload_packed(msa_ctx *ctx, const uint8_t *rowmajor, int32_t m, int32_t 
 /* The same without waiting for the copy: the rows must stay valid and unchanged until the next call on this context that
  * returns results (msa_trim, msa_gaps, ...) or uploads again: each of them returns with the copy complete, msa_trim also
  * when the trim itself had nothing to read.  What a binding that holds the alignment anyway (pytrimal's Alignment
- * object) calls right in front of msa_trim. */
+ * object) calls right in front of msa_trim.  (Rows of less than 96 KB are packed into the context's own page-locked memory
+ * before either upload call returns, and the kernels read them there: nothing is left in flight.) */
 int msa_upload_packed_async(msa_ctx *ctx, const uint8_t *rowmajor, int32_t m, int32_t n, int64_t ld, uint8_t indet);
 /* Page-lock the caller's rows so that uploads of them are one DMA copy at the link's rate, straight from where they lie
  * (no staging, no packing).  Worth it for rows that are uploaded more than once; the range must be unregistered before

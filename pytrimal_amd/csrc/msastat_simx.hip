@@ -1232,26 +1232,35 @@ __global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const f
     const int T = nv * (nv - 1) / 2;  // pairs (a < b) of list positions, lexicographic: row a holds the nv - 1 - a pairs (a, b > a)
     const gf32p wup = (gf32p)(uint64_t)A.wup;
     const int ldw = A.ldw;
-    // Eight terms per lane and pass (two chunks of 256, four consecutive terms of each), requested a pass ahead: with one or
-    // two waves per SIMD (a wave per column, ~1000 columns) nothing else hides the gather's latency.  A lane walks its terms
-    // by (a, p) = the pair's row and its place in the row, advanced by carrying places into the next (shorter) rows -- no
-    // division, no root.
+    // Eight terms per lane and pass (two chunks of 256, four consecutive terms of each), requested a pass ahead: with two
+    // waves per SIMD (two per column, ~1000 columns) nothing else hides the gather's latency.
     constexpr int U = 8;
-    int ra = 0, rp = 4 * lane, rt = 4 * lane;  // the lane's next term: row, place in the row, index
+    int rt = 4 * lane;  // the lane's first term of the next pass
+    const float fn = (float)(2 * nv - 1);
     auto request = [&](float (&w)[U], uint32_t (&ti)[U]) {
         uint32_t ea[U], eb[U];
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            // (terms behind the last one: the last row's only pair, counted as zero by the caller)
-            while (__ballot(rt < T && rp >= nv - 1 - ra)) {
-                if (rt < T && rp >= nv - 1 - ra) rp -= nv - 1 - ra, ++ra;
+        for (int h = 0; h < 2; ++h) {
+            // the lane's first term of the chunk -> (row a, place p): the largest a with a nv - a (a + 1) / 2 <= t, from the root
+            // of an exact integer below 2^24 (two corrections cover a root that is off by an ulp); its three neighbours by a carry
+            // into the next row.  Straight-line code: the eight gathers below leave back to back.  Terms behind the last one
+            // read the last one's operands and count as zero (the caller masks them).
+            const int t0 = rt + 256 * h;
+            const int t = t0 < T ? t0 : T - 1;
+            int a = (int)((fn - sqrtf(fn * fn - 8.0f * (float)t)) * 0.5f);
+            a = a > nv - 2 ? nv - 2 : a;
+            a -= (a * nv - a * (a + 1) / 2 > t) ? 1 : 0;
+            a += (a + 1 <= nv - 2 && (a + 1) * nv - (a + 1) * (a + 2) / 2 <= t) ? 1 : 0;
+            int pl = t - (a * nv - a * (a + 1) / 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ea[4 * h + i] = mine[a], eb[4 * h + i] = mine[a + 1 + pl];
+                const bool adv = t0 + i + 1 < T, wrap = pl + 1 >= nv - 1 - a;
+                a += (adv && wrap) ? 1 : 0;
+                pl = adv ? (wrap ? 0 : pl + 1) : pl;
             }
-            const bool in = rt < T;
-            const int a = in ? ra : nv - 2, b = in ? ra + 1 + rp : nv - 1;
-            ea[i] = mine[a], eb[i] = mine[b];
-            const int step = (i & 3) == 3 ? 253 : 1;  // to the lane's first term of the next chunk
-            rp += step, rt += step;
         }
+        rt += 64 * U;
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             w[i] = wup[(size_t)(ea[i] & 0xFFFFu) * ldw + (eb[i] & 0xFFFFu)];
@@ -1270,7 +1279,8 @@ __global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const f
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 if (t0 + 256 * (i >> 2) + 4 * lane + (i & 3) >= T) w[i] = 0.0f;
-                x[i] = denominator ? w[i] : w[i] * tab[ti[i]].x;
+                const float d = tab[ti[i]].x;  // (both waves read it: no branch around eight LDS loads)
+                x[i] = denominator ? w[i] : w[i] * d;
             }
 #pragma unroll
             for (int h = 0; h < U; h += 4) {
