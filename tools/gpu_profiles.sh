@@ -41,6 +41,7 @@ timeout 300 python tools/small_latency.py > $OUT/small_latency.jsonl 2>/dev/null
 # and the kernels of two small trims as the profiler sees them
 MSA_COMPACT=0 MSA_ZEROCOPY_KB=0 timeout 300 python tools/small_latency.py > $OUT/small_latency_ordinary_launch_sequence.jsonl 2>/dev/null
 timeout 300 python tools/flat_sweep.py > $OUT/flat_sweep.jsonl 2>/dev/null
+timeout 300 python tests/measure/fixtures_time.py > $OUT/fixtures_time.jsonl 2>/dev/null
 ( cd /tmp; : > $OUT/small_kernel_stats.txt
   for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict"; do
     rm -rf /tmp/small_prof

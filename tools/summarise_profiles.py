@@ -106,7 +106,7 @@ ub = os.path.join(SRC, "ubench_wstream.txt")
 if os.path.exists(ub):
     shutil.copy(ub, os.path.join(DST, TAG + "_ubench_wstream.txt"))
 for name in ("ubench_wform.txt", "sim_shapes.jsonl", "sim_shapes_one_wave_per_column.jsonl", "small_batch.jsonl", "c5_engine.jsonl", "c5_counts.jsonl",
-             "small_latency.jsonl", "small_latency_ordinary_launch_sequence.jsonl", "flat_sweep.jsonl", "small_kernel_stats.txt", "cold_upload.jsonl"):
+             "small_latency.jsonl", "small_latency_ordinary_launch_sequence.jsonl", "flat_sweep.jsonl", "fixtures_time.jsonl", "small_kernel_stats.txt", "cold_upload.jsonl"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 for name in ("bx_stamps.jsonl", "ab_switches.txt", "timeline_C3.txt", "timeline_C2.txt", "timeline_C4.txt", "reference_shape.jsonl",
