@@ -7,11 +7,15 @@ import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
 from pytrimal_amd.synth import synth_msa
 
-m, n = (int(x) for x in sys.argv[1:3]) if len(sys.argv) > 2 else (46, 1181)
 method = sys.argv[3] if len(sys.argv) > 3 else "strict"
 count = int(sys.argv[4]) if len(sys.argv) > 4 else 300
-a = synth_msa(m, n, 77 + m)
-ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+if len(sys.argv) > 2 and not sys.argv[1].isdigit():  # a FASTA file instead of a shape:  small_one.py tests/golden/data/X.fasta - strictplus
+    ali = Alignment.load(sys.argv[1], "fasta")
+    m, n = len(ali.sequences), len(ali.sequences[0])
+else:
+    m, n = (int(x) for x in sys.argv[1:3]) if len(sys.argv) > 2 else (46, 1181)
+    a = synth_msa(m, n, 77 + m)
+    ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
 tr = AutomaticTrimmer(method, platform="hip")
 for _ in range(5):
     tr.trim(ali)
@@ -24,5 +28,16 @@ for rep in range(3):
         ctx.upload(dense, indet)
         ctx.trim(params)
     best = min(best, (time.perf_counter() - t) / count)
-print(f"{m} x {n} {method}: {best * 1e3:.4f} ms per upload + msa_trim", flush=True)
+ctx.prof_enable(True)
+ctx.lib.msa_prof_reset(ctx.h)
+for _ in range(20):
+    ctx.upload(dense, indet)
+    ctx.trim(params)
+kern = {}
+for k in ("front", "gaps", "prep", "pairs", "idstats", "encode", "sim"):
+    ms, cnt = ctx.prof_get(k)
+    if cnt:
+        kern[k] = round(ms / cnt, 4)
+ctx.prof_enable(False)
+print(f"{m} x {n} {method}: {best * 1e3:.4f} ms per upload + msa_trim", kern, flush=True)
 ctx.close()  # (not at interpreter exit: under a profiler the runtime may be gone by then)
