@@ -102,10 +102,10 @@ struct BAlign {
 };
 // The compact pipeline of one small alignment (msa_trim): THREE launches -- everything that reads the rows (gap counts, row
 // totals, planes, codes + lists), the pair pass (which also sums the rows' weights), the similarity kernel with the MDK values
-// (automated1: a fourth, the identity statistics) -- and one copy back, instead of a dozen launches, two memsets and four
-// copies: at 46 x 1181 a trim is 0.15 ms of queue operations around 0.08 ms of kernels (profiles/r04_small_latency.jsonl).  No
-// memset either: every word a kernel accumulates into is zeroed by the kernel in front of it (device pointers;
-// msastat_simx.hip: compact_front_kernel).
+// (automated1: a fourth, the identity statistics) -- whose results the kernels store into pinned host memory themselves, instead of
+// a dozen launches, two memsets and four copies: at 46 x 1181 such a trim was 0.15 ms of queue operations around 0.08 ms of kernels
+// (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  No memset either: every word a kernel accumulates into is zeroed
+// by the kernel in front of it (msastat_simx.hip: compact_front_kernel).
 struct CompactArgs {
     const uint8_t *raw;       // [m][ld] residues (device memory, or pinned host memory read over the link: MSA_ZEROCOPY_KB)
     int64_t ld;
@@ -138,7 +138,7 @@ size_t compact_slot_words(int n);
 void launch_compact_front(hipStream_t s, const CompactArgs &a);
 void launch_compact_identity(hipStream_t s, const CompactArgs &a);
 int flat_rows_max();
-void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab);  // a wave per column: the column's pairs as one sequence
+void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab);  // two waves per column (one per sum): the column's pairs as one sequence
 int pair_tiles_pipe(int m, int m_pad);    // tiles of the pair pass in its one-row-per-lane regime
 bool pair_pipe_regime(int m, int m_pad);  // ... which launch_pair_counts picks for this shape (a batch holds no other)
 void launch_fetch_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
