@@ -2187,7 +2187,8 @@ struct msa_batch {
     std::vector<int32_t> sel_redo;
     std::vector<uint8_t> sel_finished;  // per alignment of the call: the engine has delivered its result
     bool use_engine = true;                       // MSA_BATCH_ENGINE=0: every alignment through the workers (diagnostics, tests)
-    double engine_max_work = 8e8;                 // m * m * n up to which the engine takes an alignment (MSA_BATCH_ENGINE_MAX)
+    double engine_max_work = 3e8;                 // m * m * n up to which the engine takes an alignment (MSA_BATCH_ENGINE_MAX)
+    int engine_min_count = 40;                    // fewer eligible alignments than this go to the workers instead (MSA_BATCH_ENGINE_MIN)
     bool in_call = false;
 };
 
@@ -2276,8 +2277,10 @@ bool engine_takes(const msa_batch *b, int32_t k, const msa_trim_params *ref) {
     // Where the batched kernels pay: alignments that do not fill the chip by themselves.  From ~600 x 2500 on a context per
     // alignment (four workers) is as fast or faster -- the similarity kernel bounds both (64 x 1000 x 4000: 23.8 ms of it in
     // either scheme), and four alignments in flight overlap the VALU-bound pair pass of one with the similarity kernel of
-    // another, which one launch per family cannot (measured: 26.8 ms against 25.4; 96 x 700 x 3000: 19.7 against 17.5; 128 x 500 x 2000: 13.4 against 14.1;
-    // 1024 x 100 x 1000: 6.8 against 50).  MSA_BATCH_ENGINE_MAX: the m * m * n up to which the engine takes an alignment.
+    // another, which one launch per family cannot (measured: 26.8 ms against 25.4; 96 x 700 x 3000: 19.7 against 17.5; 1024 x 100 x 1000:
+    // 10.2 against 30 through trim_batch).  Since a worker's trim of a small alignment is the compact pipeline the line lies lower:
+    // 128 x 500 x 2000 12.8 against 11.7 for the workers, 256 x 300 x 1200 11.0 against 15.2 for the engine.
+    // MSA_BATCH_ENGINE_MAX: the m * m * n up to which the engine takes an alignment.
     if ((double)m * m * n > b->engine_max_work) return false;
     if ((double)m * m * 12 + (double)msak::bx_cols_pad(n) * msak::bx_ldk(m) * 7 > 6e9) return false;  // (a few GB per alignment: one at a time)
     return true;
@@ -2841,6 +2844,7 @@ int msa_batch_create(int device, int32_t workers, msa_batch **out) {
     b->device = device;
     if (const char *e = std::getenv("MSA_BATCH_ENGINE")) b->use_engine = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSA_BATCH_ENGINE_MAX")) b->engine_max_work = std::atof(e);
+    if (const char *e = std::getenv("MSA_BATCH_ENGINE_MIN")) b->engine_min_count = std::atoi(e);
     for (int w = 0; w < workers; ++w) {
         msa_ctx *c = nullptr;
         const int rc = msa_ctx_create(device, &c);
@@ -2901,6 +2905,16 @@ int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, cons
             } else {
                 b->order.push_back(k);
             }
+        }
+        // A handful of small alignments is faster through the worker contexts (each a compact pipeline of three launches,
+        // compact_begin) than as a group of the batched kernels with its arena, tables and ten launches: 8 x (100 x 1000) 0.31
+        // against 0.96 ms, 16: 0.57 / 1.11, 32: 1.0 / 1.2, 64: 2.0 / 1.45 (tools/small_batch.py).
+        if ((int)engine_ks.size() < b->engine_min_count) {
+            b->order.insert(b->order.end(), engine_ks.begin(), engine_ks.end());
+            std::stable_sort(b->order.begin(), b->order.end(), [&](int32_t x, int32_t y) {
+                return (double)m[x] * m[x] * n[x] > (double)m[y] * m[y] * n[y];
+            });
+            engine_ks.clear();
         }
         b->only_gaps.assign(count, {});
         for (int32_t k = 0; k < count; ++k) rc[k] = MSA_OK;

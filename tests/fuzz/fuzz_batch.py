@@ -80,7 +80,12 @@ def params_for(kw):
     return P
 
 
-batch = _lib.Batch(0, 3)
+# two batch objects: the shipped policy (fewer than 40 eligible alignments go to the worker contexts, each a compact pipeline), and
+# the batched-kernel engine for any number of them (the library reads the switch when a batch object is created)
+batch_default = _lib.Batch(0, 3)
+os.environ["MSA_BATCH_ENGINE_MIN"] = "1"
+batch_engine = _lib.Batch(0, 3)
+os.environ.pop("MSA_BATCH_ENGINE_MIN")
 t_end = time.time() + budget
 batches = cases = raised = engine_like = 0
 failures = []
@@ -91,6 +96,7 @@ while time.time() < t_end and not failures:
         items = [items[int(i)] for i in rng.integers(0, 12, count)]  # (many alignments, few distinct ones: the oracle is the slow side)
     else:
         items = [(alignment(), settings()) for _ in range(count)]
+    batch = batch_engine if rng.random() < 0.5 else batch_default
     out = batch.trim([(a, ord("X"), params_for(kw)) for a, kw in items])
     memo = {}
     for k, ((a, kw), (res, seq, info, rc, rows)) in enumerate(zip(items, out)):
@@ -111,7 +117,8 @@ while time.time() < t_end and not failures:
         if rc != _lib.OK or not np.array_equal(res, ores.astype(bool)) or not np.array_equal(seq, oseq.astype(bool)):
             failures.append({"batch": batches, "k": k, "shape": list(a.shape), "settings": kw, "rc": rc})
     batches += 1
-batch.close()
+batch_default.close()
+batch_engine.close()
 print(json.dumps({"mismatch": bool(failures), "failures": failures[:5], "batches": batches, "alignments": cases,
                   "alignments_where_both_raise": raised, "seconds": round(budget, 1), "seed": seed}))
 sys.exit(1 if failures else 0)

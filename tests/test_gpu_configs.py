@@ -171,7 +171,8 @@ def test_batch_engine_against_single_trims(monkeypatch, cols_max):
 
     if cols_max:
         monkeypatch.setenv("MSA_BATCH_COLS_MAX", cols_max)
-    batch_mod.close_batches()  # (the library reads the switch when the batch object is created)
+    monkeypatch.setenv("MSA_BATCH_ENGINE_MIN", "1")  # (the engine for any number of eligible alignments: by default fewer than 40 go to the workers)
+    batch_mod.close_batches()  # (the library reads the switches when the batch object is created)
     rng = np.random.default_rng(77)
     alis = []
     for k in range(60):
@@ -226,7 +227,11 @@ def test_batch_engine_return_codes_through_the_c_abi():
                              vhash.ctypes.data, dist.ctypes.data, len(mat))
     mats = [np.ascontiguousarray(synth_msa(30 + 7 * k, 200 + 31 * k, 50 + k)) for k in range(12)]
     mats[4][3, 17] = 0xC3
-    batch = _lib.Batch(0, 2)
+    os.environ["MSA_BATCH_ENGINE_MIN"] = "1"  # (a dozen alignments would otherwise go to the worker contexts)
+    try:
+        batch = _lib.Batch(0, 2)
+    finally:
+        os.environ.pop("MSA_BATCH_ENGINE_MIN")
     try:
         out = batch.trim([(a, ord("X"), params) for a in mats])
     finally:
