@@ -1225,7 +1225,9 @@ bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
            msak::pair_pipe_regime(c->m, c->m_pad);
 }
 bool compact_gaps_applies(const msa_ctx *c) {
-    return c->tuning.compact != 0 && !c->have_gaps && c->m >= 1 && c->m <= 4096 && (size_t)c->m * (size_t)c->ld <= ((size_t)4 << 20);
+    // (up to 1024 sequences: a column block walks its 64-row tiles four at a time, and beyond sixteen tiles that chain is longer
+    // than the launches it saves)
+    return c->tuning.compact != 0 && !c->have_gaps && c->m >= 1 && c->m <= 1024 && (size_t)c->m * (size_t)c->ld <= ((size_t)4 << 20);
 }
 msak::CompactArgs compact_args(msa_ctx *c) {
     msak::CompactArgs a = {};
