@@ -1340,7 +1340,10 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     L.gate = gated ? c->state.p + ST_GATE : nullptr;
     L.mdk_out = mdk, L.q_out = mdk + c->state_npad, L.mdk_host = c->tuning.mdk_host;
     L.ldk = a.ldk, L.m = m, L.n = n, L.ldw = c->ldw, L.ncols = n;  // (cols = null: every column, in its own order)
-    const bool flat = m <= std::min(c->tuning.flat_max_m, msak::flat_rows_max());
+    // the flat kernel up to flat_max_m sequences -- with two waves per column, and from half that size on, only while both waves of
+    // every column are resident at once (128 x 5000: 106 us against 70 for the wave-per-column kernel; 64 x 5000: 46 against 58)
+    const int flat_m = std::min(c->tuning.flat_max_m, msak::flat_rows_max());
+    const bool flat = m <= flat_m && (n <= c->cus * 10 || m <= flat_m / 2);
     a.lists = flat ? 0 : 1;
     if (!flat && !msak::lg_finishes(L, c->cus)) return MSA_E_INVALID;  // (compact_sim_applies keeps such shapes and switches out)
     {
