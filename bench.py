@@ -410,7 +410,9 @@ def main():
         def step(masks_only=True):
             # from host rows to the masks gathered on rank 0 (what the gather moves: BASELINE's "RCCL broadcast/gather of
             # trim masks"); the TrimmedAlignment objects of the public batch call are timed beside it (value_public_api)
-            return trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, masks_only=masks_only)
+            # (under a launcher even ONE rank gathers its masks through the process group: RCCL on a one-GPU box)
+            return trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, masks_only=masks_only,
+                              force_collectives=dist is not None)
 
         for _ in range(args.warmup):
             step()
@@ -653,6 +655,7 @@ def main():
                 "avg_seq": round(float(info.avg_seq), 6) if info is not None else None,
                 "max_seq": round(float(info.max_seq), 6) if info is not None else None,
                 "kept_columns": kept, "ranks": world, "ranks_seen": ranks_seen,
+                "backend": dist.get_backend() if dist is not None else None,  # "nccl" = RCCL; None: no process group (one rank, no launcher)
                 "parallelism": (f"batch of {C5_BATCH} sharded over {world} rank(s) x 4 threads" if args.workload == "C5"
                                 else f"replicas x{world} (alignment per rank)"),
             },

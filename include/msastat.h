@@ -259,6 +259,38 @@ void msa_prof_enable(msa_ctx *ctx, int enable);
 /* Kernel launches the context's last similarity pass issued (one, or one per six rounds from 1800 rows on): what a
  * profiler lists per pass.  Diagnostics; bench.py reports it beside the pass's time. */
 int msa_debug_sim_launches(msa_ctx *ctx);
+/* Which code path the context's last upload and its last statistic / trim call took under the settings in force
+ * (diagnostics, like msa_debug_sim_launches: the default dispatch by shape is what ships, and
+ * tests/test_gpu_dispatch.py asserts it shape by shape).  out[0] how the rows reached the kernels (MSA_PATH_UPLOAD_*),
+ * out[1] the launch sequence (MSA_PATH_PIPE_*), out[2] the similarity kernel (MSA_PATH_SIM_*), out[3] its waves per column,
+ * out[4] its launches per pass, out[5] 1 when it wrote MDK and Q itself, out[6] the pair kernel (MSA_PATH_PAIRS_*), out[7] its
+ * waves per tile.  Entries of a stage the call did not run are 0. */
+enum {
+    MSA_PATH_UPLOAD_NONE = 0,
+    MSA_PATH_UPLOAD_IN_PLACE = 1, /* packed into the context's pinned staging area, read there by the kernels (no copy) */
+    MSA_PATH_UPLOAD_LINEAR = 2,   /* rows already at the device pitch: one linear copy */
+    MSA_PATH_UPLOAD_PITCHED = 3,  /* one pitched copy straight from the caller's rows */
+    MSA_PATH_UPLOAD_PACKED = 4,   /* packed into pinned pieces, each sent as soon as it is packed */
+    MSA_PATH_UPLOAD_ATTACHED = 5  /* msa_attach_device */
+};
+enum {
+    MSA_PATH_PIPE_NONE = 0,
+    MSA_PATH_PIPE_SERIAL = 1,       /* msa_similarity's own launch sequence (also msa_trim with MSA_PIPELINE=0) */
+    MSA_PATH_PIPE_ONE_STREAM = 2,   /* msa_trim's pipeline, everything on the context's stream */
+    MSA_PATH_PIPE_TWO_STREAMS = 3,  /* ... codes, lists and row totals on the side stream beside the pair pass */
+    MSA_PATH_PIPE_COMPACT = 4,      /* the compact pipeline of a small alignment: front, pairs, [identity], similarity */
+    MSA_PATH_PIPE_COMPACT_GAPS = 5  /* its front kernel alone (a trim that needs the gap statistics only) */
+};
+enum {
+    MSA_PATH_SIM_NONE = 0,
+    MSA_PATH_SIM_FLAT = 1,       /* the column's pairs as one sequence, two waves per column */
+    MSA_PATH_SIM_LG = 2,         /* a wave (or out[3] waves of a workgroup) per column, byte offsets in the lists */
+    MSA_PATH_SIM_LG_BIG = 3,     /* ... row indices in the lists (beyond 32768 rows) */
+    MSA_PATH_SIM_SEQ = 4,        /* the plain sequential kernel (MSA_SIM_KERNEL=seq) */
+    MSA_PATH_SIM_COLS = 5        /* a lane per column (groups of small alignments in msa_trim_batch) */
+};
+enum { MSA_PATH_PAIRS_NONE = 0, MSA_PATH_PAIRS_PIPE = 1 /* one row j per lane */, MSA_PATH_PAIRS_TWO_ROWS = 2 /* two rows j per lane */ };
+int msa_debug_last_paths(msa_ctx *ctx, int32_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ EXPORTS = [
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
     "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_trim_only_gaps_rows", "msa_batch_create", "msa_batch_destroy", "msa_batch_workers", "msa_trim_batch",
     "msa_batch_only_gaps_rows", "msa_batch_last_hip_error", "msa_prof_get", "msa_prof_reset",
-    "msa_prof_enable", "msa_debug_sim_launches", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
+    "msa_prof_enable", "msa_debug_sim_launches", "msa_debug_last_paths", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
 ]
 
 
@@ -446,6 +446,26 @@ class Context:
         ms, k = ctypes.c_float(0), ctypes.c_int32(0)
         check(self.lib, self.h, self.lib.msa_prof_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(k)))
         return ms.value, k.value
+
+    PATH_KEYS = ("upload", "pipeline", "sim_kernel", "sim_waves_per_column", "sim_launches", "sim_writes_mdk", "pair_kernel", "pair_waves_per_tile")
+    PATH_NAMES = {
+        "upload": ("none", "in_place", "linear", "pitched", "packed", "attached"),
+        "pipeline": ("none", "serial", "one_stream", "two_streams", "compact", "compact_gaps"),
+        "sim_kernel": ("none", "flat", "lg", "lg_big", "seq", "cols"),
+        "pair_kernel": ("none", "pipe", "two_rows"),
+    }
+
+    def last_paths(self):
+        """Which code path the last upload and the last statistic / trim call of this context took (`msa_debug_last_paths`):
+        a dict with the names of include/msastat.h's MSA_PATH_* values (diagnostics; tests/test_gpu_dispatch.py)."""
+        out = (ctypes.c_int32 * 8)()
+        self.lib.msa_debug_last_paths.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+        check(self.lib, self.h, self.lib.msa_debug_last_paths(self.h, out))
+        rec = {}
+        for key, v in zip(self.PATH_KEYS, out):
+            names = self.PATH_NAMES.get(key)
+            rec[key] = names[v] if names and 0 <= v < len(names) else int(v)
+        return rec
 
     def sync(self):
         check(self.lib, self.h, self.lib.msa_ctx_sync(self.h))

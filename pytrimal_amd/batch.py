@@ -89,7 +89,7 @@ def _pack_masks(results):
 
 
 def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, trim_fn=None, threads=6, shard=True,
-               masks_only=False):
+               masks_only=False, force_collectives=False):
     """Trim `alignments` (the same list on every rank) with `trimmer`, sharded over the ranks of
     `group`.  Returns the list of `TrimmedAlignment` on rank 0 and `None` elsewhere; without an
     initialised process group it simply trims everything locally.
@@ -105,6 +105,9 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     `masks_only=True`: return `(residues_mask, sequences_mask)` pairs of bool arrays instead of `TrimmedAlignment`
     objects -- what the gather moves; building 64 result objects is interpreter time behind the device's work (and, on
     rank 0 of a sharded run, serial work for every other rank's alignments).
+    `force_collectives=True`: run the gather of the masks even in a process group of ONE rank (where it moves nothing): the
+    collective path of a multi-GPU run -- device buffer, `dist.gather` over RCCL, unpacking -- on a one-GPU box
+    (tests/measure/rccl_one_rank.py, `bench.py` under a launcher).
     """
     distributed = shard and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
@@ -155,9 +158,10 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
             else:
                 t = trimmer._finish(names, dense, alignments[mine[k]]._datatype, res, seq, info, rows, None, params)
             local.append((res, seq, t))
-    if masks_only and (not distributed or world == 1):
+    collect = distributed and (world > 1 or force_collectives)
+    if masks_only and not collect:
         return [(np.asarray(r, dtype=bool), np.asarray(s, dtype=bool)) for r, s, _ in local]
-    if not distributed or world == 1:
+    if not collect:
         # (what the workers produced, as it is: rebuilding 64 results from their masks in the calling thread was a serial
         # tail of ~4 ms behind a 35 ms batch)
         return [t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], r, s, _gap_stats(trimmer)) for i, (r, s, t) in zip(mine, local)]

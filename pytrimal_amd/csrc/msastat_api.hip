@@ -145,6 +145,7 @@ struct msa_ctx {
     bool order_ready = false;
     msak::Tuning tuning;       // the MSA_* diagnostic switches, read once in msa_ctx_create
     bool have_ident = false, have_w = false;
+    bool have_wbar = false;    // wbar holds the mean weights of the current W (the compact pipeline leaves them to its kernel: wsum)
     DevBuf<uint32_t> hit, dst;
     DevBuf<float> row_avg, row_max, row_min;
     DevView<float> stats2;  // {mean, max} of the identity rows (state block)
@@ -193,6 +194,10 @@ struct msa_ctx {
     std::vector<int32_t> only_gaps_rows;  // the sequences the last msa_trim removed because the trimming left them with gaps only
 
     int sim_launches = 0;  // kernel launches of the last similarity pass (msa_debug_sim_launches)
+    // which path the last upload and the last statistic / trim call took (msa_debug_last_paths; MSA_PATH_* of msastat.h):
+    // [0] upload, [1] pipeline, [2] similarity kernel, [3] its waves per column, [4] its launches, [5] it wrote MDK itself,
+    // [6] pair kernel, [7] its waves per tile
+    int32_t paths[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // profiling
     int prof_on = 0;  // 0 off, 1 every kernel group, 2 the similarity and pair passes only
@@ -206,6 +211,19 @@ struct TuneScope {  // the context's diagnostic switches, visible to the launch 
     const msak::Tuning *prev;
     explicit TuneScope(msa_ctx *c) : prev(msak::current_tuning()) { msak::set_tuning(&c->tuning); }
     ~TuneScope() { msak::set_tuning(prev); }  // (calls nest: the batch engine runs trim_impl on its host-only view)
+};
+
+struct PathScope {  // msa_debug_last_paths: the call's entries start at "none", the launch wrappers' note lands in them at its end
+    msa_ctx *c;
+    explicit PathScope(msa_ctx *ctx) : c(ctx) {
+        std::fill(c->paths + 1, c->paths + 8, 0);
+        msak::launch_note() = msak::LaunchNote();
+    }
+    ~PathScope() {
+        const msak::LaunchNote &k = msak::launch_note();
+        c->paths[2] = k.sim_kind, c->paths[3] = k.lg_split, c->paths[4] = k.lg_launches, c->paths[5] = k.lg_fin;
+        c->paths[6] = k.pair_kind, c->paths[7] = k.pair_waves;
+    }
 };
 
 int fail_hip(msa_ctx *c, hipError_t e, const char *what) {
@@ -305,7 +323,7 @@ void prof_collect(msa_ctx *c) {
 }
 
 void invalidate(msa_ctx *c) {
-    c->have_planes = c->have_gaps = c->have_ident = c->have_w = false;
+    c->have_planes = c->have_gaps = c->have_ident = c->have_w = c->have_wbar = false;
     c->pairflag_state = 0;
     c->h_gaps.clear();
     c->gaps_staged = 0;
@@ -480,7 +498,7 @@ int run_pairs(msa_ctx *c, bool want_ident, bool want_w, bool want_counts) {
     c->flags_dirty = true;
     c->pairflag_state = 1;  // (its flag word arrives with the next flag fetch: sync_stream)
     if (need_ident) c->have_ident = true;
-    if (need_w) c->have_w = true;
+    if (need_w) c->have_w = c->have_wbar = true;
     return MSA_OK;
 }
 
@@ -655,6 +673,13 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
     HIPCHK(c, c->simnum.reserve((size_t)n + 64));
     HIPCHK(c, c->simden.reserve((size_t)n + 64));
     HIPCHK(c, c->simstate.reserve(msak::lg_state_floats(n)));
+    if (!c->have_wbar) {
+        // W is there from a compact pass (compact_begin), whose similarity kernel divides the pair pass's row sums itself:
+        // the predictor's mean weights of the ordinary kernel have not been computed for this W yet
+        HIPCHK(c, c->wbar.reserve((size_t)m + 128));
+        msak::launch_w_row_means(c->stream, c->wmat.p, m, c->ldw, c->wbar.p);
+        c->have_wbar = true;
+    }
     // (no memset of the two sums: the kernel writes every evaluated column, sim_finish does not use the others)
     {
         ProfScope ps(c, "sim");
@@ -686,12 +711,16 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     if (!gaps_windowed && !c->order_ready && compact_sim_applies(c, 0)) {  // a small alignment: three launches (compact_begin)
         int rc = compact_begin(c, vhash, dist, npos, false);
         c->pipe_active = false;
-        if (rc) {
-            (void)hipStreamSynchronize(c->stream);
-            return rc;
+        if (rc != MSA_E_FALLBACK) {
+            if (rc) {
+                (void)hipStreamSynchronize(c->stream);
+                return rc;
+            }
+            c->paths[1] = MSA_PATH_PIPE_COMPACT;
+            return fetch_similarity_finish(c, c->n, mdk_out, q_out, detail);
         }
-        return fetch_similarity_finish(c, c->n, mdk_out, q_out, detail);
     }
+    c->paths[1] = MSA_PATH_PIPE_SERIAL;
     const auto t_begin = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {  // MSA_TRACE=1: host time since the call began
         if (c->tuning.trace)
@@ -1200,6 +1229,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
     if ((rc = fetch_similarity_enqueue(c, n))) return rc;
     c->pipe_active = true;
     c->pipe_gated = gated;
+    c->paths[1] = forked ? MSA_PATH_PIPE_TWO_STREAMS : MSA_PATH_PIPE_ONE_STREAM;
     return MSA_OK;
 }
 
@@ -1345,7 +1375,9 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     const int flat_m = std::min(c->tuning.flat_max_m, msak::flat_rows_max());
     const bool flat = m <= flat_m && (n <= c->cus * 10 || m <= flat_m / 2);
     a.lists = flat ? 0 : 1;
-    if (!flat && !msak::lg_finishes(L, c->cus)) return MSA_E_INVALID;  // (compact_sim_applies keeps such shapes and switches out)
+    // (compact_sim_applies keeps the shapes and switches out for which the wave-per-column kernel would not finish the columns
+    // itself; should the two ever disagree, nothing has been enqueued yet and the callers take the ordinary pipeline)
+    if (!flat && !msak::lg_finishes(L, c->cus)) return MSA_E_FALLBACK;
     {
         ProfScope ps(c, "front");
         msak::launch_compact_front(c->stream, a);
@@ -1658,7 +1690,11 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
     int rc = set_shape(c, m, n, indet);
     if (rc) return rc;
     c->ld = round_up(std::max(n, 1), 64);
-    if (zero_copy_rows(c, m, n)) return stage_rows_zero_copy(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
+    c->paths[0] = MSA_PATH_UPLOAD_NONE;
+    if (zero_copy_rows(c, m, n)) {
+        c->paths[0] = MSA_PATH_UPLOAD_IN_PLACE;
+        return stage_rows_zero_copy(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
+    }
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {
@@ -1670,6 +1706,7 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
         }
         const bool aligned16 = ld % 16 == 0 && reinterpret_cast<uintptr_t>(rowmajor) % 16 == 0;
         if (ld == c->ld) {  // already pitched: one linear copy
+            c->paths[0] = MSA_PATH_UPLOAD_LINEAR;
             c->raw_own.tag = 0;
             HIPCHK(c, hipMemcpyAsync(c->raw_own.p, rowmajor, (size_t)m * c->ld, hipMemcpyHostToDevice, c->stream));
         } else if ((locked && ld % 8 == 0) || (aligned16 && c->tuning.upload_direct)) {
@@ -1678,9 +1715,11 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
             // writes).  They are zeroed when the buffer is new or was last used for another shape, and stay zero under
             // pitched copies of the same shape.
             if ((rc = zero_padding_for_shape(c, m, n))) return rc;
+            c->paths[0] = MSA_PATH_UPLOAD_PITCHED;
             HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor, (size_t)ld, (size_t)n, (size_t)m, hipMemcpyHostToDevice,
                                        c->stream));
         } else {
+            c->paths[0] = MSA_PATH_UPLOAD_PACKED;
             c->raw_own.tag = 0;
             rc = upload_rows_pitched(c, m, n, [&](int i) { return rowmajor + (size_t)i * ld; });
             if (rc) return rc;
@@ -1722,10 +1761,15 @@ int msa_upload_rows(msa_ctx *c, const uint8_t *const *rows, int32_t m, int32_t n
     int rc = set_shape(c, m, n, indet);
     if (rc) return rc;
     c->ld = round_up(std::max(n, 1), 64);
-    if (zero_copy_rows(c, m, n)) return stage_rows_zero_copy(c, m, n, [&](int i) { return rows[i]; });
+    c->paths[0] = MSA_PATH_UPLOAD_NONE;
+    if (zero_copy_rows(c, m, n)) {
+        c->paths[0] = MSA_PATH_UPLOAD_IN_PLACE;
+        return stage_rows_zero_copy(c, m, n, [&](int i) { return rows[i]; });
+    }
     HIPCHK(c, c->raw_own.reserve((size_t)std::max(m, 1) * c->ld + 256));
     c->raw = c->raw_own.p;
     if (m > 0 && n > 0) {  // (straight from the row pointers into the pinned pieces: no packed copy in between)
+        c->paths[0] = MSA_PATH_UPLOAD_PACKED;
         c->raw_own.tag = 0;
         rc = upload_rows_pitched(c, m, n, [&](int i) { return rows[i]; });
         if (rc) return rc;
@@ -1741,6 +1785,7 @@ int msa_attach_device(msa_ctx *c, const void *rowmajor_dev, int32_t m, int32_t n
     if (rc) return rc;
     const bool usable = (ld % 64 == 0) && (ld >= round_up(std::max(n, 1), 64)) &&
                         (reinterpret_cast<uintptr_t>(rowmajor_dev) % 16 == 0);
+    c->paths[0] = MSA_PATH_UPLOAD_ATTACHED;
     if (usable) {
         c->raw = static_cast<const uint8_t *>(rowmajor_dev);
         c->ld = ld;
@@ -1759,6 +1804,7 @@ int msa_gaps(msa_ctx *c, int32_t *gaps_out, int32_t *indet_out) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     int rc = ensure_gaps(c, true);
     if (rc) return rc;
     if (gaps_out) std::copy(c->h_gaps.begin(), c->h_gaps.end(), gaps_out);
@@ -1776,6 +1822,7 @@ int msa_pair_counts(msa_ctx *c, uint32_t *hit, uint32_t *dst) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     int rc = run_pairs(c, false, false, true);
     if (rc) return rc;
     const size_t bytes = (size_t)c->m * c->m * sizeof(uint32_t);
@@ -1789,6 +1836,7 @@ int msa_identities(msa_ctx *c, float *ident, float *w) {
     if (!c || !c->raw || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;  // empty alignments never reach the device
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     int rc = run_pairs(c, true, true, false);
     if (rc) return rc;
     const size_t row = (size_t)c->m * sizeof(float);
@@ -1811,6 +1859,7 @@ int msa_identity_stats(msa_ctx *c, float *avg_seq, float *max_seq) {
     if (!c || !c->raw || !avg_seq || !max_seq || c->m < 2 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     return identity_stats(c, avg_seq, max_seq);
 }
 
@@ -1819,6 +1868,7 @@ int msa_similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int32_t 
     if (!c || !c->raw || !vhash || !dist || !mdk_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     c->order_ready = false;  // (only msa_trim builds the column order ahead, for its own call)
     return similarity(c, vhash, dist, npos, gaps_windowed, mdk_out, q_out, detail);
 }
@@ -1827,6 +1877,7 @@ int msa_overlap(msa_ctx *c, float residue_overlap, float *spurious_out) {
     if (!c || !c->raw || !spurious_out || c->m <= 0 || c->n <= 0) return MSA_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     TuneScope tune(c);
+    PathScope path(c);
     return overlap(c, residue_overlap, spurious_out);
 }
 
@@ -1879,6 +1930,7 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
     if (!c->prefetched) HIPCHK(c, hipSetDevice(c->device));
     TrimTrace trace(c->tuning.trace != 0);
     TuneScope tune(c);
+    PathScope path(c);
     c->order_ready = false;
     c->pipe_active = false;
     c->colcnt_staged = false;
@@ -1960,14 +2012,15 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
         gaps_w = c->h_gaps;
         c->pipe_active = pipelined;
         c->pipe_gated = pipelined && method == MSA_METHOD_AUTOMATED1;
-    } else if (pipelined && compact_sim_applies(c, gap_hw)) {
-        rc = compact_begin(c, p->vhash, p->dist, p->npos, method == MSA_METHOD_AUTOMATED1);
+    } else if (pipelined && compact_sim_applies(c, gap_hw) &&
+               (rc = compact_begin(c, p->vhash, p->dist, p->npos, method == MSA_METHOD_AUTOMATED1)) != MSA_E_FALLBACK) {
         if (rc) {
             (void)hipStreamSynchronize(c->stream);
             return rc;
         }
         gaps_w = c->h_gaps;  // (no window)
         pipe_waited = true;  // (compact_begin waits itself: there is nothing for the host to do in between)
+        c->paths[1] = MSA_PATH_PIPE_COMPACT;
         trace.mark("compact pipeline");
     } else if (pipelined) {
         rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
@@ -1980,7 +2033,7 @@ static int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, ui
     } else {
         // residues per sequence: fetched by whatever synchronisation comes first, used by remove_all_gaps -- a small alignment
         // gets them together with its gap counts in one launch and one copy
-        if (compact_gaps_applies(c)) rc = compact_gaps(c);
+        if (compact_gaps_applies(c)) rc = compact_gaps(c), c->paths[1] = MSA_PATH_PIPE_COMPACT_GAPS;
         else rc = stage_row_totals(c);
         if (rc) return rc;
     }
@@ -2144,6 +2197,12 @@ void msa_prof_reset(msa_ctx *c) {
 
 // kernel launches of the context's last similarity pass (bench.py reports it beside the pass's time: a profiler lists launches)
 int msa_debug_sim_launches(msa_ctx *c) { return c ? c->sim_launches : 0; }
+
+int msa_debug_last_paths(msa_ctx *c, int32_t out[8]) {
+    if (!c || !out) return MSA_E_INVALID;
+    std::copy_n(c->paths, 8, out);
+    return MSA_OK;
+}
 
 void msa_prof_enable(msa_ctx *c, int enable) {
     if (c) c->prof_on = enable < 0 ? 0 : (enable > 2 ? 1 : enable);

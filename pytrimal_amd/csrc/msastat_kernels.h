@@ -30,6 +30,16 @@ Tuning tuning_from_env();
 void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults
 const Tuning *current_tuning();    // what set_tuning last received on this thread
 const Tuning &tuning();
+// What the launch wrappers last chose on this thread (diagnostics: msa_debug_last_paths copies it into the context).
+struct LaunchNote {
+    int sim_kind = 0;     // 0 none, 1 flat, 2 wave-per-column (byte offsets), 3 wave-per-column (row indices), 4 sequential, 5 lane-per-column (batches)
+    int lg_split = 0;     // waves of a workgroup per column (1: a wave per column)
+    int lg_launches = 0;  // launches of the pass
+    int lg_fin = 0;       // the kernel writes MDK and Q itself (the compact pipeline)
+    int pair_kind = 0;    // 0 none, 1 one row j per lane (software pipeline), 2 two rows j per lane
+    int pair_waves = 0;   // waves per tile
+};
+LaunchNote &launch_note();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch
 int set_max_lds_once(const void *kernel, int bytes);
 

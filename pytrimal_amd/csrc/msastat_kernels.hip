@@ -512,6 +512,10 @@ const Tuning &tuning() {
     static const Tuning defaults;
     return tl_tuning ? *tl_tuning : defaults;
 }
+LaunchNote &launch_note() {
+    static thread_local LaunchNote note;
+    return note;
+}
 Tuning tuning_from_env() {
     Tuning t;
     auto num = [](const char *name, int dflt) {
@@ -589,9 +593,12 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     const int nib = (m + PAIR_TI - 1) / PAIR_TI, njb = two ? m_pad / 128 : m_pad / 64;
     const int R = 64 * (two ? 2 : 1) / PAIR_TI, jc = (nib + R - 1) / R - 1;
     const unsigned tiles = (unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib);
+    launch_note().pair_kind = two ? 2 : 1;
+    launch_note().pair_waves = 1;
     if (two) pair_counts_kernel<PAIR_TI, 2><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
     else {
         const int K = pair_split(tiles, nchunk);
+        launch_note().pair_waves = K;
         pair_counts_pipe_kernel<1><<<tiles, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
                                                                                                                 wlow, undef_flag, nib, wsum);
     }

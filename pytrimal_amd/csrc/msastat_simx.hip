@@ -1613,6 +1613,8 @@ static int launch_lg(hipStream_t s, const LgAlign &one, const LgAlign *table, co
     else LG_BY_BIG(false, false);
 #undef LG_BY_BIG
 #undef LG_LAUNCH
+    LaunchNote &note = launch_note();
+    note.sim_kind = big ? 3 : 2, note.lg_split = split, note.lg_launches = launches, note.lg_fin = fin ? 1 : 0;
     if (launches_out) *launches_out = launches;
     return 0;
 }
@@ -1651,6 +1653,7 @@ void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_
 // prefix: 64-column groups per alignment; total = their number
 void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab) {
     if (total > 0) similarity_cols_batch_kernel<<<(total + 3) / 4, 256, 0, s>>>(table, prefix, K, total, static_cast<const float *>(tab));
+    launch_note() = LaunchNote{5, 0, 1, 0, launch_note().pair_kind, launch_note().pair_waves};
 }
 void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *prefix_encode, int blocks_encode, const int32_t *prefix_compact,
                             int blocks_compact, int K, const uint8_t *lut, int npos) {
@@ -1672,6 +1675,8 @@ void launch_compact_front(hipStream_t s, const CompactArgs &a) {
 int flat_rows_max() { return FLAT_ROWS_MAX; }
 void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab) {
     if (one.n > 0) similarity_flat_kernel<<<(unsigned)((one.n + 1) / 2), 256, 0, s>>>(one, static_cast<const float *>(tab));
+    LaunchNote &note = launch_note();
+    note.sim_kind = 1, note.lg_split = 0, note.lg_launches = 1, note.lg_fin = 1;
 }
 void launch_compact_identity(hipStream_t s, const CompactArgs &a) {
     compact_identity_kernel<<<(unsigned)((a.m + 3) / 4), 256, 0, s>>>(a);
@@ -1688,6 +1693,8 @@ int launch_similarity_seq(hipStream_t s, const uint8_t *codeT, int m, int n, con
     if (ncols <= 0) return 0;
     similarity_seq_kernel<<<(ncols + 63) / 64, 64, 0, s>>>(codeT, bx_ldk(m), m, n, cols, ncols, wup, ldw, static_cast<const float *>(tab),
                                                            num_out, den_out);
+    LaunchNote &note = launch_note();
+    note.sim_kind = 4, note.lg_split = 0, note.lg_launches = 1, note.lg_fin = 0;
     return 0;
 }
 

@@ -314,6 +314,58 @@ def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
     assert seconds < 180, f"the eight-rank run took {seconds:.0f} s"
 
 
+def _launcher_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def test_rccl_one_rank_collectives():
+    """RCCL for real, on this box's one GPU: a one-rank `nccl` process group created in a process where libmsastat_hip.so is
+    already loaded and has computed (tests/measure/rccl_one_rank.py, a fresh child: the launcher runs before any GPU call) --
+    `broadcast_trimmer`, an `all_reduce` of a device tensor, and `trim_batch(..., force_collectives=True)`, whose
+    `dist.gather` of the packed uint8 device buffer runs over RCCL even at world size 1; the gathered masks against single
+    trims and the oracle, and single trims again with RCCL alive."""
+    import json
+
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "measure", "rccl_one_rank.py")],
+                         capture_output=True, text=True, timeout=600, env=_launcher_env())
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["all_reduce"] == 1.0 and rec["hip_library_loaded_first"] is True
+    assert rec["trimmer_repr"] == "AutomaticTrimmer('automated1', platform='hip')" or "automated1" in rec["trimmer_repr"]
+    assert rec["gathered_masks_equal_single"] is True and rec["gathered_objects_equal_single"] is True
+    assert rec["trims_after_rccl_equal"] is True and rec["oracle_equal"] is True
+
+
+def test_bench_one_rank_under_the_launcher_uses_rccl():
+    """What the driver's scaling run starts, at N = 1: `python -m torch.distributed.run --nproc-per-node 1 bench.py --workload C5`
+    -- the `nccl` backend initialised by bench.py itself, barriers and the max-over-ranks all-reduce on device tensors, the
+    gather of the 64 masks over RCCL, ONE JSON line whose `config.backend` says so."""
+    import json
+
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C5", "--steps", "1",
+                          "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=_launcher_env())
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 1 and "C5" in rec["config"]["workload"]
+    assert rec["config"]["backend"] == "nccl" and rec["config"]["ranks_seen"] == 1
+    assert rec["config"]["kept_columns"] == 192501 and rec["config"]["kept_columns_ok"] is True and rec["value"] > 0
+
+
 def test_batch_module_in_a_fresh_process():
     """`import pytrimal_amd.batch` + a HIP `trim_batch` in a process that did not import torch first: importing the
     package must not initialise the GPU runtime (the platform is resolved lazily), so that batch's own `import torch`

@@ -458,15 +458,31 @@ def test_similarity_many_rows(ctx_with, kernel, shape):
 def test_similarity_tall_alignments_split_columns(ctx_with, shape):
     """Pfam-style shapes: far fewer columns than the chip has wave slots, so the launcher gives every column a workgroup of
     8 / 16 waves (lg_split), each on a segment of every round's partner list.  Q and MDK of that default path against the
-    plain sequential kernel (one lane per column, the reference's two loops) and against the wave-per-column path, bit for
-    bit, every column."""
+    CPU oracle on two 16-column slices, and against the plain sequential kernel (one lane per column, the reference's two
+    loops) and the wave-per-column path, bit for bit, every column."""
     m, n = shape
     a = synth_msa(m, n, 20000 + n)
     vhash, dist = oracle.aa_matrix()
     ctx = ctx_with()
     ctx.upload(a, ord("X"))
+    g = ctx.gaps()
     mdk, q = ctx.similarity(vhash, dist)
+    paths = ctx.last_paths()  # (the default dispatch: a workgroup of eight waves per column, row indices beyond 32768 rows)
+    assert paths["sim_waves_per_column"] == 8 and paths["sim_kernel"] == ("lg_big" if m > 32768 else "lg"), paths
+    # the CPU oracle itself on two 16-column slices of the workgroup-per-column path at the sizes it was built for (W from the
+    # device's pair pass -- the oracle's own would take minutes here; the device's W against the oracle on row slices)
+    assert np.array_equal(g, (a == ord("-")).sum(axis=0))
+    _, w = ctx.identities(want_ident=False)
     ctx.close()
+    rows = np.r_[0:40, m // 2 - 20:m // 2 + 20, m - 40:m]
+    ohit, odst = oracle.pair_counts(a[rows])
+    assert np.array_equal(bits(w[np.ix_(rows, rows)]), bits(oracle.weights(ohit, odst)))
+    for c0 in (0, n - 16):
+        sl = slice(c0, c0 + 16)
+        omdk, oq = oracle.similarity(np.ascontiguousarray(a[:, sl]), w, g[sl], vhash, dist)
+        assert np.array_equal(bits(q[sl]), bits(oq)), f"Q of columns {c0}..{c0 + 15} differs from the oracle"
+        assert np.array_equal(bits(mdk[sl]), bits(omdk)), f"MDK of columns {c0}..{c0 + 15} differs from the oracle"
+    del w
     for env in (dict(MSA_SIM_KERNEL="seq"), dict(MSA_LG_SPLIT="1")):
         other = ctx_with(**env)
         other.upload(a, ord("X"))
@@ -488,6 +504,7 @@ def test_similarity_beyond_32768_rows(ctx_with):
     g = ctx.gaps()
     assert np.array_equal(g, (a == ord("-")).sum(axis=0))
     mdk, q = ctx.similarity(vhash, dist)
+    assert ctx.last_paths()["sim_kernel"] == "lg_big"
     seq = ctx_with(MSA_SIM_KERNEL="seq")
     seq.upload(a, ord("X"))
     mdk2, q2 = seq.similarity(vhash, dist)
