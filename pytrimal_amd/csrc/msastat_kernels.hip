@@ -229,14 +229,17 @@ __global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_pipe_kernel(const 
                                                               uint32_t *__restrict__ dst_out, float *__restrict__ ident,
                                                               float *__restrict__ wmat, float *__restrict__ wlow,
                                                               int *__restrict__ undef_flag, int n_iblocks, uint32_t *__restrict__ wsum) {
-    pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, n_iblocks, (int)blockIdx.x, wsum);
+    int ib, jb;
+    if (!pair_tile_xcd<PAIR_TI>(n_iblocks, m_pad / 64, (int)blockIdx.x, ib, jb)) return;  // (uniform per workgroup)
+    pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, ib, jb, wsum);
 }
 // (a batch holds alignments of the one-row-per-lane regime only -- below ~4100 sequences: pair_tiles_pipe)
 __global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
     int local;
     const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
-    pair_counts_pipe_body<1>(d.planes, d.nchunk, d.m_pad, d.m, d.ldw, nullptr, nullptr, d.ident, d.w, d.wlow, d.flags + 1,
-                             (d.m + PAIR_TI - 1) / PAIR_TI, local);
+    int ib, jb;
+    pair_tile<PAIR_TI, 1>((d.m + PAIR_TI - 1) / PAIR_TI, local, ib, jb);
+    pair_counts_pipe_body<1>(d.planes, d.nchunk, d.m_pad, d.m, d.ldw, nullptr, nullptr, d.ident, d.w, d.wlow, d.flags + 1, ib, jb);
 }
 
 // (the identity row statistics -- selectMethod's sequential float32 sums -- live in msastat_simx.hip: they are
@@ -599,7 +602,18 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     else {
         const int K = pair_split(tiles, nchunk);
         launch_note().pair_waves = K;
-        pair_counts_pipe_kernel<1><<<tiles, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
+        // (dealt to the XCDs by j-block: pair_tile_xcd; the grid is eight times the longest of the eight lists)
+        int longest = 0;
+        for (int x = 0; x < 8; ++x) {
+            int cnt = 0;
+            for (int g = 0; 8 * g < njb; ++g) {
+                const int y = 8 * g + ((g & 1) ? 7 - x : x);
+                if (y < njb) cnt += std::min(nib, (y + 1) * R);
+            }
+            longest = std::max(longest, cnt);
+        }
+        const unsigned grid = 8u * (unsigned)longest;
+        pair_counts_pipe_kernel<1><<<grid, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
                                                                                                                 wlow, undef_flag, nib, wsum);
     }
 }

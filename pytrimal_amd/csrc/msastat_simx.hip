@@ -40,6 +40,7 @@
 
 #include "msastat_kernels.h"
 #include "msastat_device.h"
+#include "msastat_lgloop.inc"
 
 namespace msak {
 namespace {
@@ -80,6 +81,16 @@ __device__ __forceinline__ float rl(float v, int lane) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a wave-uniform 64-bit mask as a per-lane predicate / the set bits below the lane: the mask stays in scalar registers (the
+// shifts by the lane index the plain C spelling implies keep 64-bit per-lane masks alive in two vector registers each, across the
+// whole round loop)
+__device__ __forceinline__ bool lane_in(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+__device__ __forceinline__ int bits_below_lane(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ float unif(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
 
 // Inclusive prefix sum over the wave with DPP row shifts (the pattern LLVM's atomic optimizer uses on gfx9):
 // Hillis-Steele inside each row of 16 lanes, then the row totals are carried across rows.  Lanes that a shift
@@ -165,7 +176,7 @@ __device__ __forceinline__ float chunk_step(float s, const float (&x)[4]) {
 
 // scan_rows over an arbitrary set of lanes
 __device__ __forceinline__ float scan_lanes(float s, float top, float ie, float io, unsigned long long segm, int lane, int &cross) {
-    const bool in = ((segm >> lane) & 1ull) != 0ull;
+    const bool in = lane_in(segm);
     const float a = in ? ie : 0.0f;
     const float P = wave_prefix(a);
     unsigned long long ties = __ballot(in && ie != io);
@@ -218,61 +229,125 @@ __device__ __forceinline__ float flat_add_chunk(float s, const float (&x)[4], in
     return s;
 }
 
-// Row j of one column in the reference's order: its partners are the rows k > j, 64 per block (lane = partner), 256 per
-// chunk.  Dense: EVERY row behind j is read -- W[j][k] from the row-major upper triangle (coalesced), the column's code
-// of row k (coalesced bytes) -- and a row that takes no part contributes W x 0 = 0, which changes no float32 sum; the
-// rows up to j inside the first block read the zeros of the lower triangle, the codes behind row m are BX_SKIP.  No
-// list, hence no load that depends on another: the loads of a chunk are issued while the chunk before it is added up
-// (with the compacted lists of round 2 every chunk waited for a gather through entries it had to load first, under a
+// cycle stamps of MSA_SIM_MODE=64 (diagnostics): [0] prologue, [1] round loops, [2] stitching, [3] waves, [4] rounds,
+// [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles), [8] most rounds of a wave, [10] ordered rows,
+// [11] their cycles; [13] [14] [15] [5] the prologue's parts (histogram, G, rows skipped, ordered first rows)
+__device__ unsigned long long g_bx_stamps[16];
+__device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): column, cycles / 64 of the three phases, rounds, shortened rounds, [6] ordered rows
+
+// U consecutive terms per lane (x[i]: term U lane + i) added to s in order: flat_add_chunk for any run length.  A row evaluated in
+// the reference's order is there BECAUSE it holds a binade crossing: with the row's terms in ONE run per 64 U partners the scan
+// names the crossing lane at once -- the lanes before it commit on the old grid, its U terms are added one by one, the lanes
+// behind it start over on the new grid: two scans and U dependent adds per crossing, however long the row (with U = 4 a row of
+// 1000 partners was four chunks, each with a scan of its own, the crossing chunk with two: 6 000 cycles per ordered row at 1000
+// rows, a fifth of a wave's life outside the round loop).
+template <int U>
+__device__ __forceinline__ float flat_add_run(float s, const float (&x)[U], int lane) {
+    float top = x[0];  // (terms >= 0: nothing to add if the largest is zero)
+#pragma unroll
+    for (int i = 1; i < U; ++i) top = fmaxf(top, x[i]);
+    if (__ballot(top != 0.0f) == 0ull) return s;
+    unsigned long long live = ~0ull;
+    while (live) {
+        float B, u;
+        int f;
+        if (grid_of(s, B, u)) {
+            const float Bo = B + u;
+            float ae = B, ao = Bo;
+#pragma unroll
+            for (int i = 0; i < U; ++i) ae = ae + x[i], ao = ao + x[i];
+            const float sp = scan_lanes(s, 2.0f * B, ae - B, ao - Bo, live, lane, f);
+            if (f >= 64) return rl(sp, 63);  // (live always ends at lane 63)
+            const unsigned long long before = live & ((1ull << f) - 1ull);
+            if (before) s = rl(sp, 63 - __builtin_clzll(before));
+        } else {
+            f = __builtin_ctzll(live);  // zero / tiny sum: the next lane's terms as the reference adds them
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) s = s + rl(x[i], f);
+        live &= ~((2ull << f) - 1ull);
+    }
+    return s;
+}
+
+// Row j of one column in the reference's order: its partners are the rows k > j, U CONSECUTIVE ones per lane (k = kb + U lane +
+// i), 64 U per chunk.  Dense: EVERY row behind j is read -- W[j][k] from the row-major upper triangle (16-byte loads), the
+// column's code of row k (U bytes per lane) -- and a row that takes no part contributes W x 0 = 0, which changes no float32 sum;
+// the rows up to j inside the first chunk read the zeros of the lower triangle, the codes behind row m are BX_SKIP; a lane whose
+// partners lie behind the row's padding (k >= ldw, a multiple of 64) loads nothing.  No list, hence no load that depends on
+// another (with the compacted lists of round 2 every chunk waited for a gather through entries it had to load first, under a
 // vector-memory pipeline that the round loops of the other waves keep saturated: 20 000 cycles per ordered row).
 // s = {numerator sum, denominator sum}; `which` selects the sums to advance.
 // (Every argument by value: a struct passed by reference would live in scratch memory and make the caller's
 // loop counters look divergent to the compiler.)
 // cj: the column's code of row j (the callers hold it: loading it here put one more memory latency in front of the row's
 // own loads, a fifth of an ordered row's time on short rows).
+// (measured in round 5, every variant bit-exact: 4 / 8 / 16 partners per lane -- 99 / 76 / 85 kcycles of ordered rows per wave at
+// 1000 x 4000 once the arguments are scalars again; sixteen spill, four cost a scan per 256 partners; the next chunk's loads in
+// flight while this one is added up: no gain, twelve more live registers)
+#ifndef MSA_ROW_U  // (A/B builds: tools/build_variant.sh)
+#define MSA_ROW_U 8
+#endif
+constexpr int ROW_U = MSA_ROW_U;  // partners per lane and chunk of an ordered row
 __device__ __noinline__ f2 exact_row(ColView cv, gf32p wup, ldsp tab, int j, uint32_t cj, int which, f2 s) {
+    constexpr int U = ROW_U, Q = U / 4;
     const int lane = threadIdx.x & 63;
+    // Everything the callers pass is wave-uniform, but the arguments of a function that is not inlined arrive in vector registers
+    // and the compiler must take them for divergent: the sums' loop below (grid, crossing lane, the set of lanes still to commit)
+    // then runs as a divergent loop -- per-lane 64-bit masks, exec-mask bookkeeping around every branch, twice the instructions.
+    // Through readfirstlane they are scalars again.
+    j = uni(j), cj = (uint32_t)uni((int)cj), which = uni(which);
+    cv.m = uni(cv.m), cv.ldw = uni(cv.ldw);
+    cv.colcode = uniform_ptr(cv.colcode), wup = uniform_ptr(wup);
+    tab = (ldsp)(__attribute__((address_space(3))) void *)(uintptr_t)(uint32_t)uni((int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)tab);
     if (cj == BX_SKIP) return s;
     gf32p wr = wup + (size_t)j * cv.ldw;
-    float s0 = s.x, s1 = s.y;
-    // A lane holds FOUR CONSECUTIVE partners of a chunk (k = kb + 4 lane + i: one 16-byte load of W, one dword of codes) and
-    // the chunk goes through flat_add_chunk: ties and the crossing are settled by the scan over the lanes, where the block
-    // test of rounds 2-3 (chunk_step: lane = partner 64 i + lane) fell back to 64 adds one after the other for every block
-    // that held a tie or the crossing -- and a row is here BECAUSE it holds a crossing.
+    float s0 = unif(s.x), s1 = unif(s.y);
     typedef float f4 __attribute__((ext_vector_type(4)));
-    auto request = [&](int kb, f4 &w, uint32_t &c) {  // (reads at most 255 entries past row m: W's slack, the code padding)
-        w = *reinterpret_cast<const __attribute__((address_space(1))) f4 *>(wr + kb + 4 * lane);
-        c = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(cv.colcode + kb + 4 * lane);
-    };
-    f4 w, wn;
-    uint32_t c, cn;
-    int kb = (j + 1) & ~63;
-    request(kb, w, c);
-    for (; kb < cv.m; kb += 256) {
-        request(kb + 256 < cv.m ? kb + 256 : kb, wn, cn);  // the next chunk (a repeat behind the last: not used)
-        f2 de[4];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int lim = cv.ldw;  // (W rows and code columns are zeros / BX_SKIP from row m up to here; U divides 64)
+    auto request = [&](int kb, f4 (&w)[Q], uint32_t (&c)[Q]) {
+        const int k0 = kb + U * lane;
+        if (k0 < lim) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            de[i] = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(tab + ((cj << 5) + ((c >> (8 * i)) & 0xFFu)));
+            for (int q = 0; q < Q; ++q) w[q] = *reinterpret_cast<const __attribute__((address_space(1))) f4 *>(wr + k0 + 4 * q);
+            if constexpr (Q == 4) {
+                const u4 cc = *reinterpret_cast<const __attribute__((address_space(1))) u4 *>(cv.colcode + k0);
+                c[0] = cc[0], c[1] = cc[1], c[2] = cc[2], c[3] = cc[3];
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) c[q] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(cv.colcode + k0 + 4 * q);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) w[q] = f4{0.0f, 0.0f, 0.0f, 0.0f}, c[q] = 0x01010101u * BX_SKIP;
+        }
+    };
+    f4 w[Q];
+    uint32_t c[Q];
+    int kb = (j + 1) & ~(U - 1);
+    request(kb, w, c);
+    for (; kb < cv.m; kb += 64 * U) {
+        const uint32_t rowoff = cj << 5;
         if (which & 1) {
-            const float x[4] = {w[0] * de[0].x, w[1] * de[1].x, w[2] * de[2].x, w[3] * de[3].x};
-            s0 = flat_add_chunk(s0, x, lane);
+            float x[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                x[i] = w[i >> 2][i & 3] * *reinterpret_cast<const __attribute__((address_space(3))) float *>(tab + (rowoff + ((c[i >> 2] >> (8 * (i & 3))) & 0xFFu)));
+            s0 = flat_add_run<U>(s0, x, lane);
         }
         if (which & 2) {
-            const float x[4] = {w[0] * de[0].y, w[1] * de[1].y, w[2] * de[2].y, w[3] * de[3].y};
-            s1 = flat_add_chunk(s1, x, lane);
+            float x[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                x[i] = w[i >> 2][i & 3] * *reinterpret_cast<const __attribute__((address_space(3))) float *>(tab + (rowoff + 4 + ((c[i >> 2] >> (8 * (i & 3))) & 0xFFu)));
+            s1 = flat_add_run<U>(s1, x, lane);
         }
-        w = wn;
-        c = cn;
+        if (kb + 64 * U < cv.m) request(kb + 64 * U, w, c);
     }
     return f2{s0, s1};
 }
 
-// cycle stamps of MSA_SIM_MODE=64 (diagnostics): [0] prologue, [1] round loops, [2] stitching, [3] waves, [4] rounds,
-// [6] wave lifetimes in 100 MHz ticks, [7] longest wave (cycles), [8] most rounds of a wave, [10] ordered rows,
-// [11] their cycles
-__device__ unsigned long long g_bx_stamps[16];
-__device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): column, cycles / 64 of the three phases, rounds, shortened rounds
 
 // ---- per-lane grids ------------------------------------------------------------------------------------------
 // A kernel that fixes ONE grid per chain and round (the binade of the sum at the round's first row: round 2's `bx`)
@@ -293,9 +368,6 @@ __device__ unsigned int g_bx_rec[16384 * 8];  // per wave (diagnostics): column,
 // one ordered row, never exactness: every commit is checked against the true sum.
 constexpr int LG_R0 = 1;  // rows evaluated in order before the first round (at least up to the first valid row)
 
-__device__ __forceinline__ float unif(float v) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
-}
 
 // One chain at the end of a round: s before the round's first row; per lane the grid it accumulated on (Bl; 0 =
 // plain sums from zero) and its increments for an even / odd sum.  Commits every row of vmask; returns the sum
@@ -422,6 +494,20 @@ __device__ __forceinline__ void round_loop_lds(const float *wlow_g, uint32_t row
                                                const __attribute__((address_space(1))) uint32_t *off,
                                                const __attribute__((address_space(1))) uint16_t *trow, int tstart, int tend,
                                                uint32_t joff, uint32_t base, f2 &an, f2 &ad) {
+    if constexpr (!BIG) {
+        // THE loop: one asm statement with hand-allocated registers (msastat_lgloop.inc, generated by tools/gen_lg_loop.py, where
+        // its design is described): blocks of 16 steps, 16 W rows in flight, VMCNT counted by hand, two steps' products per
+        // v_pk_mul_f32, nothing requested behind the last block.  (The C++ loop below -- small asm statements around compiler-
+        // scheduled code, what rounds 2 - 4 shipped for every size -- stays for the row-index lists beyond 32768 rows.)
+        const uint64_t wbase = (uint64_t)uniform_ptr((const __attribute__((address_space(1))) char *)(uint64_t)wlow_g);
+        const uint64_t offp = (uint64_t)uniform_ptr(off + tstart), trowp = (uint64_t)uniform_ptr(trow + tstart);
+        uint32_t nblk = (uint32_t)uni((tend - tstart + 15) >> 4);
+        asm volatile(LG_LOOP_ASM
+                     : [an] "+v"(an), [ad] "+v"(ad), [nblk] "+s"(nblk)
+                     : [joff] "v"(joff), [wuni] "s"(wbase), [base] "s"(base), [offp] "s"(offp), [trowp] "s"(trowp)
+                     : LG_LOOP_CLOBBERS);
+        return;
+    }
     typedef const __attribute__((address_space(4))) uint32_t *c32;
     auto sload = [&](LgEntries &en, int t) {  // 16 entries = 64 + 32 bytes (t % 16 == 0)
         c32 po = (c32)(uint64_t)(off + t);
@@ -546,6 +632,17 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
         if constexpr (FIN) return j < m - 1 ? (float)A.wsum[j] * (1.0f / 65536.0f) / (float)(m - 1 - j) : 0.0f;
         else return A.wbar[j];
     };
+    // ... in two halves: what is loaded (requested a round ahead: behind the round loop, in front of the stitching) and what is
+    // made of it (rows m .. of wbar / wsum are zero padding up to m + 64; a round may look further)
+    auto wmean_raw = [&](int j) -> uint32_t {
+        if (j >= m) return 0u;
+        if constexpr (FIN) return A.wsum[j];
+        else return __float_as_uint(A.wbar[j]);
+    };
+    auto wmean_of = [&](uint32_t raw, int j) -> float {
+        if constexpr (FIN) return j < m - 1 ? (float)raw * (1.0f / 65536.0f) / (float)(m - 1 - j) : 0.0f;
+        else return __uint_as_float(raw);
+    };
     const int nv = cv.nvalid;
     unsigned long long t_pro = 0, t_loop = 0, t_res = 0, n_rounds = 0, n_ordered = 0, t_ord = 0, t0c = 0, rt0 = 0, n_both = 0;
     if (STAMP) {
@@ -566,11 +663,29 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
         if (!resume) {
             __builtin_amdgcn_s_setprio(3);  // (the ordered first row: as the stitching below)
             // the column's residue frequencies -> G
-            for (int k = lane; k < m; k += 64) {
-                const uint32_t ck = cv.colcode[k];
-                if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
+            // (four codes per lane and load, four loads in flight: a byte per lane and pass was sixteen memory latencies one
+            // after the other at 1000 rows -- a third of the prologue; the column is padded with BX_SKIP up to a multiple of 256 rows)
+            {
+                const int mup = (m + 255) & ~255;
+                for (int kb = 0; kb < mup; kb += 1024) {
+                    uint32_t cw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k0 = kb + 256 * q + 4 * lane;
+                        cw[q] = k0 < mup ? *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(cv.colcode + k0) : 0x01010101u * BX_SKIP;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t ck = (cw[q] >> (8 * i)) & 0xFFu;
+                            if (ck != BX_SKIP) atomicAdd(&hist[wave][ck >> 3], 1u);
+                        }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            unsigned long long tp1 = 0, tp2 = 0, tp3 = 0;
+            if (STAMP) tp1 = __builtin_readcyclecounter();
             if (lane < 32) {
                 float g = 0.0f;
                 for (int b = 0; b < 29; ++b) g += (float)hist[wave][b] * tab[b * 32 + lane].x;
@@ -579,6 +694,7 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
+            if (STAMP) tp2 = __builtin_readcyclecounter();
             // the first rows in the reference's order: at least up to the first row that takes part
             float qn0 = 0.0f, qd0 = 0.0f;
             int jstart = 0, tb = 0;
@@ -587,6 +703,7 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
                 // 570 rows are gaps spent 350 000 cycles walking them one dependent load at a time)
                 for (; jstart + 64 < m - 1; jstart += 64)
                     if (__ballot(cv.colcode[jstart + lane] != BX_SKIP)) break;
+                if (STAMP) tp3 = __builtin_readcyclecounter();
                 bool seen = false;
                 while (jstart < m - 1 && tb < nv && (jstart < (r0_ & 0xFFFF) || !seen)) {
                     const uint32_t cj = (uint32_t)uni((int)cv.colcode[jstart]);
@@ -610,6 +727,12 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
             if (STAMP) {
                 const unsigned long long t1 = __builtin_readcyclecounter();
                 t_pro = t1 - t0c;
+                if (lane == 0) {  // the prologue's parts: histogram, G, rows skipped, the ordered first row(s)
+                    atomicAdd(&g_bx_stamps[13], tp1 - t0c);
+                    atomicAdd(&g_bx_stamps[14], tp2 - tp1);
+                    atomicAdd(&g_bx_stamps[15], tp3 - tp2);
+                    atomicAdd(&g_bx_stamps[5], t1 - tp3);
+                }
                 t0c = t1;
             }
             __builtin_amdgcn_s_setprio(0);
@@ -648,18 +771,22 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
         alive = uni(reinterpret_cast<const int *>(hdr)[7]) != 0;
     }
     if (!alive) return;  // (uniform per workgroup when the waves share a column)
+    // the round's codes and mean weights, requested a round ahead (two memory latencies in front of every round loop otherwise:
+    // with three to four waves per SIMD -- one alignment of 1000 x 4000 -- nothing hides them)
+    uint32_t code_next = (uint32_t)cv.colcode[j0 + lane], wm_next = wmean_raw(j0 + lane);  // (j0 + 63 < ldk: the column's padding)
     for (; j0 < m - 1 && tbase < nv && j0 < jend; j0 += 64) {
         const int nrows = min(64, m - 1 - j0);
-        const uint32_t craw = lane < nrows ? (uint32_t)cv.colcode[j0 + lane] : BX_SKIP;
+        const uint32_t craw = lane < nrows ? code_next : BX_SKIP;
+        const uint32_t wm_raw = wm_next;
         const unsigned long long vall = __ballot(craw != BX_SKIP);
         const uint32_t cj8 = lane >= first ? craw : BX_SKIP;
         const unsigned long long vmask = __ballot(cj8 != BX_SKIP);
         first = 0;
         // predicted sum in front of every row -> the lane's grid
-        const int behind = nv - (tbase + __builtin_popcountll(vall & ((2ull << lane) - 1ull)));
+        const int behind = nv - (tbase + bits_below_lane(vall) + (lane_in(vall) ? 1 : 0));
         const bool takes = cj8 != BX_SKIP;
         // (the row's mean weight over its partners, a property of the alignment: rows of a tight family add less)
-        const float qd = takes ? (float)behind * wmean(j0 + lane) : 0.0f;
+        const float qd = takes ? (float)behind * wmean_of(wm_raw, j0 + lane) : 0.0f;
         const float qn = takes ? qd * gtab[wave][cj8 >> 3] : 0.0f;
         float Bn, Bd, Qn, Qd;
         {
@@ -689,6 +816,8 @@ __device__ __forceinline__ void similarity_lg_body(const LgAlign &A, int col, in
             }
             if (ts < te) round_loop_lds<BIG>(A.wlow, 4u * (uint32_t)A.ldw, cv.off, vtrow, ts, te, joff, (uint32_t)uni((int)base), an, ad);
         }
+        // (the next round's: in flight during the stitching)
+        code_next = (uint32_t)cv.colcode[j0 + 64 + lane], wm_next = wmean_raw(j0 + 64 + lane);
         if (STAMP) {
             const unsigned long long t1 = __builtin_readcyclecounter();
             t_loop += t1 - t0c;
@@ -1709,6 +1838,8 @@ extern "C" int msa_debug_bx_stamps(unsigned long long *out16, int reset) {
     if (reset) {
         unsigned long long z[16] = {0};
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_stamps), z, sizeof(z));
+        void *rec = nullptr;
+        if (hipGetSymbolAddress(&rec, HIP_SYMBOL(g_bx_rec)) == hipSuccess) rc |= (int)hipMemset(rec, 0, sizeof(unsigned int) * 16384 * 8);
     }
     return rc;
 }
