@@ -126,32 +126,11 @@ __device__ __forceinline__ void pair_tile(int n_iblocks, int t, int &ib, int &jb
     }
 }
 
-// The same tiles dealt to the XCDs j-block by j-block (one alignment, one row j per lane: pair_counts_pipe_kernel).  Workgroups
-// b and b + 8 share an XCD (round-robin dispatch; a matter of speed only), and every tile of a j-block streams the same eight
-// j planes (nchunk x 2 KB: 641 KB at 2000 x 10000) -- dealt as the one-dimensional order above, every XCD walks every j-block
-// and its 4 MB L2 holds a fifth of what its waves stream: 1 150 MB per launch from beyond the L2 for 20 MB of planes
-// (profiles/r04_pmc_hbm_traffic.txt; invisible alone -- the kernel is bound by VALU issue -- but not beside four similarity
-// kernels).  Here XCD x owns the j-blocks x, 15 - x, 16 + x, 31 - x, ... (a snake: j-block y holds min(n_iblocks, (y + 1) R)
-// tiles, so every XCD gets the same number of tiles per pair of groups); block b is tile b / 8 of XCD b % 8's list.
-// Returns false for a block behind its XCD's last tile (the grid is 8 x the longest list: pair_tiles_xcd).
-template <int TI>
-__device__ __forceinline__ bool pair_tile_xcd(int n_iblocks, int n_jblocks, int b, int &ib, int &jb) {
-    constexpr int R = 64 / TI;
-    const int x = b & 7;
-    int q = b >> 3;
-    for (int g = 0; 8 * g < n_jblocks; ++g) {
-        const int y = 8 * g + ((g & 1) ? 7 - x : x);
-        if (y >= n_jblocks) continue;
-        const int cnt = min(n_iblocks, (y + 1) * R);
-        if (q < cnt) {
-            ib = q, jb = y;
-            return true;
-        }
-        q -= cnt;
-    }
-    return false;
-}
-
+// (Measured twice and not shipped -- round 2, and round 5 with the waves of a workgroup sharing a tile: the same tiles dealt to the
+// XCDs j-block by j-block, XCD x owning the j-blocks x, 15 - x, 16 + x, ... so that its L2 holds the j planes its waves stream
+// instead of a fifth of them.  The re-reads from beyond the L2 go, the time does not: 0.31 -> 0.37 ms at 2000 x 10000, 0.041 -> 0.053
+// at 1000 x 4000 alone -- hundreds of tiles of one XCD ask its L2 for the same lines at the same moment -- and 24.0 against 24.2 ms
+// for the C5 batch: gpurun_out/ab6, profiles/r05_pairs_xcd.txt.)
 // epilogue of a tile: row-wise (coalesced along j) and mirrored (TI contiguous values per lane).  miss[][] counted the
 // misses of all 32 * nchunk columns (the columns behind n are gaps in every row).
 template <int TI, int TJ>
@@ -250,9 +229,6 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
     const int j0 = jb * (64 * TJ);
     if (j0 >= m_pad) return;
     if (j0 + 64 * TJ - 1 <= i0) return;
-#ifdef MSA_PAIR_PRIO
-    __builtin_amdgcn_s_setprio(MSA_PAIR_PRIO);
-#endif
     uint32_t miss[TJ][TI], dst[TJ][TI], d[TJ][TI];
 #pragma unroll
     for (int u = 0; u < TJ; ++u)

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_pipe_kernel(const 
                                                               float *__restrict__ wmat, float *__restrict__ wlow,
                                                               int *__restrict__ undef_flag, int n_iblocks, uint32_t *__restrict__ wsum) {
     int ib, jb;
-    if (!pair_tile_xcd<PAIR_TI>(n_iblocks, m_pad / 64, (int)blockIdx.x, ib, jb)) return;  // (uniform per workgroup)
+    pair_tile<PAIR_TI, TJ>(n_iblocks, (int)blockIdx.x, ib, jb);
     pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, ib, jb, wsum);
 }
 // (a batch holds alignments of the one-row-per-lane regime only -- below ~4100 sequences: pair_tiles_pipe)
@@ -602,18 +602,7 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     else {
         const int K = pair_split(tiles, nchunk);
         launch_note().pair_waves = K;
-        // (dealt to the XCDs by j-block: pair_tile_xcd; the grid is eight times the longest of the eight lists)
-        int longest = 0;
-        for (int x = 0; x < 8; ++x) {
-            int cnt = 0;
-            for (int g = 0; 8 * g < njb; ++g) {
-                const int y = 8 * g + ((g & 1) ? 7 - x : x);
-                if (y < njb) cnt += std::min(nib, (y + 1) * R);
-            }
-            longest = std::max(longest, cnt);
-        }
-        const unsigned grid = 8u * (unsigned)longest;
-        pair_counts_pipe_kernel<1><<<grid, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
+        pair_counts_pipe_kernel<1><<<tiles, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
                                                                                                                 wlow, undef_flag, nib, wsum);
     }
 }
