@@ -23,6 +23,7 @@ struct Tuning {
     int compact = 1;           // MSA_COMPACT=0: small alignments through the ordinary launch sequence (tests, A/B); 1: the compact pipeline
     int compact_max_m = 512;   // MSA_COMPACT_MAX_M: sequences up to which the similarity pipeline runs compact
     int flat_max_m = 128;      // MSA_FLAT_MAX_M: sequences up to which the compact pipeline runs the flat similarity kernel (0: never)
+    int flat_u = 0;            // MSA_FLAT_U: terms per lane and scan of the flat similarity kernel (0: by size; A/B: 4, 8, 16)
     int zerocopy_kb = 96;      // MSA_ZEROCOPY_KB: rows up to this size stay in pinned host memory and the kernels read them over the link
     int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
 };

@@ -539,6 +539,7 @@ Tuning tuning_from_env() {
     t.compact_max_m = num("MSA_COMPACT_MAX_M", 512);
     t.zerocopy_kb = num("MSA_ZEROCOPY_KB", 96);
     t.flat_max_m = num("MSA_FLAT_MAX_M", 128);
+    t.flat_u = num("MSA_FLAT_U", 0);
     t.lg_rounds = num("MSA_LG_ROUNDS", -1);
     t.lg_split = num("MSA_LG_SPLIT", 0);
     return t;

@@ -1,0 +1,763 @@
+// msastat_small.hip -- the layout kernels of the similarity pass (column-major codes, the compacted lists of every column's valid
+// rows, the mean weights), the identity row statistics (sequential float32 sums through the binade test), and the kernels of
+// small alignments: the flat similarity kernel, the one-launch front of the compact pipeline, the lane-per-column kernel of
+// batches (msa_trim_batch).  The similarity kernel itself: msastat_simx.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "msastat_kernels.h"
+#include "msastat_device.h"
+#include "msastat_sums.h"
+
+namespace msak {
+namespace {
+
+// wbar[j] = mean of W[j][k] over k > j (the upper triangle of a row; 0 for the last row): the similarity kernel's
+// predictor scales its per-row estimates with it.  Any order of summation: it is an estimate, nothing exact hangs on it.
+__device__ __forceinline__ void w_row_means_body(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar, int bx) {
+    const int lane = threadIdx.x & 63;
+    const int j = bx * 4 + (threadIdx.x >> 6);
+    if (j >= m + 64) return;
+    float s = 0.0f;
+    if (j < m) {
+        const float *r = wup + (size_t)j * ldw;
+        for (int k = j + 1 + lane; k < m; k += 64) s += r[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    }
+    if (lane == 0) wbar[j] = (j < m - 1) ? s / (float)(m - 1 - j) : 0.0f;  // (rows m .. m + 63: zeros, a round reads past the end)
+}
+__global__ __launch_bounds__(256) void w_row_means_kernel(const float *__restrict__ wup, int m, int ldw, float *__restrict__ wbar) {
+    w_row_means_body(wup, m, ldw, wbar, (int)blockIdx.x);
+}
+
+// ---- identity row statistics (Cleaner::calculateSeqIdentity's consumers: selectMethod, getCutPointClusters) --------
+// Per sequence: the float32 sum of its identities with every other sequence IN INDEX ORDER (/ (m - 1)), their
+// maximum and minimum; then the sums of the row averages and of the row maxima in index order (/ m).  The terms are
+// >= 0, so the sequential sums are evaluated a chunk of 256 terms at a time with the binade test of the similarity
+// kernel's ordered rows (chunk_step): one wave per sequence instead of one dependent add chain per lane (83 + 24 us
+// -> a few us at m = 2000), bit-identical.
+__device__ __forceinline__ void identity_rows_body(const float *__restrict__ ident, int m, int ldw,
+                                                   float *__restrict__ row_avg, float *__restrict__ row_max,
+                                                   float *__restrict__ row_min, int bx) {
+    const int lane = threadIdx.x & 63;
+    const int i = uni((int)(bx * 4 + (threadIdx.x >> 6)));
+    if (i >= m) return;
+    const float *r = ident + (size_t)i * ldw;  // ident[i][j] == ident[j][i]
+    float s = 0.0f, mx = 0.0f, mn = 1.0f;      // (getCutPointClusters starts its minimum at 1)
+    for (int base = 0; base < m; base += 256) {
+        float x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = base + 64 * c + lane;
+            const bool in = t < m && t != i;
+            const float v = in ? r[t] : 0.0f;
+            x[c] = v;
+            if (in) {
+                mx = mx < v ? v : mx;
+                mn = mn > v ? v : mn;
+            }
+        }
+        s = chunk_step(s, x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_xor(mx, off, 64), b = __shfl_xor(mn, off, 64);
+        mx = mx < a ? a : mx;
+        mn = mn > b ? b : mn;
+    }
+    if (lane == 0) {
+        row_avg[i] = s / (float)(m - 1);
+        row_max[i] = mx;
+        if (row_min) row_min[i] = mn;
+    }
+}
+__global__ __launch_bounds__(256) void identity_rows_kernel(const float *__restrict__ ident, int m, int ldw,
+                                                            float *__restrict__ row_avg, float *__restrict__ row_max,
+                                                            float *__restrict__ row_min) {
+    identity_rows_body(ident, m, ldw, row_avg, row_max, row_min, (int)blockIdx.x);
+}
+
+// (two waves: one per sum.  gate != nullptr: Cleaner::selectMethod's decision is taken here as well -- *gate = 1 when it
+// selects gappyout, i.e. the similarity kernel enqueued behind this one has nothing to do; the host takes the same
+// decision from the same two numbers when they arrive)
+__device__ __forceinline__ void identity_final_body(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                    int m, float *__restrict__ out2, int *__restrict__ gate, int *__restrict__ gate_host = nullptr) {
+    __shared__ float res[2];
+    const int lane = threadIdx.x & 63;
+    const int which = uni((int)(threadIdx.x >> 6));
+    if (which < 2) {  // (the compact pipeline calls this from a workgroup of eight waves)
+        const float *src = which ? row_max : row_avg;
+        float a = 0.0f;
+        for (int base = 0; base < m; base += 256) {
+            float xa[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = base + 64 * c + lane;
+                xa[c] = t < m ? src[t] : 0.0f;
+            }
+            a = chunk_step(a, xa);
+        }
+        if (lane == 0) {
+            a = a / (float)m;
+            out2[which] = a;
+            res[which] = a;
+        }
+    }
+    __syncthreads();
+    if (gate && threadIdx.x == 0) {
+        const float avg = res[0], mx = res[1];
+        int sel;  // msah::select_method, literally
+        if (avg >= 0.55) sel = 1;
+        else if (avg <= 0.38) sel = 2;
+        else if (m <= 20) sel = 1;
+        else if (mx >= 0.5 && mx <= 0.65) sel = 1;
+        else sel = 2;
+        *gate = sel == 1 ? 1 : 0;
+        if (gate_host) *gate_host = sel == 1 ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(128) void identity_final_kernel(const float *__restrict__ row_avg, const float *__restrict__ row_max,
+                                                             int m, float *__restrict__ out2, int *__restrict__ gate) {
+    identity_final_body(row_avg, row_max, m, out2, gate);
+}
+
+// codeT -> the compacted lists of one column's valid rows (one wave per column): byte offset of the row in W (or its
+// index: `big`) and byte offset of its residue's row in the per-wave table; padded behind the last valid row with
+// {zero row m, the table's zero row}.  6 bytes per residue (round 2 also kept the row index and the code for the
+// ordered rows, which now read the column densely: 9 bytes).
+__device__ __forceinline__ void bx_compact_body(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
+                                                uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
+                                                int skiprow, int32_t *__restrict__ nvalid, int big, int bx) {
+    const int lane = threadIdx.x & 63;
+    const int col = bx * 4 + (threadIdx.x >> 6);
+    if (col >= ncols_pad) return;
+    const uint8_t *src = codeT + (size_t)col * ldk;
+    uint32_t *po = voff + (size_t)col * ldk;
+    uint16_t *pt = vtrow + (size_t)col * ldk;  // byte offset of the residue's row in a [row][64 lanes] float table
+    int count = 0;
+    for (int kb = 0; kb < m; kb += 64) {
+        const int k = kb + lane;
+        const uint32_t code = k < m ? src[k] : BX_SKIP;
+        const unsigned long long mask = __ballot(code != BX_SKIP);
+        if (code != BX_SKIP) {
+            const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            po[pos] = big ? (uint32_t)k : (uint32_t)k * ldw4;  // (big: the row index; the kernel multiplies it out)
+            pt[pos] = (uint16_t)((code >> 3) * 256u);
+        }
+        count += __builtin_popcountll(mask);
+    }
+    for (int64_t t = count + lane; t < ldk; t += 64) {
+        po[t] = big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+        pt[t] = (uint16_t)(skiprow * 256);  // the table's zero row
+    }
+    if (lane == 0) nvalid[col] = count;
+}
+__global__ __launch_bounds__(256) void bx_compact_kernel(const uint8_t *__restrict__ codeT, int64_t ldk, int m, int ncols_pad,
+                                                         uint32_t ldw4, uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow,
+                                                         int skiprow, int32_t *__restrict__ nvalid, int big) {
+    bx_compact_body(codeT, ldk, m, ncols_pad, ldw4, voff, vtrow, skiprow, nvalid, big, (int)blockIdx.x);
+}
+
+// raw bytes -> column-major codes (64 x 64 tiles through LDS); first bad residue through atomicMin as in the
+// other encode kernels.  Columns cut by the ">= 80 % gaps" rule and all padding hold BX_SKIP.
+__device__ __forceinline__ void sim_encode_cm_body(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                   const uint8_t *__restrict__ lut_g,
+                                                   const int32_t *__restrict__ gaps_w, uint8_t *__restrict__ codeT,
+                                                   int64_t ldk, int ncols_pad,
+                                                   unsigned long long *__restrict__ err_key, int bx, int by) {
+    __shared__ uint8_t lut[256];
+    __shared__ uint8_t tile[64][68];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = bx * 64 + tx;
+    bool skipcol = true;
+    if (c < n) skipcol = gaps_w ? (((float)gaps_w[c] / (float)m) >= 0.8f) : false;
+    for (int r = ty; r < 64; r += 4) {
+        const int row = by * 64 + r;
+        uint32_t code = BX_SKIP;
+        if (row < m && c < n && !skipcol) {
+            const uint32_t byte = raw[(size_t)row * ld + c];
+            code = lut[byte];  // 8 x table row, 224 = skipped, 0xFE / 0xFF = bad symbol
+            if (code >= 0xFEu) {
+                const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)row << 16) |
+                                               ((unsigned long long)(code & 1u) << 8) | byte;
+                atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
+                code = BX_SKIP;
+            }
+        }
+        tile[r][tx] = (uint8_t)code;
+    }
+    __syncthreads();
+    const int64_t k = (int64_t)by * 64 + tx;
+    for (int q = ty; q < 64; q += 4) {
+        const int col = bx * 64 + q;
+        if (col < ncols_pad && k < ldk) codeT[(size_t)col * ldk + k] = tile[tx][q];
+    }
+}
+
+__global__ __launch_bounds__(256) void sim_encode_cm_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                            const uint8_t *__restrict__ lut_g,
+                                                            const int32_t *__restrict__ gaps_w, uint8_t *__restrict__ codeT,
+                                                            int64_t ldk, int ncols_pad,
+                                                            unsigned long long *__restrict__ err_key) {
+    sim_encode_cm_body(raw, m, n, ld, lut_g, gaps_w, codeT, ldk, ncols_pad, err_key, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- batches (msa_trim_batch): the kernels above for every alignment of a shard in one launch each -- a table of BAlign
+// descriptors, a block finds its alignment by bisection over the family's prefix sums of blocks (msastat_kernels.hip) ----
+__device__ __forceinline__ BAlign batch_desc(const BAlign *table, int a) {  // wave-uniform copy: scalar loads
+    cu32p src = (cu32p)(uint64_t)(table + a);
+    uint32_t words[sizeof(BAlign) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(BAlign) / 4); ++i) words[i] = src[i];
+    BAlign d;
+    __builtin_memcpy(&d, words, sizeof(BAlign));
+    return d;
+}
+__global__ __launch_bounds__(256) void w_row_means_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    w_row_means_body(d.w, d.m, d.ldw, d.wbar, local);
+}
+__global__ __launch_bounds__(256) void identity_rows_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    if (!d.gated) return;  // (only automated1 needs the identity statistics)
+    identity_rows_body(d.ident, d.m, d.ldw, d.row_avg, d.row_max, nullptr, local);
+}
+__global__ __launch_bounds__(128) void identity_final_batch_kernel(const BAlign *__restrict__ table) {  // a block per alignment
+    const BAlign d = batch_desc(table, (int)blockIdx.x);
+    if (!d.gated) return;
+    identity_final_body(d.row_avg, d.row_max, d.m, reinterpret_cast<float *>(d.flags + 4), d.flags + 6);
+}
+__global__ __launch_bounds__(256) void sim_encode_cm_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                  const uint8_t *__restrict__ lut_g) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int nbx = d.ncols_pad / 64;
+    sim_encode_cm_body(d.raw, d.m, d.n, d.ld, lut_g, d.gaps, d.codeT, d.ldk, d.ncols_pad,
+                       reinterpret_cast<unsigned long long *>(d.flags + 2), local % nbx, local / nbx);
+}
+// ---- small alignments in a batch: one LANE per column ---------------------------------------------------------------------
+// A column of 100 rows is a dozen binade crossings and a prologue around two rounds of 64 rows: the wave-per-column kernel
+// spends 50 us on it, nearly all of it in ordered rows.  With thousands of such columns in one launch (a batch of small
+// alignments: 10^5 - 10^6 columns) the statistic as the reference writes it is the better kernel: a lane per column, the two
+// nested loops, one add after the other -- W[j][k] is the same for the 64 columns of a wave (a scalar load), their codes of
+// row k are 64 consecutive bytes of a ROW-major code array, the {distance, valid} pair comes from the LDS table; 5 VALU
+// instructions per step for 64 pairs, no prologue, no stitching, and enough waves to hide the add latency.  m * m / 2 steps per
+// wave against ~170 000 cycles of fixed cost per column.  The wave's codes are staged in LDS (64 columns x m bytes, four codes
+// to a dword), the weights of a row arrive sixteen per scalar load: up to 128 rows (msa_trim_batch picks per group).
+__global__ __launch_bounds__(256) void sim_encode_rm_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                  const uint8_t *__restrict__ lut_g) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    // a block = 256 columns x 16 rows
+    const int nbx = (int)((d.ld + 255) / 256);
+    const int c = (local % nbx) * 256 + (int)threadIdx.x, r0 = (local / nbx) * 16;
+    if (c >= d.ld) return;
+    const bool skipcol = c >= d.n || (((float)d.gaps[c] / (float)d.m) >= 0.8f);
+    for (int r = r0; r < min(d.m, r0 + 16); ++r) {
+        uint32_t code = BX_SKIP;
+        if (!skipcol) {
+            const uint32_t byte = d.raw[(size_t)r * d.ld + c];
+            code = lut[byte];
+            if (code >= 0xFEu) {
+                const unsigned long long key = ((unsigned long long)c << 40) | ((unsigned long long)r << 16) |
+                                               ((unsigned long long)(code & 1u) << 8) | byte;
+                atomicMax(reinterpret_cast<unsigned long long *>(d.flags + 2), ~key);
+                code = BX_SKIP;
+            }
+        }
+        d.codeR[(size_t)r * d.ld + c] = (uint8_t)code;
+    }
+}
+
+constexpr int COLS_MAX_M = 128;  // rows of an alignment the lane-per-column kernel takes (its code tiles live in LDS)
+__global__ __launch_bounds__(256) void similarity_cols_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                                    int total, const float *__restrict__ tab_g) {
+    __shared__ f2 tab[32 * 32];  // {distance, both valid}[row code][column code], rows 28.. zero
+    // the wave's 64 columns x m codes, [lane][k] packed four to a dword; 33 dwords per lane: lanes on different banks
+    __shared__ uint32_t tile[4][64][COLS_MAX_M / 4 + 1];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
+        f2 v = {0.0f, 0.0f};
+        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
+        tab[i] = v;
+    }
+    __syncthreads();
+    const ldsp tabp = (ldsp)(const __attribute__((address_space(3))) void *)tab;
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const int item = (int)blockIdx.x * 4 + wave;  // a wave = 64 columns of one alignment
+    if (item >= total) return;
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, item, local));
+    if (d.gated && d.flags[6]) return;  // (selectMethod took gappyout on the device)
+    const int c = local * 64 + lane, m = d.m;
+    const bool in = c < d.n;
+    const int64_t ld = d.ld;
+    const gu8p code = (gu8p)(uint64_t)(d.codeR + (in ? c : 0));
+    uint32_t *mine = tile[wave][lane];
+    for (int k4 = 0; k4 < COLS_MAX_M / 4 + 1; ++k4) {  // (rows behind m: codes that take no part)
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * k4 + i;
+            const uint32_t ck = (in && k < m) ? (uint32_t)code[(size_t)k * ld] : BX_SKIP;
+            packed |= ck << (8 * i);
+        }
+        mine[k4] = packed;
+    }
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) f16v *c16;
+    float num = 0.0f, den = 0.0f;
+    for (int j = 0; j + 1 < m; ++j) {
+        const uint32_t cj = (mine[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (cj == BX_SKIP) continue;
+        const float *wr = d.w + (size_t)j * d.ldw;  // the row's weights: the same for every column (scalar loads, 16 at a time)
+        const ldsp row = tabp + (cj << 5);
+        // (chunks of 16 partners from the one that holds row j + 1: W[j][k <= j] = 0, the upper triangle is strict, and a
+        // product with it adds +0 to either sum)
+        for (int kb = (j + 1) & ~15; kb < m; kb += 16) {
+            const f16v w = *(c16)(uint64_t)(wr + kb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c4 = mine[(kb >> 2) + q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t ck = (c4 >> (8 * i)) & 0xFFu;
+                    const f2 de = *reinterpret_cast<const __attribute__((address_space(3))) f2 *>(row + ck);
+                    const float wk = w[4 * q + i];
+                    const float x = wk * de.x, y = wk * de.y;
+                    num = num + x;
+                    den = den + y;
+                }
+            }
+        }
+    }
+    if (in) {
+        d.simnum[c] = num;
+        d.simden[c] = den;
+    }
+}
+
+__global__ __launch_bounds__(256) void bx_compact_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K,
+                                                               int skiprow, int big) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    bx_compact_body(d.codeT, d.ldk, d.m, d.ncols_pad, (uint32_t)d.ldw * 4u, d.off, d.trow, skiprow, d.nvalid, big, local);
+}
+
+
+// ---- small alignments, one at a time: the FLAT similarity kernel ---------------------------------------------------------
+// The binade-exact kernel above spends ~35 us on a column of 46 rows and ~100 us on one of 200: a prologue, a predictor,
+// ordered rows at every binade crossing -- fixed costs that m^2 / 2 terms per column repay only from a few hundred rows on.
+// Below that the terms of a column are few enough to be taken as ONE sequence: the pairs (j, k > j) of the column's valid
+// rows in the reference's order, 64 U at a time through scan_lanes (flat_add_run).  Its valid rows (index, code) are compacted into LDS from the
+// column-major codes; W[j][k] a gather from the (L2-resident) upper triangle; the distance from the LDS table.  No lists, no
+// predictor, no per-row state.  Two waves per column (one per sum); the numerator's wave writes MDK and Q itself (mdk_value).
+constexpr int FLAT_ROWS_MAX = 512;
+template <int U>
+__global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const float *__restrict__ tab_g) {
+    __shared__ f2 tab[32 * 32];                    // {distance, both valid}[row code][column code], rows 28.. zero
+    __shared__ uint32_t rows[4][FLAT_ROWS_MAX];    // per wave: the column's valid rows, index | table row << 16
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
+        f2 v = {0.0f, 0.0f};
+        if (i < 29 * 32) v = reinterpret_cast<const f2 *>(tab_g)[i];
+        tab[i] = v;
+    }
+    __syncthreads();
+    // TWO waves per column, one per sum: the chains are independent, and a lone wave on its SIMD issues an instruction of a
+    // dependent chain every ten cycles or so -- a second wave costs the walk over the pairs twice and still halves the time
+    __shared__ float sums[4];
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+    const int col = (int)blockIdx.x * 2 + (wave >> 1);
+    const bool denominator = (wave & 1) != 0;
+    // (automated1: selectMethod may have taken gappyout on the device)
+    const bool active = col < A.n && !(A.gate && *A.gate);
+    float sum = 0.0f;
+    if (active) {
+    const int m = A.m;
+    uint32_t *mine = rows[wave];
+    const gu8p code = (gu8p)(uint64_t)(A.codeT + (size_t)col * A.ldk);
+    int nv = 0;
+    for (int kb = 0; kb < m; kb += 64) {
+        const int k = kb + lane;
+        const uint32_t ck = k < m ? (uint32_t)code[k] : BX_SKIP;
+        const unsigned long long mask = __ballot(ck != BX_SKIP);
+        if (ck != BX_SKIP) mine[nv + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)k | ((ck >> 3) << 16);
+        nv += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int T = nv * (nv - 1) / 2;  // pairs (a < b) of list positions, lexicographic: row a holds the nv - 1 - a pairs (a, b > a)
+    const gf32p wup = (gf32p)(uint64_t)A.wup;
+    const int ldw = A.ldw;
+    // U CONSECUTIVE terms per lane and pass (one run of 64 U terms through flat_add_run: one scan per pass -- with four terms per
+    // lane, what rounds 4 shipped, a column of 200 rows was 78 scans per sum), requested a pass ahead: with two waves per SIMD
+    // (two per column, ~1000 columns) nothing else hides the gather's latency.
+    int rt = U * lane;  // the lane's first term of the next pass
+    const float fn = (float)(2 * nv - 1);
+    auto request = [&](float (&w)[U], uint32_t (&ti)[U]) {
+        uint32_t ea[U], eb[U];
+        {
+            // the lane's first term of the pass -> (row a, place p): the largest a with a nv - a (a + 1) / 2 <= t, from the root
+            // of an exact integer below 2^24 (two corrections cover a root that is off by an ulp); its neighbours by a carry
+            // into the next row.  Straight-line code: the gathers below leave back to back.  Terms behind the last one
+            // read the last one's operands and count as zero (the caller masks them).
+            const int t0 = rt;
+            const int t = t0 < T ? t0 : T - 1;
+            int a = (int)((fn - sqrtf(fn * fn - 8.0f * (float)t)) * 0.5f);
+            a = a > nv - 2 ? nv - 2 : a;
+            a -= (a * nv - a * (a + 1) / 2 > t) ? 1 : 0;
+            a += (a + 1 <= nv - 2 && (a + 1) * nv - (a + 1) * (a + 2) / 2 <= t) ? 1 : 0;
+            int pl = t - (a * nv - a * (a + 1) / 2);
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                ea[i] = mine[a], eb[i] = mine[a + 1 + pl];
+                const bool adv = t0 + i + 1 < T, wrap = pl + 1 >= nv - 1 - a;
+                a += (adv && wrap) ? 1 : 0;
+                pl = adv ? (wrap ? 0 : pl + 1) : pl;
+            }
+        }
+        rt += 64 * U;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            w[i] = wup[(size_t)(ea[i] & 0xFFFFu) * ldw + (eb[i] & 0xFFFFu)];
+            ti[i] = (ea[i] >> 16) * 32 + (eb[i] >> 16);
+        }
+    };
+    if (T > 0) {
+        float w[U];
+        uint32_t ti[U];
+        request(w, ti);
+        for (int t0 = 0; t0 < T; t0 += 64 * U) {
+            float wn[U];
+            uint32_t tn[U];
+            if (t0 + 64 * U < T) request(wn, tn);
+            float x[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                if (t0 + U * lane + i >= T) w[i] = 0.0f;
+                const float d = tab[ti[i]].x;  // (both waves read it: no branch around the LDS loads)
+                x[i] = denominator ? w[i] : w[i] * d;
+            }
+            sum = flat_add_run<U>(sum, x, lane);
+#pragma unroll
+            for (int i = 0; i < U; ++i) w[i] = wn[i], ti[i] = tn[i];
+        }
+    }
+    }
+    if (lane == 0) sums[wave] = sum;
+    __syncthreads();
+    if (active && !denominator && lane == 0) {
+        const float sn = sums[wave], sd = sums[wave + 1];
+        if (A.num_out) A.num_out[col] = sn, A.den_out[col] = sd;
+        float q;
+        A.mdk_out[col] = mdk_value(sn, sd, false, A.mdk_host, q);
+        A.q_out[col] = q;
+    }
+}
+
+// ---- the compact pipeline of a small alignment (CompactArgs, msastat_kernels.h) -------------------------------------------
+// Front kernel, one launch for everything that reads the rows.  Blocks by role:
+//   * a COLUMN block owns 64 columns over all rows, read once (64 consecutive bytes of a row per wave and load): their gap and
+//     indetermination counts (plain stores: no atomics, hence no memset), the bit planes of the pair pass (a thread per row on
+//     the 64 x 64 tile in LDS: planes_of_row), and -- the ">= 80 % gaps" cut follows from the block's own counts -- the
+//     column-major codes and the compacted lists.  The block's codes live in LDS ([column][row] bytes) between the pass over
+//     the rows and the pass that writes them out: nothing is read back from memory.  A bad residue counts only in a column
+//     that is not cut: the first bad row of every column by an LDS minimum, the block's first bad residue and its non-ASCII
+//     verdict into the block's own slots;
+//   * a ROW block: the residues of four sequences (row_nongap_body).
+// Block 0 zeroes the device's flag words, the identity statistics' ticket and the pair pass's row sums (nothing of this launch
+// touches them).  Results go to the state block's mirror in pinned host memory as well (`hres`: same offsets; the rows' totals,
+// the slots, MDK and Q only there): no copy back, the host folds the slots into the two flag words after the wait.
+constexpr int COMPACT_ROWS_MAX = 512;  // rows of the LDS code array of a column block
+constexpr int COMPACT_TEAMS_MAX = 4;  // 64-row tiles a column block works on at once (a team of four waves each)
+template <bool SIM>
+__device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b) {
+    constexpr int LDC = COMPACT_ROWS_MAX + 4;  // bytes per column (4 past a multiple of 128: consecutive columns on different banks)
+    constexpr int TM = COMPACT_TEAMS_MAX;
+    __shared__ uint8_t lut[256];
+    __shared__ uint8_t codes[SIM ? 64 * LDC : 4];
+    __shared__ uint32_t rawt[SIM ? TM * 64 * 17 : 1];  // per team a tile's bytes, [row][64 columns + 4]
+    __shared__ uint32_t cnt[2][4 * TM][64];
+    __shared__ uint32_t firstbad[64];
+    __shared__ uint8_t skipc[64];
+    __shared__ int anybad;
+    // The workgroup is `teams` teams of four waves; team t takes the tiles t, t + teams, ...: a tile is a chain of small
+    // latencies (loads, LDS, two barriers), and a column block of 500 rows that walked its eight tiles one after the other
+    // took 58 us where the whole alignment's pair pass takes 18.
+    const int teams = (int)(blockDim.x >> 8), team = (int)(threadIdx.x >> 8), tid = (int)(threadIdx.x & 255);
+    const int tx = threadIdx.x & 63, ty = tid >> 6, wave = (int)(threadIdx.x >> 6), nwaves = 4 * teams;
+    const int m = a.m, n = a.n;
+    const int64_t ld = a.ld, ldk = a.ldk;
+    const int c = b * 64 + tx;
+    const bool inb = c < n;
+    uint8_t lutbyte = 0;
+    if (SIM) {
+        if (threadIdx.x < 256) lutbyte = a.lut[threadIdx.x];  // (requested with the first tile's rows; stored behind them)
+        if (threadIdx.x < 64) firstbad[threadIdx.x] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) anybad = 0;
+    }
+    const uint32_t indet = a.indet4 & 0xFFu;
+    const uint8_t *col0 = a.raw + (inb ? c : 0);
+    const int mtiles = (m + 63) / 64, passes = (mtiles + teams - 1) / teams;
+    uint32_t g = 0, x = 0;
+    uint32_t next[16];  // (sixteen rows requested before the first is looked at, and a pass ahead of the one being worked on)
+    auto request = [&](int by) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = by * 64 + ty + 4 * i;
+            next[i] = (row < m && inb) ? (uint32_t)col0[(size_t)row * ld] : 0x100u;  // 0x100: outside, counts as nothing
+        }
+    };
+    request(team);
+    uint32_t *myraw = rawt + (SIM ? team * 64 * 17 : 0);
+    for (int ps = 0; ps < passes; ++ps) {
+        const int by = ps * teams + team;  // (a team without a tile in the last pass walks rows behind m: nothing counts)
+        uint32_t bytes[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bytes[i] = next[i];
+        if (ps + 1 < passes) request(by + teams);
+        if (SIM && ps == 0) {
+            if (threadIdx.x < 256) lut[threadIdx.x] = lutbyte;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t byte = bytes[i];
+            g += byte == (uint32_t)'-';
+            x += byte == indet;
+            if (SIM) {
+                const int row = by * 64 + ty + 4 * i;
+                uint32_t code = BX_SKIP;
+                if (byte < 0x100u) {
+                    code = lut[byte];  // 8 x table row, 224 = skipped, 0xFE / 0xFF = bad symbol
+                    if (code >= 0xFEu) {
+                        atomicMin(&firstbad[tx], ((uint32_t)row << 16) | ((code & 1u) << 8) | byte);
+                        code = BX_SKIP;
+                    }
+                }
+                if (row < mtiles * 64) codes[tx * LDC + row] = (uint8_t)code;
+                reinterpret_cast<uint8_t *>(myraw)[(ty + 4 * i) * 68 + tx] = (uint8_t)(byte < 0x100u ? byte : (uint32_t)'-');
+            }
+        }
+        if (SIM) {
+            __syncthreads();
+            {  // four threads per row of the team's tile, 16 columns each: the row's two chunk words of every plane
+                const int r = tid >> 2, q = tid & 3;
+                const int row = by * 64 + r;
+                uint32_t o[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) o[p] = 0;
+                uint32_t bad = 0;
+                if (row < m) bad = planes_of_quarter(myraw + r * 17 + q * 4, b * 64 + q * 16, n, a.indet4, o);
+                const int chunk = b * 2 + (q >> 1);
+                const size_t pstride = (size_t)a.nchunk * a.m_pad;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    uint32_t v = o[p] << ((q & 1) * 16);
+                    v |= (uint32_t)__shfl_xor((int)v, 1, 64);  // (the other half of the chunk word: the neighbouring lane)
+                    if ((q & 1) == 0 && row < a.m_pad && chunk < a.nchunk) a.planes[p * pstride + (size_t)chunk * a.m_pad + row] = v;
+                }
+                if (bad) anybad = 1;
+            }
+            __syncthreads();
+        }
+    }
+    if (SIM && wave == 1) {  // the rows between the last pass and m_pad: zero in every plane
+        const uint32_t zero[2][8] = {};
+        for (int row = passes * teams * 64 + tx; row < a.m_pad; row += 64) planes_store(a.planes, a.nchunk, a.m_pad, b, row, zero);
+    }
+    cnt[0][wave][tx] = g;
+    cnt[1][wave][tx] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t G = 0, X = 0;
+        for (int w = 0; w < nwaves; ++w) G += cnt[0][w][tx], X += cnt[1][w][tx];
+        if (inb) {
+            a.gaps[c] = (int32_t)G;
+            a.indets[c] = (int32_t)X;
+            a.hres[a.h_gaps + c] = (int32_t)G;
+            a.hres[a.h_indets + c] = (int32_t)X;
+        }
+        if (SIM) {
+            const bool skip = !inb || (((float)(int32_t)G / (float)m) >= 0.8f);
+            skipc[tx] = skip ? 1 : 0;
+            // the block's first bad residue: smallest column, then smallest row -- the key of sim_encode_cm, complemented
+            unsigned long long key = ~0ull;
+            if (!skip && firstbad[tx] != 0xFFFFFFFFu) key = ((unsigned long long)c << 40) | firstbad[tx];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = other < key ? other : key;
+            }
+            if (tx == 0) {
+                key = key == ~0ull ? 0ull : ~key;
+                a.hres[a.h_slots + 2 * b] = (int32_t)(uint32_t)key;
+                a.hres[a.h_slots + 2 * b + 1] = (int32_t)(uint32_t)(key >> 32);
+                a.hres[a.h_slots + 2 * (a.ncols_pad / 64) + b] = anybad;
+            }
+        }
+    }
+    if (SIM) {
+        __syncthreads();
+        // a wave per column, lane = row: the codes (coalesced) and the compacted lists, as sim_encode_cm and bx_compact write them
+        const int lane = tx;
+        const uint32_t ldw4 = (uint32_t)a.ldw * 4u;
+        for (int q = wave; q < 64; q += nwaves) {
+            const size_t col = (size_t)b * 64 + q;
+            const bool skip = skipc[q] != 0;
+            uint8_t *ct = a.codeT + col * ldk;
+            uint32_t *po = a.voff + col * ldk;
+            uint16_t *pt = a.vtrow + col * ldk;
+            int count = 0;
+            for (int kb = 0; kb < mtiles * 64; kb += 64) {
+                const int k = kb + lane;
+                const uint32_t code = (k < m && !skip) ? (uint32_t)codes[q * LDC + k] : BX_SKIP;
+                ct[k] = (uint8_t)code;
+                if (!a.lists) continue;  // (the flat similarity kernel reads the codes alone)
+                const unsigned long long mask = __ballot(code != BX_SKIP);
+                if (code != BX_SKIP) {
+                    const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    po[pos] = a.big ? (uint32_t)k : (uint32_t)k * ldw4;
+                    pt[pos] = (uint16_t)((code >> 3) * 256u);
+                }
+                count += __builtin_popcountll(mask);
+            }
+            if (!a.lists) continue;
+            for (int64_t k = (int64_t)mtiles * 64 + lane; k < ldk; k += 64) ct[k] = (uint8_t)BX_SKIP;
+            for (int64_t t = count + lane; t < ldk; t += 64) {
+                po[t] = a.big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+                pt[t] = (uint16_t)(a.skiprow * 256);               // the table's zero row
+            }
+            if (lane == 0) a.nvalid[col] = count;
+        }
+    }
+}
+template <bool SIM>
+__global__ __launch_bounds__(256 * COMPACT_TEAMS_MAX) void compact_front_kernel(CompactArgs a) {
+    const int b = (int)blockIdx.x;
+    const int ncb = a.ncols_pad / 64;
+    if (b == 0) {
+        if (threadIdx.x < 32) a.flags[threadIdx.x] = 0;
+        if (SIM) {
+            if (threadIdx.x == 0) a.scratch[0] = 0;  // the ticket of the identity statistics
+            for (int i = threadIdx.x; i < a.m_pad + 64; i += (int)blockDim.x) a.wsum[i] = 0u;
+        }
+    }
+    if (b < ncb) compact_column_block<SIM>(a, b);
+    else if (threadIdx.x < 256) row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
+}
+
+// automated1: the identity statistics -- a wave per sequence (identity_rows_body), and in the workgroup that finishes last (a
+// ticket) the two means and Cleaner::selectMethod's decision (identity_final_body): one launch for the ordinary path's two.
+__global__ __launch_bounds__(256) void compact_identity_kernel(CompactArgs a) {
+    identity_rows_body(a.ident, a.m, a.ldw, a.row_avg, a.row_max, nullptr, (int)blockIdx.x);
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // (release: the workgroup's four rows, device-wide -- its waves' stores are complete behind the barrier)
+        last = atomicAdd(a.scratch, 1) == (int)gridDim.x - 1;
+        __threadfence();  // (acquire)
+    }
+    __syncthreads();
+    if (!last) return;
+    identity_final_body(a.row_avg, a.row_max, a.m, reinterpret_cast<float *>(a.hres + 4), a.flags + 6, a.hres + 6);
+}
+
+}  // namespace
+
+
+// leading dimension of the per-column lists: the valid rows, then >= 192 padding entries (a block of the ordered
+// path, two prefetched groups of the round loop)
+int64_t bx_ldk(int m) { return ((int64_t)m + 63) / 64 * 64 + 256; }  // (the ordered path reads up to 191 entries past the last valid one, the round loops up to 63)
+int bx_cols_pad(int n) { return (n + 1 + 63) / 64 * 64; }  // at least one all-skipped column behind the last one
+size_t bx_wlow_rows(int m) { return (size_t)m + 2; }         // row m: zeros (the padding entries of the lists point there)
+
+void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut,
+                          const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key) {
+    const int64_t ldk = bx_ldk(m);
+    const int ncp = bx_cols_pad(n);
+    dim3 grid((unsigned)(ncp / 64), (unsigned)(ldk / 64));
+    sim_encode_cm_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codeT, ldk, ncp, err_key);
+}
+
+void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vtrow,
+                       int32_t *nvalid) {
+    const int ncp = bx_cols_pad(n);
+    bx_compact_kernel<<<(ncp + 3) / 4, 256, 0, s>>>(codeT, bx_ldk(m), m, ncp, (uint32_t)ldw * 4u, voff, vtrow, npos, nvalid,
+                                                    lg_big(m, ldw) ? 1 : 0);
+}
+
+void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) w_row_means_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) identity_rows_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+    if (K > 0) identity_final_batch_kernel<<<K, 128, 0, s>>>(table);
+}
+void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, const uint8_t *lut) {
+    if (blocks > 0) sim_encode_rm_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K, lut);
+}
+// prefix: 64-column groups per alignment; total = their number
+void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab) {
+    if (total > 0) similarity_cols_batch_kernel<<<(total + 3) / 4, 256, 0, s>>>(table, prefix, K, total, static_cast<const float *>(tab));
+    launch_note() = LaunchNote{5, 0, 1, 0, launch_note().pair_kind, launch_note().pair_waves};
+}
+void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *prefix_encode, int blocks_encode, const int32_t *prefix_compact,
+                            int blocks_compact, int K, const uint8_t *lut, int npos) {
+    if (blocks_encode > 0) sim_encode_cm_batch_kernel<<<blocks_encode, 256, 0, s>>>(table, prefix_encode, K, lut);
+    if (blocks_compact > 0) bx_compact_batch_kernel<<<blocks_compact, 256, 0, s>>>(table, prefix_compact, K, npos, tuning().lg_big != 0 ? 1 : 0);
+}
+
+
+// words of the slots behind the state block's mirror: a first-bad-residue key (two words) and a non-ASCII word per column block
+size_t compact_slot_words(int n) { return (size_t)3 * (bx_cols_pad(n) / 64) + 2; }
+size_t compact_scratch_words(int m, int n) { return (size_t)2 + (std::max(m, 1) + 127) / 128 * 128 + 64 + 8; }
+void launch_compact_front(hipStream_t s, const CompactArgs &a) {
+    const unsigned blocks = (unsigned)(a.ncols_pad / 64 + (a.m + 3) / 4);
+    const int teams = std::min(COMPACT_TEAMS_MAX, std::max(1, (a.m + 63) / 64));  // a team of four waves per 64-row tile, up to four
+    if (a.sim) compact_front_kernel<true><<<blocks, 256 * teams, 0, s>>>(a);
+    else compact_front_kernel<false><<<blocks, 256 * teams, 0, s>>>(a);
+}
+// the flat similarity kernel: any alignment of up to FLAT_ROWS_MAX rows whose codes exist (A.codeT, A.wup, A.mdk_out, A.q_out)
+int flat_rows_max() { return FLAT_ROWS_MAX; }
+void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab) {
+    // terms per lane and scan: eight, sixteen from ~110 sequences on (profiles/r05_flat_sweep.jsonl: four, what round 4 shipped, is 12 %
+    // behind at 128 sequences and 25 % at 256; MSA_FLAT_U forces 4, 8 or 16: tools/flat_sweep.py)
+    const int forced = tuning().flat_u;
+    const int u = forced ? forced : (one.m >= 112 ? 16 : 8);
+    const unsigned grid = (unsigned)((one.n + 1) / 2);
+    const float *t = static_cast<const float *>(tab);
+    if (one.n > 0) {
+        if (u >= 16) similarity_flat_kernel<16><<<grid, 256, 0, s>>>(one, t);
+        else if (u >= 8) similarity_flat_kernel<8><<<grid, 256, 0, s>>>(one, t);
+        else similarity_flat_kernel<4><<<grid, 256, 0, s>>>(one, t);
+    }
+    LaunchNote &note = launch_note();
+    note.sim_kind = 1, note.lg_split = 0, note.lg_launches = 1, note.lg_fin = 1;
+}
+void launch_compact_identity(hipStream_t s, const CompactArgs &a) {
+    compact_identity_kernel<<<(unsigned)((a.m + 3) / 4), 256, 0, s>>>(a);
+}
+
+// mean weight of every row over its later partners (m + 64 floats): the similarity kernel's predictor reads it
+void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar) {
+    w_row_means_kernel<<<(m + 64 + 3) / 4, 256, 0, s>>>(wup, m, ldw, wbar);
+}
+
+void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max, float *out2,
+                           float *row_min, int *gate) {
+    identity_rows_kernel<<<(m + 3) / 4, 256, 0, s>>>(ident, m, ldw, row_avg, row_max, row_min);
+    identity_final_kernel<<<1, 128, 0, s>>>(row_avg, row_max, m, out2, gate);
+}
+
+}  // namespace msak

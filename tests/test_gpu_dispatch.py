@@ -5,7 +5,7 @@ the table below pins, shape by shape on both sides of every size threshold, the 
 threshold in pytrimal_amd/csrc fails this file until the table is updated with it.
 
 Thresholds covered (DESIGN.md section 11 lists them): rows read in place up to 96 KB; flat similarity kernel up to 128 rows
-(64 beyond 2560 columns: both waves of every column resident); compact pipeline up to 512 rows and 5120 columns; side stream
+(96 beyond 2560 columns: both waves of every column resident); compact pipeline up to 512 rows and 5120 columns; side stream
 from m^2 n = 2 * 10^9; a launch every six rounds from 1800 rows; a workgroup per column from 2048 rows when the columns leave
 wave slots free; front kernel alone for gap-only trims up to 1024 rows and 4 MB; two rows per lane in the pair pass from 4096 rows."""
 import numpy as np
@@ -18,7 +18,7 @@ from pytrimal_amd.synth import synth_msa
 pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
-                "MSA_UPLOAD_DIRECT", "MSA_UPLOAD_PIECE_KB", "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB",
+                "MSA_UPLOAD_DIRECT", "MSA_UPLOAD_PIECE_KB", "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
                 "MSA_DEVICE_CLUSTERS", "MSA_TRACE")
 
 
@@ -52,9 +52,10 @@ LG1 = dict(sim_kernel="lg", sim_waves_per_column=1)
 STRICT = [
     # --- flat kernel <-> wave-per-column kernel inside the compact pipeline
     (64, 300, dict(upload="in_place", pipeline="compact", sim_kernel="flat", sim_writes_mdk=1, sim_launches=1)),
-    (64, 5000, dict(upload="packed", pipeline="compact", sim_kernel="flat")),       # up to 64 rows: flat at any column count
-    (65, 2560, dict(upload="linear", pipeline="compact", sim_kernel="flat")),       # 65 .. 128 rows: flat while n <= cus * 10
-    (65, 2561, dict(upload="packed", pipeline="compact", sim_writes_mdk=1, sim_launches=1, **LG1)),
+    (64, 5000, dict(upload="packed", pipeline="compact", sim_kernel="flat")),
+    (96, 2561, dict(upload="packed", pipeline="compact", sim_kernel="flat")),       # up to 96 rows: flat at any column count
+    (97, 2560, dict(upload="linear", pipeline="compact", sim_kernel="flat")),       # 97 .. 128 rows: flat while n <= cus * 10
+    (97, 2561, dict(upload="packed", pipeline="compact", sim_writes_mdk=1, sim_launches=1, **LG1)),
     (127, 600, dict(upload="in_place", pipeline="compact", sim_kernel="flat")),
     (128, 600, dict(upload="in_place", pipeline="compact", sim_kernel="flat")),
     (129, 600, dict(upload="in_place", pipeline="compact", sim_writes_mdk=1, **LG1)),

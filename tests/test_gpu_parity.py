@@ -35,7 +35,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT",
-                     "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB"):
+                     "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -406,11 +406,13 @@ def _sim_parity(ctx, a, indet=ord("X")):
 # lg-split-S: S waves of a workgroup share one column, each on a segment of every round's partner list (what the launcher
 # picks by itself for tall alignments: fewer columns than wave slots); the increment pairs of the segments compose exactly
 # (the default path of a small alignment is the compact pipeline -- three launches -- with the flat similarity kernel up to 128
-# rows and the wave-per-column kernel from there to 512; MSA_COMPACT=0 is the ordinary launch sequence at every size)
-KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLAT_MAX_M="512"), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"),
+# rows and the wave-per-column kernel from there to 512; MSA_COMPACT=0 is the ordinary launch sequence at every size; MSA_FLAT_U:
+# terms per lane and scan of the flat kernel, by itself 8 below 112 rows and 16 from there on)
+KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLAT_MAX_M="512"), dict(MSA_FLAT_MAX_M="512", MSA_FLAT_U="4"),
+           dict(MSA_FLAT_MAX_M="512", MSA_FLAT_U="8"), dict(MSA_FLAT_MAX_M="512", MSA_FLAT_U="16"), dict(MSA_LG_BIG="1"), dict(MSA_LG_ROUNDS="1"),
            dict(MSA_LG_SPLIT="2"), dict(MSA_LG_SPLIT="4", MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="8"), dict(MSA_LG_SPLIT="16", MSA_LG_BIG="1"),
            dict(MSA_SIM_KERNEL="seq")]
-KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
+KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "compact-flat-512-u4", "compact-flat-512-u8", "compact-flat-512-u16", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
               "lg-split-16-big", "seq"]
 
 

@@ -9,13 +9,19 @@ from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
 from pytrimal_amd.synth import synth_msa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
-for m in (8, 16, 32, 46, 64, 80, 100, 128, 160, 200, 256, 320):
+for m in (8, 16, 32, 46, 64, 80, 100, 128, 160, 200, 256, 320, 400, 512):
     a = synth_msa(m, n, 77 + m)
     ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
     tr = AutomaticTrimmer("strict", platform="hip")
     rec = {"m": m, "n": n}
-    for name, flat in (("flat_ms", "512"), ("wave_per_column_ms", "0")):
+    variants = [("flat_ms", "512", None), ("wave_per_column_ms", "0", None)]
+    if os.environ.get("FLAT_U_SWEEP"):  # terms per lane and scan of the flat kernel: 4 (rounds 4), 8, 16
+        variants = [(f"flat_u{u}_ms", "512", str(u)) for u in (4, 8, 16)] + [("wave_per_column_ms", "0", None)]
+    for name, flat, u in variants:
         os.environ["MSA_FLAT_MAX_M"] = flat
+        os.environ.pop("MSA_FLAT_U", None)
+        if u:
+            os.environ["MSA_FLAT_U"] = u
         _lib.reset_thread_context()  # (the library reads the switches when a context is created)
         for _ in range(5):
             tr.trim(ali)
