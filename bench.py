@@ -53,7 +53,9 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 -> L1 bandwidth figur
 def similarity_w_stream_bytes(a, indet=ord("X")):
     """Bytes of W the similarity kernel moves through the vector-memory pipeline in one launch (one 256-byte row per
     partner step), computed from the alignment: per evaluated column and 64-row round, the valid rows at or behind
-    the round's first row, rounded to the 32-step granularity of the round loop."""
+    the round's first row, in the round loop's blocks of 16 steps (the list is entered at a multiple of 16; nothing is
+    requested behind a round's last block -- through round 4: blocks of 32, and 16 - 32 more loads of padding per round,
+    which this count never included)."""
     m, n = a.shape
     valid = (a != ord("-")) & (a != indet)
     nvalid = valid.sum(axis=0)
@@ -63,9 +65,40 @@ def similarity_w_stream_bytes(a, indet=ord("X")):
     for j0 in range(0, m - 1, 64):
         todo = nvalid - before
         live = active & (todo > 0)
-        steps += int((((todo[live] + (before[live] & 15) + 31) // 32) * 32).sum())
+        steps += int((((todo[live] + (before[live] & 15) + 15) // 16) * 16).sum())
         before = before + valid[j0:j0 + 64].sum(axis=0)
     return steps * 256, steps
+
+
+def similarity_kernel_clock(a, vhash, dist):
+    """The shader clock the similarity kernel runs at, GHz: one pass of the STAMPED kernel (MSA_SIM_MODE=64, a context of its own,
+    behind every timed region) -- its waves' cycle counts (s_memtime) over their lifetimes in 100 MHz ticks (s_memrealtime).  A
+    box whose chip clocks this kernel at 1.86 instead of 2.1 GHz explains most of a box-to-box difference of `value`."""
+    from pytrimal_amd import _lib
+
+    lib = _lib.load()
+    lib.msa_debug_bx_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    saved = {k: os.environ.get(k) for k in ("MSA_SIM_MODE",)}
+    os.environ["MSA_SIM_MODE"] = "64"
+    try:
+        c = _lib.Context(0 if "LOCAL_RANK" not in os.environ else int(os.environ["LOCAL_RANK"]))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        buf = (ctypes.c_ulonglong * 16)()
+        c.upload(a, ord("X"))
+        c.similarity(vhash, dist)
+        lib.msa_debug_bx_stamps(buf, 1)
+        c.upload(a, ord("X"))
+        c.similarity(vhash, dist)
+        lib.msa_debug_bx_stamps(buf, 1)
+    finally:
+        c.close()
+    return round((buf[0] + buf[1] + buf[2]) / max(buf[6], 1) / 10, 3) if buf[6] else None
 
 
 WORKLOADS = {
@@ -391,7 +424,7 @@ def main():
     ctx = _lib.Context(local_rank)
     params = params_for(args.workload)
     kernels, resident_s, public_api_s, info, units_per_step, single_gpu_s = {}, None, None, None, None, None
-    pageable_s, cold_s, ranks_seen = None, None, world
+    locked_s, cold_s, ranks_seen, region_ms, sim_clock = None, None, world, None, None
     if dist is not None:  # the ranks that really take part in the timed process group
         t = torch.ones(1, dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t)
@@ -470,11 +503,13 @@ def main():
             finish(keep_res)
             return keep_res, keep_seq, info
 
-        def step_host_rows():
-            # host rows -> device: the rows are page-locked on the first call (msa_host_register, once per array: the same
-            # alignment is trimmed step after step), every upload is then one pitched DMA copy from where they lie
-            # ... enqueued without a wait of its own: the trim behind it waits for the stream once (`a` outlives the step)
-            ctx.upload(a, ord("X"), pin=True, wait=False)
+        def step_host_rows(rows=a, pin=False):
+            # host rows -> device: ordinary (pageable) rows, as a numpy array holds them -- nothing registered, nothing staged by
+            # the caller; the upload is enqueued without a wait of its own: the trim behind it waits for the stream once (the
+            # rows outlive the step).  (Until round 4 the headline page-locked the rows once, in front of the timed steps; at
+            # this size that no longer buys anything -- round 4: 3.395 against 3.352 ms -- and is now the number BESIDE the
+            # headline: value_page_locked_rows.)
+            ctx.upload(rows, ord("X"), pin=pin, wait=False)
             keep_res, keep_seq, info = ctx.trim(params)
             finish(keep_res)
             return keep_res, keep_seq, info
@@ -504,6 +539,16 @@ def main():
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         ctx.prof_enable(False)
+        # four more regions of the same K steps, same fences: the median of the five says how much of `value` is the box's mood
+        # (a region is 0.07 s at --steps 20, the clock is still ramping in the first)
+        region_ms = [elapsed / args.steps * 1e3]
+        for _ in range(4):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_host_rows()
+            fence()
+            region_ms.append(max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
         for name in ("pairs", "sim"):
             ms, launches = ctx.prof_get(name)
             if launches:
@@ -533,19 +578,17 @@ def main():
         public_api_s = max_over_ranks(time.perf_counter() - t0)
         assert np.array_equal(api_masks._res_mask, keep_res) and np.array_equal(api_masks._seq_mask, keep_seq)
         kept = int(info.kept_residues)
-        # ... from PAGEABLE rows (a copy of the alignment that was never page-locked: what a load-then-trim-once pipeline hands
-        # over), and COLD: the first trim of a fresh Alignment through the public API (pageable rows, a context that last saw
+        # ... from PAGE-LOCKED rows (a copy of the alignment registered once, in front of its timed steps: every upload is then one
+        # pitched DMA copy from where the rows lie), and COLD: the first trim of a fresh Alignment through the public API (pageable rows, a context that last saw
         # another alignment), one fresh object per sample
-        pageable = a.copy()
-        ctx.upload(pageable, ord("X"), pin=False, wait=False)
-        ctx.trim(params)
+        locked = a.copy()
+        step_host_rows(locked, pin=True)  # (registered here: msa_host_register, once per array)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            ctx.upload(pageable, ord("X"), pin=False, wait=False)
-            ctx.trim(params)
+            step_host_rows(locked, pin=True)
         fence()
-        pageable_s = max_over_ranks(time.perf_counter() - t0)
+        locked_s = max_over_ranks(time.perf_counter() - t0)  # (the page-locked leg, beside the pageable headline)
         cold = []
         for _ in range(5):
             fresh = Alignment(ali.names, [bytes(r) for r in a])
@@ -555,6 +598,8 @@ def main():
             cold.append(time.perf_counter() - t0)
         cold_s = max_over_ranks(float(np.median(cold)))
 
+    if args.workload in ("C2", "C3") and rank == 0:
+        sim_clock = similarity_kernel_clock(a, vhash, dmat)
     for name in ("prep", "pairs", "idstats", "gaps", "encode", "sim", "overlap", "cluster"):
         ms, launches = ctx.prof_get(name)
         if launches and name not in kernels:  # (pairs / sim of a resident workload: already taken from the timed region)
@@ -601,7 +646,7 @@ def main():
                 rate = wbytes / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
                 roofline["w_stream"] = {
                     "bound": "vector-memory pipeline (L1/TA), 256-byte global_load_dword wave-loads of L2-resident W rows "
-                             "(texture addresser 92 % busy at the clock the kernel runs at: profiles/r03_pmc_sq.txt)",
+                             "(texture addresser 0.89 busy, VALU 0.82 at 2000 x 10000: profiles/r05_pmc_sim.txt)",
                     "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
                     "frac_of_peak_with_the_loop_valu_work": round(rate / W_STREAM_PEAK_WITH_VALU_GBS, 4),
@@ -622,7 +667,7 @@ def main():
                              "(row, partner) terms; bound by the W stream through the vector-memory pipeline (roofline.w_stream), "
                              "HBM is irrelevant (the path moves tens of MB)") if dom == "sim" else
                             "bit-sliced compare / popcount over 32 columns per word on the seven symbol planes + validity: 11 VALU "
-                            "instructions per pair and word; VALU issue (86 % busy at 5000 x 5000, profiles/r03_pmc_sq.txt), not bandwidth",
+                            "instructions per pair and word; VALU issue (0.82 - 0.88 busy at 5000 x 5000, profiles/r04_pmc_sq.txt), not bandwidth",
                 }
         roofline_all = {}
         for kname, kv in kernels.items():
@@ -676,10 +721,14 @@ def main():
             out["value_public_api"] = round(units_per_step * args.steps / public_api_s, 2)
             out["ms_per_step_public_api"] = round(public_api_s / args.steps * 1e3, 4)
         if args.workload != "C5":
-            out["rows_page_locked"] = True  # (value / ms_per_step: the rows were registered once, before the timed steps)
-        if pageable_s is not None:
-            out["value_pageable_rows"] = round(units_per_step * args.steps / pageable_s, 2)
-            out["ms_per_step_pageable_rows"] = round(pageable_s / args.steps * 1e3, 4)
+            out["rows_page_locked"] = False  # (value / ms_per_step: ordinary pageable rows, nothing registered)
+            out["ms_per_step_median_of_5_regions"] = round(float(np.median(region_ms)), 4)
+            out["ms_per_step_regions"] = [round(x, 4) for x in region_ms]
+            if sim_clock is not None:
+                out["sim_kernel_clock_GHz"] = sim_clock
+        if locked_s is not None:
+            out["value_page_locked_rows"] = round(units_per_step * args.steps / locked_s, 2)
+            out["ms_per_step_page_locked_rows"] = round(locked_s / args.steps * 1e3, 4)
         if cold_s is not None:
             out["value_cold"] = round(units_per_step / cold_s, 2)
             out["ms_cold"] = round(cold_s * 1e3, 4)

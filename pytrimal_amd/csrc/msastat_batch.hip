@@ -83,9 +83,9 @@ struct Engine {
     };
     static constexpr int MAX_LANES = 4;
     Lane lanes[MAX_LANES];
-    int nlanes = 2;             // groups in flight (MSA_BATCH_LANES)
-    bool trace = false;         // MSA_BATCH_TRACE=1: host-side timing of every group on stderr
-    long fetch_max_bytes = 1 << 20;  // page-locked alignments up to this size are fetched by a kernel instead of a copy each (MSA_BATCH_FETCH_KB)
+    int nlanes = 2;             // groups in flight
+    bool trace = false;         // MSA_TRACE=1: host-side timing of every group on stderr
+    long fetch_max_bytes = 1 << 20;  // page-locked alignments up to this size are fetched by a kernel instead of a copy each
     int cols_max_m = 128;       // groups whose alignments have at most this many sequences: a lane per column (MSA_BATCH_COLS_MAX <= 128)
     msa_ctx *tables = nullptr;  // owns the similarity tables (and trims the alignments that fall back)
     std::vector<msa_ctx *> views;  // the host-only views handed to trim_impl: one per worker, the last one the calling thread's
@@ -545,10 +545,8 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
             v->prefetched = true;
             e->views.push_back(v);
         }
-        e->trace = std::getenv("MSA_BATCH_TRACE") != nullptr;
-        if (const char *ev = std::getenv("MSA_BATCH_FETCH_KB")) e->fetch_max_bytes = (long)std::atol(ev) << 10;
+        e->trace = std::getenv("MSA_TRACE") != nullptr;
         if (const char *ev = std::getenv("MSA_BATCH_COLS_MAX")) e->cols_max_m = std::min(128, std::atoi(ev));  // (the kernel's LDS tile)
-        if (const char *ev = std::getenv("MSA_BATCH_LANES")) e->nlanes = std::max(1, std::min((int)Engine::MAX_LANES, std::atoi(ev)));
         b->engine = e;
     }
     Engine *e = b->engine;
@@ -567,7 +565,6 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
     // by the arena (~8 GB) and by 256 alignments
     const int total = (int)ks.size();
     int parts = 4;
-    if (const char *ev = std::getenv("MSA_BATCH_GROUPS")) parts = std::max(1, std::atoi(ev));  // (diagnostics)
     const int target = std::max(1, std::min(256, (total + parts - 1) / parts));
     std::vector<std::vector<int32_t>> groups;
     {
@@ -801,7 +798,7 @@ int msa_trim_batch(msa_batch *b, int32_t count, const uint8_t *const *data, cons
         std::lock_guard<std::mutex> lk(b->mu);
         b->in_call = false;
     }
-    if (std::getenv("MSA_BATCH_TRACE"))
+    if (std::getenv("MSA_TRACE"))
         std::fprintf(stderr, "[msa_trim_batch] %d alignments: %zu through the batched kernels, %zu through the workers, %.2f ms\n", (int)count,
                      engine_ks.size(), b->order.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
     for (int32_t k = 0; k < count; ++k)

@@ -227,8 +227,7 @@ class PackPool {
 
   private:
     PackPool() {
-        const char *e = std::getenv("MSA_PACK_THREADS");
-        int k = e ? std::atoi(e) : 3;
+        int k = 3;  // (round 3's sweep, profiles/r03_upload.txt: three helpers beside the calling thread saturate the link)
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0) k = std::min(k, std::max(0, hw - 1));
         for (int i = 0; i < k; ++i) {
@@ -272,9 +271,7 @@ template <typename RowAt>
 int upload_rows_pitched(msa_ctx *c, int m, int n, RowAt row) {
     const size_t bytes = (size_t)m * c->ld;
     HIPCHK(c, c->h_raw.reserve(bytes));
-    const int rows_per_piece = c->tuning.upload_piece_kb > 0
-                                   ? std::max<int>(1, (int)(((size_t)c->tuning.upload_piece_kb << 10) / (size_t)c->ld))
-                                   : std::max(m, 1);
+    const int rows_per_piece = std::max<int>(1, (int)(((size_t)1 << 20) / (size_t)c->ld));  // pieces of 1 MB (round 3's sweep: profiles/r03_upload.txt)
     const int npieces = (m + rows_per_piece - 1) / rows_per_piece;
     auto pack_piece = [c, m, n, rows_per_piece, row](int p) {
         const int i0 = p * rows_per_piece, i1 = std::min(m, i0 + rows_per_piece);

@@ -14,14 +14,12 @@ struct Tuning {
     int lg_big = 0;            // MSA_LG_BIG=1: row indices instead of byte offsets in the lists at any size (tests; default: beyond 32768 rows)
     int device_clusters = -1;  // MSA_DEVICE_CLUSTERS: -1 unset (size heuristic), 0 host, 1 device
     int trace = 0;             // MSA_TRACE
-    int upload_piece_kb = 1024;  // MSA_UPLOAD_PIECE_KB: rows are packed and sent in pieces of this size (0: one copy after packing everything)
     int upload_direct = 1;     // MSA_UPLOAD_DIRECT=0: every upload through the packed pinned staging pieces (diagnostics)
     int pipeline = 1;          // MSA_PIPELINE: 0 msa_trim waits for the gap counts / identity statistics before it enqueues the similarity
                                // pass; 1 pipelined (side stream for large alignments); 2 pipelined, never a side stream; 3 always
     int lg_rounds = -1;        // MSA_LG_ROUNDS: rounds of the similarity kernel per launch (-1: by size, 0: one launch; tests: any)
     int lg_split = 0;          // MSA_LG_SPLIT: waves of a workgroup that share one column of the similarity kernel (0: by shape; tests: 1, 2, 4, 8, 16)
     int compact = 1;           // MSA_COMPACT=0: small alignments through the ordinary launch sequence (tests, A/B); 1: the compact pipeline
-    int compact_max_m = 512;   // MSA_COMPACT_MAX_M: sequences up to which the similarity pipeline runs compact
     int flat_max_m = 128;      // MSA_FLAT_MAX_M: sequences up to which the compact pipeline runs the flat similarity kernel (0: never)
     int flat_u = 0;            // MSA_FLAT_U: terms per lane and scan of the flat similarity kernel (0: by size; A/B: 4, 8, 16)
     int zerocopy_kb = 96;      // MSA_ZEROCOPY_KB: rows up to this size stay in pinned host memory and the kernels read them over the link

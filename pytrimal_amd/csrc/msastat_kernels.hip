@@ -531,12 +531,10 @@ Tuning tuning_from_env() {
     t.trace = getenv("MSA_TRACE") != nullptr;
     t.pipeline = num("MSA_PIPELINE", 1);
     t.upload_direct = num("MSA_UPLOAD_DIRECT", 1);
-    t.upload_piece_kb = num("MSA_UPLOAD_PIECE_KB", 1024);
     t.lg_r0 = num("MSA_LG_R0", -1);
     t.lg_big = num("MSA_LG_BIG", 0);
     t.mdk_host = num("MSA_MDK_HOST", 0);
     t.compact = num("MSA_COMPACT", 1);
-    t.compact_max_m = num("MSA_COMPACT_MAX_M", 512);
     t.zerocopy_kb = num("MSA_ZEROCOPY_KB", 96);
     t.flat_max_m = num("MSA_FLAT_MAX_M", 128);
     t.flat_u = num("MSA_FLAT_U", 0);

@@ -84,7 +84,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 
 // ---- the compact pipeline of a small alignment -------------------------------------------------------------------------
 // A trim of 46 x 1181 residues spent 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
-// 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to `compact_max_m` sequences, with every
+// 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to 512 sequences, with every
 // column's wave resident at once (no column order needed) and no gap window, the same statistics take THREE launches and no copy
 // (msak::CompactArgs):
 //   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes (+ lists; the ">= 80 % gaps" cut
@@ -99,7 +99,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
     const msak::Tuning &t = c->tuning;
     return t.compact != 0 && gap_hw == 0 && t.sim_kernel == 0 && (t.sim_mode & 64) == 0 && t.lg_rounds < 0 && t.lg_split == 0 &&
-           t.lg_big == 0 && c->m >= 2 && c->m <= std::min(t.compact_max_m, 512) && c->n <= c->cus * 20 &&
+           t.lg_big == 0 && c->m >= 2 && c->m <= 512 && c->n <= c->cus * 20 &&
            msak::pair_pipe_regime(c->m, c->m_pad);
 }
 bool compact_gaps_applies(const msa_ctx *c) {

@@ -18,7 +18,7 @@ from pytrimal_amd.synth import synth_msa
 pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
-                "MSA_UPLOAD_DIRECT", "MSA_UPLOAD_PIECE_KB", "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
+                "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
                 "MSA_DEVICE_CLUSTERS", "MSA_TRACE")
 
 

@@ -35,7 +35,7 @@ def ctx_with(monkeypatch):
 
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT",
-                     "MSA_COMPACT", "MSA_COMPACT_MAX_M", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB"):
+                     "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:

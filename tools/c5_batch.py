@@ -28,5 +28,4 @@ for workers in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 6, 8, 12]:
         times.append(time.perf_counter() - t)
     best = min(times)
     print(json.dumps({"workers": workers, "ms_per_batch_best": round(best * 1e3, 2), "ms_per_batch_median": round(sorted(times)[2] * 1e3, 2),
-                      "columns_per_s": round(64 * 4000 / best), "kept_columns": int(sum(sum(t.residues_mask) for t in out)),
-                      "pack_threads": os.environ.get("MSA_PACK_THREADS", "3")}), flush=True)
+                      "columns_per_s": round(64 * 4000 / best), "kept_columns": int(sum(sum(t.residues_mask) for t in out))}), flush=True)

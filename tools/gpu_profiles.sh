@@ -32,8 +32,7 @@ for shape in "1024 100 1000" "1024 60 600" "4096 40 300" "512 128 2000" "256 300
   timeout 300 python tools/small_batch.py $shape 2>/dev/null; MSA_BATCH_ENGINE=0 timeout 300 python tools/small_batch.py $shape 2>/dev/null
 done > $OUT/small_batch.jsonl
 MSA_BATCH_COLS_MAX=0 timeout 300 python tools/small_batch.py 1024 100 1000 2>/dev/null >> $OUT/small_batch.jsonl
-MSA_BATCH_FETCH_KB=0 timeout 300 python tools/small_batch.py 1024 100 1000 2>/dev/null >> $OUT/small_batch.jsonl
-for g in 1 4 16; do MSA_BATCH_ENGINE_MAX=1e12 MSA_BATCH_GROUPS=$g timeout 300 python tools/c5_engine.py 2>/dev/null; done > $OUT/c5_engine.jsonl
+MSA_BATCH_ENGINE_MAX=1e12 timeout 300 python tools/c5_engine.py 2>/dev/null > $OUT/c5_engine.jsonl
 MSA_BATCH_ENGINE=0 timeout 300 python tools/c5_engine.py 2>/dev/null >> $OUT/c5_engine.jsonl
 timeout 300 python tools/c5_counts.py > $OUT/c5_counts.jsonl 2>/dev/null
 timeout 300 python tools/small_latency.py > $OUT/small_latency.jsonl 2>/dev/null

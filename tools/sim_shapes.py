@@ -1,4 +1,4 @@
-"""The similarity kernel and the pair pass by shape, default settings: ms per pass from the context's HIP events, partner steps
+"""The similarity kernel and the pair pass by shape, default settings: ms per pass from the context's HIP events, EXACT partner steps
 per second, Q compared bit for bit with the sequential kernel where that is affordable (m * m * n <= 4e10).
     python tools/sim_shapes.py [m n seed]...        (default: the round-4 shape list)"""
 import json, os, sys, time
@@ -9,6 +9,7 @@ import torch  # noqa: F401
 from pytrimal_amd import _lib
 from pytrimal_amd.matrix import SimilarityMatrix
 from pytrimal_amd.synth import synth_msa
+import bench
 
 vhash, dist = SimilarityMatrix.aa()._device_arrays()
 shapes = [(1000, 4000, 11), (2000, 10000, 1003), (3583, 7287, 1003), (5000, 5000, 1004), (8000, 3000, 5), (20000, 500, 3), (40000, 300, 4)]
@@ -34,12 +35,15 @@ for m, n, seed in shapes:
         ms, cnt = ctx.prof_get(k)
         if cnt:
             rec[k + "_ms"] = round(ms / cnt, 4)
-    g, x = ctx.gaps(with_indet=True)
-    valid = (m - g - x).astype(np.float64)
-    act = (g.astype(np.float64) / m) < 0.8
-    steps = float(np.sum((valid[act] ** 2) / 128.0))
+    # partner steps of the pass, EXACT (bench.similarity_w_stream_bytes: per evaluated column and 64-row round the valid rows at or
+    # behind the round's first row, in blocks of 16 since round 5 -- the estimate nv^2 / 128 this tool printed through round 4
+    # undercounts: a round walks the partner list from its first row on, a column costs ~ nv m / 128 steps)
+    wbytes, steps = bench.similarity_w_stream_bytes(a)
     rec["partner_steps"] = steps
     rec["steps_per_s"] = round(steps / (rec["sim_ms"] * 1e-3), 0)
+    rec["w_stream_TBs"] = round(wbytes / (rec["sim_ms"] * 1e-3) / 1e12, 2)
+    rec["sim_launches"] = int(ctx.last_paths()["sim_launches"])
+    rec["sim_waves_per_column"] = int(ctx.last_paths()["sim_waves_per_column"])
     ctx.close()
     if float(m) * m * n <= 4e10 and os.environ.get("CHECK", "1") == "1":
         os.environ["MSA_SIM_KERNEL"] = "seq"
