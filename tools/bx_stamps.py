@@ -38,13 +38,12 @@ def stamped_similarity(a, indet=ord("X"), matrix=None):
     finally:
         ctx.close()
     w = max(buf[3], 1)
-    return mdk, q, {"sim_ms": round(ms / max(k, 1), 3), "waves": int(buf[3]), "ordered_rows_per_wave": round(buf[10] / w, 1), "of_which_same_row_in_both_chains": round(2 * buf[12] / w, 1),
+    return mdk, q, {"sim_ms": round(ms / max(k, 1), 3), "waves": int(buf[3]), "ordered_rows_per_wave": round(buf[10] / w, 1), "of_which_sparse_rows": round(buf[9] / w, 1), "of_which_same_row_in_both_chains": round(2 * buf[12] / w, 1),
                     "rounds_per_wave": round(buf[4] / w, 1), "max_rounds": int(buf[8]), "wave_ms_avg": round(buf[6] / w / 1e5, 3),
                     "longest_wave_kcycles": round(buf[7] / 1e3, 1), "clock_GHz": round((buf[0] + buf[1] + buf[2]) / max(buf[6], 1) / 10, 3),
                     "kcycles_per_wave": {"prologue": round(buf[0] / w / 1e3, 1), "loops": round(buf[1] / w / 1e3, 1),
                                          "stitch": round(buf[2] / w / 1e3, 1), "of_which_ordered_rows": round(buf[11] / w / 1e3, 1)},
-                    "prologue_parts_kcycles": {"histogram": round(buf[13] / w / 1e3, 1), "G": round(buf[14] / w / 1e3, 1), "skip": round(buf[15] / w / 1e3, 1),
-                                               "first_rows": round(buf[5] / w / 1e3, 1)}}
+                    "prologue_parts_kcycles": {"histogram": round(buf[13] / w / 1e3, 1), "G": round(buf[14] / w / 1e3, 1), "first_rows": round(buf[5] / w / 1e3, 1)}}
 
 
 if __name__ == "__main__":
