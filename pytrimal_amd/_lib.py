@@ -194,7 +194,7 @@ def ptr(arr):
 # threads); an entry made by another process (a fork inherits the table, not the registrations) is ignored, and its
 # finalizer does not enter a HIP runtime that process never initialised.
 _pinned = collections.OrderedDict()
-_pin_lock = threading.Lock()
+_pin_lock = threading.RLock()  # (re-entrant: a finalizer of a pinned array may run on the thread that holds it, inside an allocation)
 
 
 _pin_budget_cache = (None, 1024 << 20)
@@ -250,7 +250,9 @@ def pin_array(a):
         for k in list(_pinned):
             if used + nbytes <= budget:
                 break
-            e = _pinned.pop(k)
+            e = _pinned.pop(k, None)
+            if e is None:  # (released by a finalizer that ran under this very loop)
+                continue
             if e[3] == pid:
                 used -= e[1]
             _unpin_entry(e)

@@ -270,7 +270,14 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     HIPCHK(tc, L.meta.reserve(meta_bytes));
     HIPCHK(tc, L.h_meta.reserve(meta_bytes));
     HIPCHK(tc, L.h_res.reserve(res_words * 4 + 64));
-    if (stage_bytes) HIPCHK(tc, L.h_stage.reserve(stage_bytes));
+    if (stage_bytes) {
+        // (a grown staging buffer starts as zeros: the runs copied out of it span the slack and the alignment gaps between the packed
+        // alignments, which only ever hold what the buffer held when it was allocated -- the arena's padding stays zero whatever
+        // way the rows arrive)
+        const size_t had = L.h_stage.cap;
+        HIPCHK(tc, L.h_stage.reserve(stage_bytes));
+        if (L.h_stage.cap != had) std::memset(L.h_stage.p, 0, L.h_stage.cap);
+    }
     (void)old_base;
     uint8_t *A = L.arena.p;
     msak::BAlign *bt = reinterpret_cast<msak::BAlign *>(L.h_meta.p);

@@ -199,6 +199,13 @@ struct msa_ctx {
     std::vector<int32_t> h_gaps, h_indets;
     std::vector<int32_t> only_gaps_rows;  // the sequences the last msa_trim removed because the trimming left them with gaps only
 
+    // Cleaner::calculateSpuriousVector's values, staged by compact_overlap (a small alignment's front kernel and the overlap kernels
+    // behind ONE wait) for the overlap() call that follows in the same msa_trim
+    std::vector<float> ov_vals;
+    float ov_key = 0.0f;
+    bool ov_valid = false;
+    std::vector<uint8_t> ov_keep;  // ... and the sequences its device-side decision kept (the mask h_colcnt was counted over)
+    bool ov_colcnt = false;        // h_colcnt holds the residues per column over ov_keep
     int sim_launches = 0;  // kernel launches of the last similarity pass (msa_debug_sim_launches)
     // which path the last upload and the last statistic / trim call took (msa_debug_last_paths; MSA_PATH_* of msastat.h):
     // [0] upload, [1] pipeline, [2] similarity kernel, [3] its waves per column, [4] its launches, [5] it wrote MDK itself,
@@ -321,6 +328,7 @@ int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t s
 int sim_order_enqueue(msa_ctx *c, const SimOrder &ord, hipStream_t st);
 int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t *gw_dev, const int *gate);
 int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, const int32_t *gaps_windowed, float *mdk_out, float *q_out, msa_err_detail *detail);
+int overlap_enqueue(msa_ctx *c, float residue_overlap);
 int overlap(msa_ctx *c, float residue_overlap, float *out);
 int stage_row_totals(msa_ctx *c, hipStream_t st = nullptr);
 int remove_all_gaps(msa_ctx *c, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info);
@@ -342,6 +350,7 @@ msak::CompactArgs compact_args(msa_ctx *c);
 int compact_prepare(msa_ctx *c);
 int compact_fetch(msa_ctx *c, bool sim);
 int compact_gaps(msa_ctx *c);
+int compact_overlap(msa_ctx *c, float residue_overlap, float sequence_overlap);
 int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, bool gated);
 int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *keep_seq, msa_trim_info *info);
 // msastat_batch.hip

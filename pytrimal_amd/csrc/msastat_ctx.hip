@@ -57,6 +57,7 @@ void invalidate(msa_ctx *c) {
     c->state_zeroed = false;
     c->flags_dirty = false;
     c->colcnt_staged = false;
+    c->ov_valid = c->ov_colcnt = false;
 }
 
 // the state block of the current alignment, zeroed once (one memset for the flags and both count vectors)

@@ -169,6 +169,7 @@ void launch_sim_finish(hipStream_t s, const float *num, const float *den, const 
                        float *q_out, float *mdk_out);
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
                     const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good);
+void launch_overlap_keep(hipStream_t s, const int32_t *good, int m, int n, float min_ov, uint8_t *keep);
 void launch_row_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_res,
                        int32_t *row_nongap);
 void launch_col_nongap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq,

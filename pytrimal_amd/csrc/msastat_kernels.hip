@@ -639,6 +639,16 @@ void launch_sim_finish(hipStream_t s, const float *num, const float *den, const 
     sim_finish_kernel<<<(n + 255) / 256, 256, 0, s>>>(num, den, gaps_w, m, n, q_out, mdk_out, tuning().mdk_host);
 }
 
+// OverlapTrimmer's decision on the device as well (the host takes it from the same counts after the wait and compares): a sequence
+// stays when (float)good / n is not below the threshold -- the mask the all-gap column counts behind it are taken over
+__global__ __launch_bounds__(256) void overlap_keep_kernel(const int32_t *__restrict__ good, int m, int n, float min_ov, uint8_t *__restrict__ keep) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < m) keep[i] = (static_cast<float>(good[i]) / n) < min_ov ? 0 : 1;
+}
+void launch_overlap_keep(hipStream_t s, const int32_t *good, int m, int n, float min_ov, uint8_t *keep) {
+    overlap_keep_kernel<<<(m + 255) / 256, 256, 0, s>>>(good, m, n, min_ov, keep);
+}
+
 void launch_overlap(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
                     const int32_t *indets, int need, uint32_t *col_ok, int nchunk, int32_t *good) {
     overlap_colmask_kernel<<<(nchunk * 32 + 255) / 256, 256, 0, s>>>(gaps, indets, m, n, need, col_ok, nchunk);

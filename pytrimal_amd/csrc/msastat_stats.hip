@@ -394,22 +394,33 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
     return rc;
 }
 
-int overlap(msa_ctx *c, float residue_overlap, float *out) {
-    int rc = ensure_gaps(c, false);
-    if (rc) return rc;
+// the overlap kernels behind whatever the stream holds, their counts on the way to h_i32 (no wait)
+int overlap_enqueue(msa_ctx *c, float residue_overlap) {
     const int m = c->m, n = c->n;
     const float fo = residue_overlap * static_cast<float>(m - 1);
     const int need = static_cast<int>(std::ceil(fo));
     HIPCHK(c, c->col_ok.reserve((size_t)3 * c->nchunk + 64));
     HIPCHK(c, c->good.reserve((size_t)m + 64));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
     {
         ProfScope ps(c, "overlap");
         msak::launch_overlap(c->stream, c->raw, m, n, c->ld, c->indet, c->gaps.p, c->indets.p, need, c->col_ok.p,
                              c->nchunk, c->good.p);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
     HIPCHK(c, hipMemcpyAsync(c->h_i32.p, c->good.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, c->stream));
+    return MSA_OK;
+}
+
+int overlap(msa_ctx *c, float residue_overlap, float *out) {
+    if (c->ov_valid && c->ov_key == residue_overlap && (int)c->ov_vals.size() == c->m) {  // (staged by compact_overlap)
+        std::copy(c->ov_vals.begin(), c->ov_vals.end(), out);
+        return MSA_OK;
+    }
+    int rc = ensure_gaps(c, false);
+    if (rc) return rc;
+    const int m = c->m, n = c->n;
+    if ((rc = overlap_enqueue(c, residue_overlap))) return rc;
     SYNC(c);
     for (int i = 0; i < m; ++i) out[i] = static_cast<float>(c->h_i32.p[i]) / n;
     return MSA_OK;

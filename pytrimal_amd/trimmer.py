@@ -156,8 +156,11 @@ class BaseTrimmer:
                 matrix = _default_matrix("ntdeg" if ty & 8 else "nt")
         # the parameter block of this trimmer for this matrix: filled once, copied per alignment (trim_batch prepares
         # thousands of small alignments per call)
+        # (keyed by the matrix AND by what configures the block -- the trimmer's state: an attribute written after the first
+        # trim, or a `__setstate__` on a used object, must not keep the old thresholds)
         cache = self.__dict__.setdefault("_params_cache", {})
-        entry = cache.get(id(matrix))
+        key = (id(matrix), tuple(self.__getstate__().items()))
+        entry = cache.get(key)
         if entry is None or entry[2] is not matrix:
             template = _lib.TrimParams(0, -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, None, None, 0)
             self._configure(template)
@@ -167,7 +170,7 @@ class BaseTrimmer:
             template.npos = len(matrix)
             if len(cache) > 64:
                 cache.clear()
-            entry = cache[id(matrix)] = (bytes(template), (vhash, dist, matrix), matrix)
+            entry = cache[key] = (bytes(template), (vhash, dist, matrix), matrix)
         params = _lib.TrimParams.from_buffer_copy(entry[0])
         return alignment.names, dense, indet, params, entry[1]
 

@@ -448,3 +448,38 @@ def test_concurrent_contexts_keep_parity():
     with ThreadPool(4) as pool:
         for _ in range(3):
             assert all(pool.map(run, cases))
+
+
+def test_a_trimmer_reconfigured_after_its_first_trim():
+    """The parameter block of a trimmer is cached per matrix: an attribute written after the first trim, or `__setstate__` on
+    a used object, must configure the next trim (round 4's advisor: the cache kept the old method and thresholds)."""
+    a = synth_msa(60, 400, 91)
+    ali = Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a])
+    t = AutomaticTrimmer("strict", platform=PLATFORM)
+    assert_matches_oracle(t.trim(ali), a, method="strict")
+    t.method = "gappyout"
+    assert_matches_oracle(t.trim(ali), a, method="gappyout")
+    t.__setstate__({"method": "nogaps", "platform": PLATFORM})
+    assert_matches_oracle(t.trim(ali), a, method="nogaps")
+    mt = ManualTrimmer(gap_threshold=0.3, platform=PLATFORM)
+    assert_matches_oracle(mt.trim(ali), a, gap_threshold=0.3)
+    state = mt.__getstate__()
+    state["gap_threshold"] = float(np.float32(1) - np.float32(0.8))  # (the state holds the maximum gap FRACTION, as the reference's)
+    mt.__setstate__(state)
+    assert_matches_oracle(mt.trim(ali), a, gap_threshold=0.8)
+
+
+@pytest.mark.parametrize("shape", [(46, 1181), (209, 1227), (400, 900)])
+@pytest.mark.parametrize("args", [(80, 0.8), (40, 0.6), (95, 0.95), (10, 0.1)])
+def test_overlap_trimmer_one_wait_on_small_alignments(shape, args):
+    """OverlapTrimmer on alignments the compact front kernel takes: counts, the sequences that stay (decided on the device as the
+    host decides it) and the column counts over them come back behind ONE wait -- against the oracle, whether sequences go or not."""
+    m, n = shape
+    a = synth_msa(m, n, 300 + m)
+    a[3, : n // 2] = ord("-")  # (a sequence that overlaps little)
+    a[7] = ord("-")
+    a[7, :5] = a[6, :5]
+    ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
+    seq_ov, res_ov = args
+    trimmed = OverlapTrimmer(seq_ov, res_ov, platform=PLATFORM).trim(ali)
+    assert_matches_oracle(trimmed, a, sequence_overlap=seq_ov, residue_overlap=res_ov)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # profiles of a round: bench lines, rocprofv3 kernel stats and PMC HBM traffic per workload, SQ counters of C3.
-#   bash tools/gpu_profiles.sh r03     -> gpurun_out/r03/; tools/summarise_profiles.py r03 turns it into profiles/r03_*.
+#   bash tools/gpu_profiles.sh r05     -> gpurun_out/r05/; tools/summarise_profiles.py r05 turns it into profiles/r05_*.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r05}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
@@ -59,6 +59,11 @@ timeout 600 python tools/sim_by_data.py > $OUT/sim_by_data.jsonl 2>/dev/null
 bash tools/gpu_c5_timeline.sh 4 > $OUT/c5_timeline.txt 2>/dev/null
 bash tools/gpu_timeline.sh > /dev/null 2>&1
 for w in C3 C2 C4; do cp $ROOT/gpurun_out/tl/timeline_$w.txt $OUT/ 2>/dev/null; done
+# round 5: the similarity kernel's counters at 1000 x 4000 and 2000 x 10000 (VALU / scalar / texture busy, L2 hit rate), its stamps on the
+# reference's ENOG fixture beside a synthetic alignment of that shape, kernels of different contexts side by side
+{ echo "== 1000 x 4000"; bash tools/pmc_kernel.sh similarity_lg python3 tools/sim_once.py 1000 4000 2000; echo "== 2000 x 10000"; bash tools/pmc_kernel.sh similarity_lg python3 tools/sim_once.py 2000 10000 1003; } > $OUT/pmc_sim.txt 2>&1
+timeout 120 python tools/sim_fixture_stamps.py > $OUT/sim_fixture_stamps.txt 2>/dev/null
+timeout 300 python tools/sim_overlap.py > $OUT/sim_overlap.jsonl 2>/dev/null
 ls $OUT | head -60
 # keep only the small csv files (the merge back is limited to 64 MiB)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete

@@ -4,7 +4,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -110,7 +110,7 @@ for name in ("ubench_wform.txt", "sim_shapes.jsonl", "sim_shapes_one_wave_per_co
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 for name in ("bx_stamps.jsonl", "ab_switches.txt", "timeline_C3.txt", "timeline_C2.txt", "timeline_C4.txt", "reference_shape.jsonl",
-             "c5_batch.jsonl", "upload.txt", "sim_by_data.jsonl", "c5_timeline.txt", "bench_REF.json"):
+             "c5_batch.jsonl", "upload.txt", "sim_by_data.jsonl", "c5_timeline.txt", "bench_REF.json", "pmc_sim.txt", "sim_fixture_stamps.txt", "sim_overlap.jsonl"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 print("\n".join(lines[-40:]))
