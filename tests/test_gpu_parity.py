@@ -666,3 +666,65 @@ def test_rows_are_the_callers_again_when_a_trim_returns():
             assert np.array_equal(c.gaps(), want)
     finally:
         c.close()
+
+
+def _conserved_columns(m, n, seed):
+    """Columns on both sides of the predictor's two gates: the commonest residue at 85 ... 100 % of the valid
+    rows, 0 ... 20 rows of other residues (the list of a `SparseCol` holds 16) placed at the top, the bottom, one round apart or at
+    random, with and without gaps -- beside ordinary columns."""
+    r = np.random.default_rng(seed)
+    a = synth_msa(m, n, seed)
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    for c in range(0, n, 2):  # (every other column stays as synth_msa made it)
+        own = alpha[r.integers(0, 20)]
+        a[:, c] = own
+        others = int(r.choice([0, 1, 2, 3, 8, 15, 16, 17, 20, max(1, m // 12), max(1, m // 9), max(1, m // 7)]))
+        place = r.integers(0, 4)
+        if place == 0:
+            rows = np.arange(others)                      # at the top: the sum starts large
+        elif place == 1:
+            rows = np.arange(m - others, m)               # at the bottom: nothing but zeros for a long time
+        elif place == 2:
+            rows = (np.arange(others) * 64 + 5) % m        # one per round
+        else:
+            rows = r.choice(m, size=min(others, m), replace=False)
+        a[rows, c] = alpha[r.integers(0, 20, len(rows))]
+        if r.random() < 0.5:
+            a[r.random(m) < r.choice([0.05, 0.3, 0.6]), c] = ord("-")
+        if r.random() < 0.2:
+            a[r.integers(0, m), c] = ord("X")
+    return np.ascontiguousarray(a)
+
+
+@pytest.mark.parametrize("kernel", [dict(MSA_COMPACT="0"), dict(MSA_COMPACT="0", MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="2", MSA_LG_ROUNDS="1"),
+                                    dict(MSA_LG_SPLIT="5"), dict(MSA_LG_BIG="1"), dict()],
+                         ids=["lg", "lg-rounds", "lg-split-2-rounds", "lg-split-5", "lg-big", "default"])
+@pytest.mark.parametrize("shape", [(70, 90), (200, 120), (333, 64), (640, 48)])
+def test_predictor_on_conserved_columns(ctx_with, kernel, shape):
+    """The predictor's paths for conserved columns (exact counts of the rows behind, the non-zero products themselves, ordered
+    rows from a handful of terms) in every instantiation that carries them -- a wave per column, one round per launch (the list
+    travels through the state), several waves per column (every wave needs the list) -- against the oracle."""
+    m, n = shape
+    _sim_parity(ctx_with(**kernel), _conserved_columns(m, n, 1000 + m))
+
+
+@pytest.mark.parametrize("kernel", [dict(), dict(MSA_LG_SPLIT="3")], ids=["default", "lg-split-3"])
+def test_predictor_on_conserved_columns_many_rows(ctx_with, kernel):
+    """... at 2100 rows: six rounds per launch, the columns' state (R, the list of a SparseCol) through memory; against the plain
+    sequential kernel, bit for bit (the oracle would take a minute)."""
+    a = _conserved_columns(2100, 40, 77)
+    vhash, dist = oracle.aa_matrix()
+    ctx = ctx_with(**kernel)
+    ctx.upload(a, ord("X"))
+    mdk, q = ctx.similarity(vhash, dist)
+    ref = ctx_with(MSA_SIM_KERNEL="seq")
+    ref.upload(a, ord("X"))
+    mdk2, q2 = ref.similarity(vhash, dist)
+    assert np.array_equal(bits(q), bits(q2)) and np.array_equal(bits(mdk), bits(mdk2))
+    ohit, odst = oracle.pair_counts(a[:, :4])  # (... and the oracle itself on the first columns, with its own W of those columns' alignment)
+    sub = np.ascontiguousarray(a[:, :4])
+    small = ctx_with(**kernel)
+    small.upload(sub, ord("X"))
+    smdk, sq = small.similarity(vhash, dist)
+    omdk, oq = oracle.similarity(sub, oracle.weights(ohit, odst), oracle.gaps(sub)[0], vhash, dist)
+    assert np.array_equal(bits(sq), bits(oq)) and np.array_equal(bits(smdk), bits(omdk))
