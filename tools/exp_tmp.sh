@@ -1,11 +1,9 @@
-cd $GRAFT_REPO_ROOT
 cp pytrimal_amd/libmsastat_hip.so /tmp/shipped.so
-for v in r04 shipped r04 shipped; do
-  cp $([ $v = shipped ] && echo /tmp/shipped.so || echo tools/_variants/$v.so) pytrimal_amd/libmsastat_hip.so
-  echo "#### $v"
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print({k:r.get(k) for k in ('ms_per_step','ms_per_step_regions','ms_per_step_page_locked_rows','ms_per_step_resident','ms_per_step_public_api','kernels_ms')})"
+for v in shipped nosload shipped nosload; do
+  if [ $v = shipped ]; then cp /tmp/shipped.so pytrimal_amd/libmsastat_hip.so; else cp tools/_variants/$v.so pytrimal_amd/libmsastat_hip.so; fi
+  echo "== $v"
+  python tools/bx_stamps.py 1000 1000 11 2>&1 | grep -v amdgpu.ids
+  python tools/bx_stamps.py 1000 4000 11 2>&1 | grep -v amdgpu.ids
+  CHECK=0 python tools/sim_shapes.py 1000 300 11 1000 1000 11 1000 4000 11 2000 10000 1003 2>&1 | grep -v amdgpu.ids | cut -c1-120
 done
 cp /tmp/shipped.so pytrimal_amd/libmsastat_hip.so

@@ -8,7 +8,7 @@ import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, _lib
 from pytrimal_amd.synth import synth_msa
 
-SIZES = [(46, 1181), (100, 1000), (200, 2000), (500, 2000), (1000, 4000)]
+SIZES = [tuple(int(v) for v in x.split("x")) for x in os.environ["SIZES"].split(",")] if os.environ.get("SIZES") else [(46, 1181), (100, 1000), (200, 2000), (500, 2000), (1000, 4000)]
 TRIMMERS = [("gappyout", lambda: AutomaticTrimmer("gappyout", platform="hip")),
             ("strict", lambda: AutomaticTrimmer("strict", platform="hip")),
             ("automated1", lambda: AutomaticTrimmer("automated1", platform="hip")),
