@@ -146,6 +146,14 @@ size_t compact_scratch_words(int m, int n);
 size_t compact_slot_words(int n);
 void launch_compact_front(hipStream_t s, const CompactArgs &a);
 void launch_compact_identity(hipStream_t s, const CompactArgs &a);
+// OverlapTrimmer behind the front kernel (m <= 1024): the sequences' overlap counts, the device's decision, the residues per column
+// over the sequences that stay -- two launches, every result stored into device AND pinned host memory (h_*)
+void launch_overlap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
+                          const int32_t *indets, int need, float min_ov, int32_t *good, int32_t *h_good, uint8_t *keep, uint8_t *h_keep,
+                          int32_t *col_nongap, int32_t *h_col_nongap);
+// ... the second of the two by itself (m <= 1024): the residues per column over keep_seq, plain stores into both vectors (no memset, no copy)
+void launch_col_nongap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq, int32_t *col_nongap,
+                             int32_t *h_col_nongap);
 int flat_rows_max();
 void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab);  // two waves per column (one per sum): the column's pairs as one sequence
 int pair_tiles_pipe(int m, int m_pad);    // tiles of the pair pass in its one-row-per-lane regime
@@ -178,8 +186,9 @@ void launch_row_digest(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
                        unsigned long long *hashes);
 size_t cluster_adj_words(int m);
 size_t cluster_adj_buffer_words(int m);  // what launch_cluster's `adj` must hold
+// count: the representatives are added to *count (zeroed by the caller), or null; h_keep: the mask in pinned host memory as well, or null
 int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *seq_at, int m, float thr, uint32_t *adj,
-                   uint8_t *keep_seq, int32_t *count);
+                   uint8_t *keep_seq, int32_t *count, uint8_t *h_keep);
 void launch_rows_equal(hipStream_t s, const uint8_t *raw, int n, int64_t ld, const int32_t *pairs, int npairs,
                        int32_t *equal);
 

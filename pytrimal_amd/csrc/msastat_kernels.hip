@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void cluster_adjacency_kernel(const float *__r
 
 __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__restrict__ adj, const uint32_t *__restrict__ nz,
                                                            int m, int words, const int32_t *__restrict__ seq_at,
-                                                           uint8_t *__restrict__ keep_seq, int32_t *__restrict__ count) {
+                                                           uint8_t *__restrict__ keep_seq, int32_t *__restrict__ count,
+                                                           uint8_t *__restrict__ h_keep) {
     extern __shared__ uint32_t sets[];  // rep[2][words], undec[2][words]
     uint32_t *rep = sets, *undec = sets + 2 * words;
     __shared__ int remaining;
@@ -497,9 +498,10 @@ __global__ __launch_bounds__(1024) void cluster_mis_kernel(const uint32_t *__res
     for (int t = threadIdx.x; t < m; t += 1024) {
         const int r = (rf[t >> 5] >> (t & 31)) & 1u;
         keep_seq[seq_at[t]] = (uint8_t)r;
+        if (h_keep) h_keep[seq_at[t]] = (uint8_t)r;  // (the mask in pinned host memory as well: no copy behind the kernel)
         local += r;
     }
-    if (local) atomicAdd(count, local);
+    if (local && count) atomicAdd(count, local);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,7 +679,7 @@ size_t cluster_adj_buffer_words(int m) { return (size_t)m * (cluster_adj_words(m
 
 // seq_at: the processing order [m] followed by its inverse [m] (position of every sequence in that order)
 int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *seq_at, int m, float thr, uint32_t *adj,
-                   uint8_t *keep_seq, int32_t *count) {
+                   uint8_t *keep_seq, int32_t *count, uint8_t *h_keep) {
     const int words = (int)cluster_adj_words(m);
     const size_t lds = (size_t)4 * words * sizeof(uint32_t);
     if (lds > 60 * 1024) return -1;  // caller falls back to the host path
@@ -685,7 +687,7 @@ int launch_cluster(hipStream_t s, const float *ident, int ldw, const int32_t *se
     uint32_t *nz = adj + (size_t)m * words;
     if (hipMemsetAsync(nz, 0, (size_t)m * ((words + 31) / 32) * sizeof(uint32_t), s) != hipSuccess) return -2;
     cluster_adjacency_kernel<<<grid, 256, 0, s>>>(ident, ldw, seq_at, seq_at + m, m, thr, adj, words, nz);
-    cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, nz, m, words, seq_at, keep_seq, count);
+    cluster_mis_kernel<<<1, 1024, lds, s>>>(adj, nz, m, words, seq_at, keep_seq, count, h_keep);
     return 0;
 }
 

@@ -673,6 +673,77 @@ __global__ __launch_bounds__(256) void compact_identity_kernel(CompactArgs a) {
     identity_final_body(a.row_avg, a.row_max, a.m, reinterpret_cast<float *>(a.hres + 4), a.flags + 6, a.hres + 6);
 }
 
+// OverlapTrimmer on a small alignment, behind the front kernel (compact_overlap, msastat_trim.hip): two launches whose results the
+// kernels store into pinned host memory themselves -- where the ordinary sequence is the two overlap kernels, the device's decision,
+// a memset, the column counts and three copies (the reference's ENOG411BWBU fixture, OverlapTrimmer(80, 0.8): 0.083 ms).
+//   1. a wave per sequence: Cleaner::calculateSpuriousVector's closed form (overlap_rows_kernel, msastat_kernels.hip) with the
+//      columns' three verdicts -- enough other sequences agree with a residue / a gap / an indetermination -- taken from the front
+//      kernel's counts as the wave walks its row (four columns per lane and load: two 16-byte loads of counts beside the row's
+//      dword), then the sequence's own verdict as the host will take it (the same float division and comparison);
+//   2. the residues per column over the sequences that stay (what removeAllGapsSeqsAndCols asks for when sequences go): a
+//      workgroup of sixteen waves per 256 columns, wave w on the rows w, w + 16, ..., byte counters (<= 64 rows per wave),
+//      summed through LDS -- plain stores: no atomics, hence no memset.
+__global__ __launch_bounds__(256) void overlap_small_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld, uint32_t indet4,
+                                                            const int32_t *__restrict__ gaps, const int32_t *__restrict__ indets, int need,
+                                                            float min_ov, int32_t *__restrict__ good, int32_t *__restrict__ h_good,
+                                                            uint8_t *__restrict__ keep, uint8_t *__restrict__ h_keep) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw + (size_t)row * ld);
+    int cnt = 0;
+    for (int c4 = lane; c4 * 4 < n; c4 += 64) {
+        const uint32_t x = p[c4];
+        const i4 g4 = *reinterpret_cast<const i4 *>(gaps + 4 * c4), x4 = *reinterpret_cast<const i4 *>(indets + 4 * c4);
+        const uint32_t isg = zero_bytes(x ^ 0x2d2d2d2du), isi = zero_bytes(x ^ indet4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c4 * 4 + k < n) {
+                const int g = g4[k], xi = x4[k];
+                const bool gap = (isg >> (8 * k + 7)) & 1u, ind = (isi >> (8 * k + 7)) & 1u;
+                const int agree = gap ? g : (ind ? xi : m - g - xi);  // sequences that hold the same kind of symbol, this one included
+                cnt += (agree - 1) >= need ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) {
+        good[row] = cnt, h_good[row] = cnt;
+        const uint8_t k = (static_cast<float>(cnt) / n) < min_ov ? 0 : 1;
+        keep[row] = k, h_keep[row] = k;
+    }
+}
+__global__ __launch_bounds__(1024) void col_nongap_small_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                               const uint8_t *__restrict__ keep_seq, int32_t *__restrict__ col_nongap,
+                                                               int32_t *__restrict__ h_col_nongap) {
+    __shared__ uint32_t part[16][64];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int c4 = blockIdx.x * 64 + lane;
+    uint32_t acc = 0;
+    if ((int64_t)c4 * 4 < ld) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(raw) + c4;
+        const size_t stride = (size_t)(ld >> 2);
+#pragma unroll 4
+        for (int r = wave; r < m; r += 16) {
+            const uint32_t x = p[(size_t)r * stride];
+            const uint32_t nongap = (~zero_bytes(x ^ 0x2d2d2d2du) & 0x80808080u) >> 7;
+            acc += keep_seq[r] ? nongap : 0u;  // (wave-uniform)
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int d = (int)(threadIdx.x >> 2), k = (int)(threadIdx.x & 3);
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += (part[w][d] >> (8 * k)) & 0xFFu;
+        const int c = (blockIdx.x * 64 + d) * 4 + k;
+        if (c < n) col_nongap[c] = (int32_t)v, h_col_nongap[c] = (int32_t)v;
+    }
+}
+
 }  // namespace
 
 
@@ -744,6 +815,18 @@ void launch_similarity_flat(hipStream_t s, const LgAlign &one, const void *tab) 
     }
     LaunchNote &note = launch_note();
     note.sim_kind = 1, note.lg_split = 0, note.lg_launches = 1, note.lg_fin = 1;
+}
+// m <= 1024 (sixteen waves x 64 rows of byte counters); every pointer but raw / gaps / indets / keep in device AND pinned host memory
+void launch_overlap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,
+                          const int32_t *indets, int need, float min_ov, int32_t *good, int32_t *h_good, uint8_t *keep, uint8_t *h_keep,
+                          int32_t *col_nongap, int32_t *h_col_nongap) {
+    overlap_small_kernel<<<(unsigned)((m + 3) / 4), 256, 0, s>>>(raw, m, n, ld, 0x01010101u * indet, gaps, indets, need, min_ov, good, h_good,
+                                                                  keep, h_keep);
+    launch_col_nongap_small(s, raw, m, n, ld, keep, col_nongap, h_col_nongap);
+}
+void launch_col_nongap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq, int32_t *col_nongap,
+                             int32_t *h_col_nongap) {
+    col_nongap_small_kernel<<<(unsigned)((ld / 4 + 63) / 64), 1024, 0, s>>>(raw, m, n, ld, keep_seq, col_nongap, h_col_nongap);
 }
 void launch_compact_identity(hipStream_t s, const CompactArgs &a) {
     compact_identity_kernel<<<(unsigned)((a.m + 3) / 4), 256, 0, s>>>(a);

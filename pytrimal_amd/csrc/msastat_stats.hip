@@ -574,6 +574,12 @@ int stage_kept_column_counts(msa_ctx *c, const std::vector<int32_t> &lengths) {
     const int m = c->m, n = c->n;
     HIPCHK(c, c->col_cnt.reserve((size_t)n + 64));
     HIPCHK(c, c->h_colcnt.reserve((size_t)n + 4));
+    if (m <= 1024) {  // a small alignment: one launch that stores into the pinned vector itself (no memset, no copy)
+        msak::launch_col_nongap_small(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p, c->h_colcnt.p);
+        HIPCHK(c, hipGetLastError());
+        c->colcnt_staged = true;
+        return MSA_OK;
+    }
     HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
     msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
     HIPCHK(c, hipGetLastError());
@@ -689,17 +695,18 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     std::memcpy(c->h_i32.p, seq_at.data(), sizeof(int32_t) * m);
     for (int t = 0; t < m; ++t) c->h_i32.p[m + seq_at[t]] = t;  // the inverse: where each sequence stands in the order
     HIPCHK(c, hipMemcpyAsync(c->pairs.p, c->h_i32.p, sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->equal.p, 0, sizeof(int32_t), c->stream));
+    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
     {
+        // (the number of representatives is not asked for here: no counter to zero; up to 4096 sequences the mask lands in pinned
+        // host memory by the kernel's own byte stores: no copy behind it)
         ProfScope ps(c, "cluster");
         if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, max_identity, c->col_ok.p,
-                                 c->keep_seq_d.p, c->equal.p) != 0)
+                                 c->keep_seq_d.p, nullptr, m <= 4096 ? c->h_u8.p : nullptr) != 0)
             return MSA_E_FALLBACK;  // too many sequences for the LDS bit sets: host path
     }
     HIPCHK(c, hipGetLastError());
     if ((rc = stage_kept_column_counts(c, lengths))) return rc;
-    HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, c->n)));
-    HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
+    if (m > 4096) HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
     SYNC(c);
     std::memcpy(keep_seq, c->h_u8.p, m);
     return MSA_OK;
@@ -755,7 +762,7 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
         {
             ProfScope ps(c, "cluster");
             if (msak::launch_cluster(c->stream, c->ident.p, c->ldw, c->pairs.p, m, threshold, c->col_ok.p,
-                                     c->keep_seq_d.p, c->equal.p) != 0)
+                                     c->keep_seq_d.p, c->equal.p, nullptr) != 0)
                 return MSA_E_FALLBACK;
         }
         HIPCHK(c, hipGetLastError());

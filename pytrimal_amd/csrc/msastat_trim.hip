@@ -195,20 +195,25 @@ int compact_overlap(msa_ctx *c, float residue_overlap, float sequence_overlap) {
     }
     HIPCHK(c, hipGetLastError());
     c->errkey_dirty = false;
-    if ((rc = overlap_enqueue(c, residue_overlap))) return rc;
-    // ... and what remove_all_gaps will ask for if sequences go: the residues per column over the sequences that stay -- the mask
-    // decided here as the host will decide it (the same float division and comparison), counted over at once
+    // the overlap counts, and what remove_all_gaps will ask for if sequences go: the residues per column over the sequences that
+    // stay -- the mask decided on the device as the host will decide it (the same float division and comparison), counted over at
+    // once; two launches that store into pinned host memory themselves (round 5, late: they were two overlap kernels, the
+    // decision, a memset, the counts and three copies -- nine queue operations behind the front kernel)
     const int m = c->m, n = c->n;
+    const float fo = residue_overlap * static_cast<float>(m - 1);
+    const int need = static_cast<int>(std::ceil(fo));
+    HIPCHK(c, c->good.reserve((size_t)m + 64));
+    HIPCHK(c, c->h_i32.reserve((size_t)std::max(m, 2 * n) + 4));
     HIPCHK(c, c->keep_seq_d.reserve((size_t)m + 64));
     HIPCHK(c, c->col_cnt.reserve((size_t)n + 64));
     HIPCHK(c, c->h_colcnt.reserve((size_t)n + 4));
     HIPCHK(c, c->h_u8.reserve(256 + (size_t)std::max(m, n)));
-    msak::launch_overlap_keep(c->stream, c->good.p, m, n, sequence_overlap / 100.0F, c->keep_seq_d.p);
-    HIPCHK(c, hipMemsetAsync(c->col_cnt.p, 0, sizeof(int32_t) * n, c->stream));
-    msak::launch_col_nongap(c->stream, c->raw, m, n, c->ld, c->keep_seq_d.p, c->col_cnt.p);
+    {
+        ProfScope ps(c, "overlap");
+        msak::launch_overlap_small(c->stream, c->raw, m, n, c->ld, c->indet, c->gaps.p, c->indets.p, need, sequence_overlap / 100.0F,
+                                   c->good.p, c->h_i32.p, c->keep_seq_d.p, c->h_u8.p, c->col_cnt.p, c->h_colcnt.p);
+    }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_colcnt.p, c->col_cnt.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_u8.p, c->keep_seq_d.p, m, hipMemcpyDeviceToHost, c->stream));
     if ((rc = compact_fetch(c, false))) return rc;
     c->ov_vals.resize(m);
     for (int i = 0; i < m; ++i) c->ov_vals[i] = static_cast<float>(c->h_i32.p[i]) / n;

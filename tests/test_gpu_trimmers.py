@@ -469,16 +469,19 @@ def test_a_trimmer_reconfigured_after_its_first_trim():
     assert_matches_oracle(mt.trim(ali), a, gap_threshold=0.8)
 
 
-@pytest.mark.parametrize("shape", [(46, 1181), (209, 1227), (400, 900)])
+@pytest.mark.parametrize("shape", [(46, 1181), (209, 1227), (400, 900), (9, 3), (16, 1029), (1024, 301), (1025, 300), (1000, 600)])
 @pytest.mark.parametrize("args", [(80, 0.8), (40, 0.6), (95, 0.95), (10, 0.1)])
 def test_overlap_trimmer_one_wait_on_small_alignments(shape, args):
-    """OverlapTrimmer on alignments the compact front kernel takes: counts, the sequences that stay (decided on the device as the
-    host decides it) and the column counts over them come back behind ONE wait -- against the oracle, whether sequences go or not."""
+    """OverlapTrimmer on alignments the compact front kernel takes (up to 1024 sequences; one shape beyond): counts, the sequences
+    that stay (decided on the device as the host decides it) and the column counts over them come back behind ONE wait -- three
+    launches that store into pinned host memory themselves -- against the oracle, whether sequences go or not; with indeterminations,
+    a row count that is no multiple of the sixteen waves of the column counts, a width that is no multiple of four."""
     m, n = shape
     a = synth_msa(m, n, 300 + m)
     a[3, : n // 2] = ord("-")  # (a sequence that overlaps little)
     a[7] = ord("-")
-    a[7, :5] = a[6, :5]
+    a[7, : min(5, n)] = a[6, : min(5, n)]
+    a[np.random.default_rng(m + n).random((m, n)) < 0.03] = ord("X")
     ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
     seq_ov, res_ov = args
     trimmed = OverlapTrimmer(seq_ov, res_ov, platform=PLATFORM).trim(ali)
