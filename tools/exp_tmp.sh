@@ -1,1 +1,2 @@
-python -m pytest tests/test_gpu_trimmers.py -x -q -m gpu -k "one_wait" 2>&1 | tail -3
+RESIDENT=1 THREADS=3,5,3,7,8,3 python tools/sim_overlap.py 2>/dev/null
+python tools/c5_batch.py 3 5 3 4 2>/dev/null

@@ -64,6 +64,7 @@ for w in C3 C2 C4; do cp $ROOT/gpurun_out/tl/timeline_$w.txt $OUT/ 2>/dev/null; 
 { echo "== 1000 x 4000"; bash tools/pmc_kernel.sh similarity_lg python3 tools/sim_once.py 1000 4000 2000; echo "== 2000 x 10000"; bash tools/pmc_kernel.sh similarity_lg python3 tools/sim_once.py 2000 10000 1003; } > $OUT/pmc_sim.txt 2>&1
 timeout 120 python tools/sim_fixture_stamps.py > $OUT/sim_fixture_stamps.txt 2>/dev/null
 timeout 300 python tools/sim_overlap.py > $OUT/sim_overlap.jsonl 2>/dev/null
+RESIDENT=1 timeout 300 python tools/sim_overlap.py >> $OUT/sim_overlap.jsonl 2>/dev/null   # (W stays: a pass is the layout kernels + the similarity kernel)
 ls $OUT | head -60
 # keep only the small csv files (the merge back is limited to 64 MiB)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete

@@ -33,7 +33,7 @@ def worker(k, barrier, out):
     ctx.close()
 
 
-for T in (1, 2, 3, 4, 6):
+for T in [int(x) for x in os.environ.get("THREADS", "1,2,3,4,6").split(",")]:
     out = [0.0] * T
     barrier = threading.Barrier(T)
     th = [threading.Thread(target=worker, args=(k, barrier, out)) for k in range(T)]
