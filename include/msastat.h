@@ -279,7 +279,9 @@ enum {
     MSA_PATH_PIPE_ONE_STREAM = 2,   /* msa_trim's pipeline, everything on the context's stream */
     MSA_PATH_PIPE_TWO_STREAMS = 3,  /* ... codes, lists and row totals on the side stream beside the pair pass */
     MSA_PATH_PIPE_COMPACT = 4,      /* the compact pipeline of a small alignment: front, pairs, [identity], similarity */
-    MSA_PATH_PIPE_COMPACT_GAPS = 5  /* its front kernel alone (a trim that needs the gap statistics only) */
+    MSA_PATH_PIPE_COMPACT_GAPS = 5, /* its front kernel alone (a trim that needs the gap statistics only) */
+    MSA_PATH_PIPE_COMPACT_SORTED = 6 /* the compact pipeline with the columns dealt to the similarity kernel by weight (from 513
+                                        sequences on): the host sorts them behind the front kernel's event, while the pair pass runs */
 };
 enum {
     MSA_PATH_SIM_NONE = 0,

@@ -477,11 +477,11 @@ __global__ __launch_bounds__(256) void similarity_flat_kernel(LgAlign A, const f
 // Block 0 zeroes the device's flag words, the identity statistics' ticket and the pair pass's row sums (nothing of this launch
 // touches them).  Results go to the state block's mirror in pinned host memory as well (`hres`: same offsets; the rows' totals,
 // the slots, MDK and Q only there): no copy back, the host folds the slots into the two flag words after the wait.
-constexpr int COMPACT_ROWS_MAX = 512;  // rows of the LDS code array of a column block
+// (ROWS: rows of the LDS code array of a column block -- 512: 33 KB, or 1024: 66 KB of the CU's 160)
 constexpr int COMPACT_TEAMS_MAX = 4;  // 64-row tiles a column block works on at once (a team of four waves each)
-template <bool SIM>
+template <bool SIM, int ROWS>
 __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b) {
-    constexpr int LDC = COMPACT_ROWS_MAX + 4;  // bytes per column (4 past a multiple of 128: consecutive columns on different banks)
+    constexpr int LDC = ROWS + 4;  // bytes per column (4 past a multiple of 128: consecutive columns on different banks)
     constexpr int TM = COMPACT_TEAMS_MAX;
     __shared__ uint8_t lut[256];
     __shared__ uint8_t codes[SIM ? 64 * LDC : 4];
@@ -642,7 +642,7 @@ __device__ __forceinline__ void compact_column_block(const CompactArgs &a, int b
         }
     }
 }
-template <bool SIM>
+template <bool SIM, int ROWS>
 __global__ __launch_bounds__(256 * COMPACT_TEAMS_MAX) void compact_front_kernel(CompactArgs a) {
     const int b = (int)blockIdx.x;
     const int ncb = a.ncols_pad / 64;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256 * COMPACT_TEAMS_MAX) void compact_front_kernel(
             for (int i = threadIdx.x; i < a.m_pad + 64; i += (int)blockDim.x) a.wsum[i] = 0u;
         }
     }
-    if (b < ncb) compact_column_block<SIM>(a, b);
+    if (b < ncb) compact_column_block<SIM, ROWS>(a, b);
     else if (threadIdx.x < 256) row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
 }
 
@@ -796,8 +796,9 @@ size_t compact_scratch_words(int m, int n) { return (size_t)2 + (std::max(m, 1) 
 void launch_compact_front(hipStream_t s, const CompactArgs &a) {
     const unsigned blocks = (unsigned)(a.ncols_pad / 64 + (a.m + 3) / 4);
     const int teams = std::min(COMPACT_TEAMS_MAX, std::max(1, (a.m + 63) / 64));  // a team of four waves per 64-row tile, up to four
-    if (a.sim) compact_front_kernel<true><<<blocks, 256 * teams, 0, s>>>(a);
-    else compact_front_kernel<false><<<blocks, 256 * teams, 0, s>>>(a);
+    if (a.sim && a.m > 512) compact_front_kernel<true, 1024><<<blocks, 256 * teams, 0, s>>>(a);
+    else if (a.sim) compact_front_kernel<true, 512><<<blocks, 256 * teams, 0, s>>>(a);
+    else compact_front_kernel<false, 512><<<blocks, 256 * teams, 0, s>>>(a);
 }
 // the flat similarity kernel: any alignment of up to FLAT_ROWS_MAX rows whose codes exist (A.codeT, A.wup, A.mdk_out, A.q_out)
 int flat_rows_max() { return FLAT_ROWS_MAX; }

@@ -341,7 +341,7 @@ int similarity(msa_ctx *c, const int32_t *vhash, const float *dist, int npos, co
                 (void)hipStreamSynchronize(c->stream);
                 return rc;
             }
-            c->paths[1] = MSA_PATH_PIPE_COMPACT;
+            c->paths[1] = c->compact_sorted ? MSA_PATH_PIPE_COMPACT_SORTED : MSA_PATH_PIPE_COMPACT;
             return fetch_similarity_finish(c, c->n, mdk_out, q_out, detail);
         }
     }

@@ -84,22 +84,29 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 
 // ---- the compact pipeline of a small alignment -------------------------------------------------------------------------
 // A trim of 46 x 1181 residues spent 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
-// 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to 512 sequences, with every
-// column's wave resident at once (no column order needed) and no gap window, the same statistics take THREE launches and no copy
+// 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to 1024 sequences (512 until late in round 5),
+// with every column's wave resident at once and no gap window, the same statistics take THREE launches and no copy
 // (msak::CompactArgs):
 //   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes (+ lists; the ">= 80 % gaps" cut
 //             from the block's own counts), all from one pass over the rows by independent blocks; no memset in front of it;
 //   pairs  -- the ordinary pair pass, whose tiles also add up the rows' weight sums (the predictor's input);
 //   [automated1: the identity statistics with the selectMethod gate, one launch]
-//   sim    -- up to `flat_max_m` sequences the flat kernel, else the wave-per-column kernel over the columns in their own order;
+//   sim    -- up to `flat_max_m` sequences the flat kernel, else the wave-per-column kernel over the columns in their own order --
+//             from 513 sequences on dealt by weight: the host sorts them behind the front kernel's event while the pair pass runs;
 //             the wave that finishes a column writes its MDK and Q;
 //   every result is stored by the kernels into a mirror of the state block in pinned host memory (h_cres): one wait, then the
 //   host folds the front kernel's per-block verdicts into the two flag words.
 // The kernels' arithmetic is the ordinary path's (the same device functions); MSA_COMPACT=0 switches the pipeline off.
+#ifndef MSA_COMPACT_SIM_MAX_M  // (A/B builds: tools/build_variant.sh)
+#define MSA_COMPACT_SIM_MAX_M 1024
+#endif
+#ifndef MSA_COMPACT_SORT_FROM_M  // sequences from which on the similarity kernel of the pipeline gets its columns dealt by weight
+#define MSA_COMPACT_SORT_FROM_M 513
+#endif
 bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
     const msak::Tuning &t = c->tuning;
     return t.compact != 0 && gap_hw == 0 && t.sim_kernel == 0 && (t.sim_mode & 64) == 0 && t.lg_rounds < 0 && t.lg_split == 0 &&
-           t.lg_big == 0 && c->m >= 2 && c->m <= 512 && c->n <= c->cus * 20 &&
+           t.lg_big == 0 && c->m >= 2 && c->m <= MSA_COMPACT_SIM_MAX_M && c->n <= c->cus * 20 &&
            msak::pair_pipe_regime(c->m, c->m_pad);
 }
 bool compact_gaps_applies(const msa_ctx *c) {
@@ -267,9 +274,20 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     // (compact_sim_applies keeps the shapes and switches out for which the wave-per-column kernel would not finish the columns
     // itself; should the two ever disagree, nothing has been enqueued yet and the callers take the ordinary pipeline)
     if (!flat && !msak::lg_finishes(L, c->cus)) return MSA_E_FALLBACK;
+    // From 513 sequences on the columns are dealt to the similarity kernel's waves BY WEIGHT, as in the ordinary pipeline: a launch
+    // of ~1000 rows takes what one wave takes for its heaviest column plus what the deal leaves uneven, and over the columns as they
+    // lie that is 0.40 instead of 0.33 ms at 1000 x 4000 (profiles/r05_compact_1024_ab.txt).  The host sorts while the pair pass
+    // runs: it waits for the front kernel alone (an event), takes the counts from the mirror, and the list goes up in front of
+    // the similarity kernel -- every column is in it, the ones the ">= 80 % gaps" rule cuts last (their waves write the zeros).
+    const bool sorted = !flat && m >= MSA_COMPACT_SORT_FROM_M;
+    c->compact_sorted = sorted;
     {
         ProfScope ps(c, "front");
         msak::launch_compact_front(c->stream, a);
+    }
+    if (sorted) {
+        if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_rowtot, c->stream));
     }
     {
         ProfScope ps(c, "pairs");
@@ -279,6 +297,21 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     if (gated) {
         ProfScope ps(c, "idstats");
         msak::launch_compact_identity(c->stream, a);
+    }
+    if (sorted) {
+        HIPCHK(c, hipEventSynchronize(c->ev_rowtot));
+        const int32_t *H = c->h_cres.p;
+        c->h_gaps.assign(H + ST_WORDS, H + ST_WORDS + n);
+        c->h_indets.assign(H + ST_WORDS + c->state_npad, H + ST_WORDS + c->state_npad + n);
+        SimOrder ord;
+        if ((rc = build_sim_order(c, nullptr, &ord))) return rc;
+        int32_t *list = c->h_simcols.p;
+        int k = ord.npad;
+        for (int j = 0; j < n; ++j)
+            if (((float)c->h_gaps[j] / (float)m) >= 0.8f) list[k++] = j;
+        ord.npad = k;  // (= n)
+        if ((rc = sim_order_enqueue(c, ord, c->stream))) return rc;
+        L.cols = c->simcols.p;
     }
     {
         ProfScope ps(c, "sim");
@@ -415,7 +448,7 @@ int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *
         }
         gaps_w = c->h_gaps;  // (no window)
         pipe_waited = true;  // (compact_begin waits itself: there is nothing for the host to do in between)
-        c->paths[1] = MSA_PATH_PIPE_COMPACT;
+        c->paths[1] = c->compact_sorted ? MSA_PATH_PIPE_COMPACT_SORTED : MSA_PATH_PIPE_COMPACT;
         trace.mark("compact pipeline");
     } else if (pipelined) {
         rc = sim_pipeline_begin(c, p, gap_hw, method == MSA_METHOD_AUTOMATED1, gaps_w);
