@@ -85,7 +85,7 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 // ---- the compact pipeline of a small alignment -------------------------------------------------------------------------
 // A trim of 46 x 1181 residues spent 0.15 ms on ~18 queue operations (memsets, a dozen launches, four copies, events) around
 // 0.08 ms of kernels (profiles/r04_small_latency_ordinary_launch_sequence.jsonl).  Up to 1024 sequences (512 until late in round 5),
-// with every column's wave resident at once and no gap window, the same statistics take THREE launches and no copy
+// and no gap window, the same statistics take THREE launches and no copy
 // (msak::CompactArgs):
 //   front  -- gap / indetermination counts, residues per sequence, planes, column-major codes (+ lists; the ">= 80 % gaps" cut
 //             from the block's own counts), all from one pass over the rows by independent blocks; no memset in front of it;
@@ -100,13 +100,16 @@ int sim_pipeline_begin(msa_ctx *c, const msa_trim_params *p, int gap_hw, bool ga
 #ifndef MSA_COMPACT_SIM_MAX_M  // (A/B builds: tools/build_variant.sh)
 #define MSA_COMPACT_SIM_MAX_M 1024
 #endif
+#ifndef MSA_COMPACT_ANY_N  // 1: any number of columns (beyond 20 per compute unit -- more waves than slots -- always dealt by weight)
+#define MSA_COMPACT_ANY_N 1
+#endif
 #ifndef MSA_COMPACT_SORT_FROM_M  // sequences from which on the similarity kernel of the pipeline gets its columns dealt by weight
 #define MSA_COMPACT_SORT_FROM_M 513
 #endif
 bool compact_sim_applies(const msa_ctx *c, int gap_hw) {
     const msak::Tuning &t = c->tuning;
     return t.compact != 0 && gap_hw == 0 && t.sim_kernel == 0 && (t.sim_mode & 64) == 0 && t.lg_rounds < 0 && t.lg_split == 0 &&
-           t.lg_big == 0 && c->m >= 2 && c->m <= MSA_COMPACT_SIM_MAX_M && c->n <= c->cus * 20 &&
+           t.lg_big == 0 && c->m >= 2 && c->m <= MSA_COMPACT_SIM_MAX_M && (MSA_COMPACT_ANY_N || c->n <= c->cus * 20) &&
            msak::pair_pipe_regime(c->m, c->m_pad);
 }
 bool compact_gaps_applies(const msa_ctx *c) {
@@ -279,7 +282,7 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     // lie that is 0.40 instead of 0.33 ms at 1000 x 4000 (profiles/r05_compact_1024_ab.txt).  The host sorts while the pair pass
     // runs: it waits for the front kernel alone (an event), takes the counts from the mirror, and the list goes up in front of
     // the similarity kernel -- every column is in it, the ones the ">= 80 % gaps" rule cuts last (their waves write the zeros).
-    const bool sorted = !flat && m >= MSA_COMPACT_SORT_FROM_M;
+    const bool sorted = !flat && (m >= MSA_COMPACT_SORT_FROM_M || n > c->cus * 20);
     c->compact_sorted = sorted;
     {
         ProfScope ps(c, "front");

@@ -5,7 +5,7 @@ the table below pins, shape by shape on both sides of every size threshold, the 
 threshold in pytrimal_amd/csrc fails this file until the table is updated with it.
 
 Thresholds covered (DESIGN.md section 11 lists them): rows read in place up to 96 KB; flat similarity kernel up to 128 rows
-(96 beyond 2560 columns: both waves of every column resident); compact pipeline up to 1024 rows and 5120 columns, from 513 rows on
+(96 beyond 2560 columns: both waves of every column resident); compact pipeline up to 1024 rows, from 513 rows or 5121 columns on
 with the columns dealt by weight; side stream from m^2 n = 2 * 10^9; a launch every six rounds from 1800 rows; a workgroup per column from 2048 rows when the columns leave
 wave slots free; front kernel alone for gap-only trims up to 1024 rows and 4 MB; two rows per lane in the pair pass from 4096 rows."""
 import numpy as np
@@ -63,15 +63,16 @@ STRICT = [
     # --- rows read in place up to 96 KB (m x the 64-byte padded row)
     (96, 1024, dict(upload="in_place", pipeline="compact", sim_kernel="flat")),
     (97, 1024, dict(upload="linear", pipeline="compact", sim_kernel="flat")),
-    # --- compact pipeline: columns as they lie up to 512 rows, dealt by weight from 513; the ordinary pipeline from 1025 rows or
-    #     beyond cus * 20 columns
+    # --- compact pipeline: columns as they lie up to 512 rows and cus * 20 columns (every wave resident), dealt by weight beyond
+    #     either; the ordinary pipeline from 1025 rows
     (512, 1000, dict(upload="packed", pipeline="compact", sim_writes_mdk=1, pair_kernel="pipe", **LG1)),
     (513, 1000, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, pair_kernel="pipe", **LG1)),
     (300, 5120, dict(upload="linear", pipeline="compact", sim_writes_mdk=1, **LG1)),
-    (300, 5121, dict(upload="packed", pipeline="one_stream", sim_writes_mdk=0, **LG1)),
+    (300, 5121, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
+    (64, 20000, dict(pipeline="compact", sim_kernel="flat", sim_writes_mdk=1)),
     (1000, 4000, dict(pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, **LG1)),
     (1024, 2000, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
-    (1024, 5121, dict(pipeline="two_streams", sim_writes_mdk=0, **LG1)),
+    (1024, 5121, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
     # --- side stream from m^2 n = 2e9
     (1025, 1903, dict(pipeline="one_stream", **LG1)),
     (1025, 1904, dict(pipeline="two_streams", **LG1)),
@@ -124,7 +125,7 @@ def test_default_dispatch_of_a_gap_only_trim(default_ctx, m, n, pipe):
 # msa_similarity by itself: the compact pipeline where it applies, else its own serial launch sequence
 SIMILARITY = [(100, 700, dict(pipeline="compact", sim_kernel="flat")), (400, 700, dict(pipeline="compact", sim_writes_mdk=1, **LG1)),
               (513, 700, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)), (1025, 700, dict(pipeline="serial", sim_writes_mdk=0, **LG1)),
-              (400, 5121, dict(pipeline="serial", **LG1))]
+              (400, 5121, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1))]
 
 
 @pytest.mark.parametrize("m,n,want", SIMILARITY, ids=[f"{m}x{n}" for m, n, _ in SIMILARITY])
