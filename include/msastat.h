@@ -271,7 +271,8 @@ enum {
     MSA_PATH_UPLOAD_LINEAR = 2,   /* rows already at the device pitch: one linear copy */
     MSA_PATH_UPLOAD_PITCHED = 3,  /* one pitched copy straight from the caller's rows */
     MSA_PATH_UPLOAD_PACKED = 4,   /* packed into pinned pieces, each sent as soon as it is packed */
-    MSA_PATH_UPLOAD_ATTACHED = 5  /* msa_attach_device */
+    MSA_PATH_UPLOAD_ATTACHED = 5, /* msa_attach_device */
+    MSA_PATH_UPLOAD_REPITCHED = 6 /* a contiguous pageable matrix of odd-sized rows: one linear copy, then a kernel lays the rows out at the device pitch */
 };
 enum {
     MSA_PATH_PIPE_NONE = 0,

@@ -451,7 +451,7 @@ class Context:
 
     PATH_KEYS = ("upload", "pipeline", "sim_kernel", "sim_waves_per_column", "sim_launches", "sim_writes_mdk", "pair_kernel", "pair_waves_per_tile")
     PATH_NAMES = {
-        "upload": ("none", "in_place", "linear", "pitched", "packed", "attached"),
+        "upload": ("none", "in_place", "linear", "pitched", "packed", "attached", "repitched"),
         "pipeline": ("none", "serial", "one_stream", "two_streams", "compact", "compact_gaps", "compact_sorted"),
         "sim_kernel": ("none", "flat", "lg", "lg_big", "seq", "cols"),
         "pair_kernel": ("none", "pipe", "two_rows"),

@@ -116,6 +116,7 @@ struct msa_ctx {
     int64_t ld = 0;
     uint8_t indet = 'X';
     const uint8_t *raw = nullptr;  // device
+    DevBuf<uint8_t> raw_lin;            // a contiguous matrix as it lies on the host, on its way into raw_own's pitch (upload_packed: MSA_PATH_UPLOAD_REPITCHED)
     DevBuf<uint8_t> raw_own;
 
     // derived device data + validity flags

@@ -160,7 +160,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     prof_collect(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     c->raw_own.release(); c->planes.release(); c->state.release(); c->h_flags.release(); c->tables.release(); c->ident.release();
-    c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
+    c->raw_lin.release(); c->wmat.release(); c->wlow.release(); c->wbar.release(); c->codeT.release(); c->simcols.release(); c->h_simcols.release(); c->bx_off.release(); c->bx_trow.release(); c->bx_nvalid.release(); c->hit.release(); c->dst.release(); c->row_avg.release(); c->row_max.release(); c->row_min.release();
     c->gaps_w.release(); c->cscratch.release(); c->h_cres.release();
     c->mdk.release(); c->simnum.release(); c->simden.release(); c->simstate.release(); c->col_ok.release();
     c->good.release(); c->row_cnt.release(); c->col_cnt.release(); c->lengths.release(); c->pairs.release();
@@ -399,6 +399,18 @@ static int upload_packed(msa_ctx *c, const uint8_t *rowmajor, int32_t m, int32_t
             c->paths[0] = MSA_PATH_UPLOAD_PITCHED;
             HIPCHK(c, hipMemcpy2DAsync(c->raw_own.p, (size_t)c->ld, rowmajor, (size_t)ld, (size_t)n, (size_t)m, hipMemcpyHostToDevice,
                                        c->stream));
+        } else if (c->tuning.upload_direct && (size_t)m * (size_t)ld >= ((size_t)1 << 20) && (size_t)(ld - n) * 8 <= (size_t)ld) {
+            // a contiguous matrix of odd-sized rows (5000 x 5000 from pageable memory: the BASELINE's C4), a megabyte or more and
+            // not much wider than its rows: ONE linear copy as it lies -- the runtime stages pageable memory at the link's rate,
+            // which the packed pieces below do not reach (they are packed by host threads first) -- and a kernel lays the rows out
+            // at the device pitch, padding zeroed (round 5, late: profiles/r05_upload.txt)
+            c->paths[0] = MSA_PATH_UPLOAD_REPITCHED;
+            c->raw_own.tag = 0;
+            const size_t bytes = (size_t)(m - 1) * (size_t)ld + (size_t)n;
+            HIPCHK(c, c->raw_lin.reserve(bytes + 256));
+            HIPCHK(c, hipMemcpyAsync(c->raw_lin.p, rowmajor, bytes, hipMemcpyHostToDevice, c->stream));
+            msak::launch_repitch_rows(c->stream, c->raw_lin.p, ld, c->raw_own.p, c->ld, m, n);
+            HIPCHK(c, hipGetLastError());
         } else {
             c->paths[0] = MSA_PATH_UPLOAD_PACKED;
             c->raw_own.tag = 0;

@@ -146,6 +146,9 @@ size_t compact_scratch_words(int m, int n);
 size_t compact_slot_words(int n);
 void launch_compact_front(hipStream_t s, const CompactArgs &a);
 void launch_compact_identity(hipStream_t s, const CompactArgs &a);
+// rows of n bytes, `ld_src` apart, into rows `ld_dst` apart (a multiple of 16, >= n), the padding zeroed: a contiguous host matrix
+// that came up in one linear copy, laid out at the device pitch
+void launch_repitch_rows(hipStream_t s, const uint8_t *src, int64_t ld_src, uint8_t *dst, int64_t ld_dst, int m, int n);
 // OverlapTrimmer behind the front kernel (m <= 1024): the sequences' overlap counts, the device's decision, the residues per column
 // over the sequences that stay -- two launches, every result stored into device AND pinned host memory (h_*)
 void launch_overlap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, uint8_t indet, const int32_t *gaps,

@@ -744,6 +744,28 @@ __global__ __launch_bounds__(1024) void col_nongap_small_kernel(const uint8_t *_
     }
 }
 
+// A contiguous host matrix whose rows are no multiple of 16 bytes (5000 x 5000: the BASELINE's C4) came up in ONE linear copy;
+// this lays the rows out at the device pitch: a thread per 16 destination bytes (byte loads: a source row starts anywhere),
+// the padding columns zeroed.  50 MB through the HBM for a 25 MB matrix: ~ 20 us.
+__global__ __launch_bounds__(256) void repitch_rows_kernel(const uint8_t *__restrict__ src, int64_t ld_src, uint8_t *__restrict__ dst,
+                                                           int64_t ld_dst, int m, int n) {
+    const int64_t per_row = ld_dst >> 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= per_row * m) return;
+    const int row = (int)(t / per_row);
+    const int c0 = (int)(t - (int64_t)row * per_row) * 16;
+    const uint8_t *p = src + (size_t)row * ld_src + c0;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (c0 + 16 <= n) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    } else {
+        for (int i = 0; c0 + i < n; ++i) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    }
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4 *>(dst + (size_t)row * ld_dst + c0) = u4{w[0], w[1], w[2], w[3]};
+}
+
 }  // namespace
 
 
@@ -828,6 +850,10 @@ void launch_overlap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64
 void launch_col_nongap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq, int32_t *col_nongap,
                              int32_t *h_col_nongap) {
     col_nongap_small_kernel<<<(unsigned)((ld / 4 + 63) / 64), 1024, 0, s>>>(raw, m, n, ld, keep_seq, col_nongap, h_col_nongap);
+}
+void launch_repitch_rows(hipStream_t s, const uint8_t *src, int64_t ld_src, uint8_t *dst, int64_t ld_dst, int m, int n) {
+    const int64_t threads = (ld_dst >> 4) * (int64_t)m;
+    if (threads > 0) repitch_rows_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(src, ld_src, dst, ld_dst, m, n);
 }
 void launch_compact_identity(hipStream_t s, const CompactArgs &a) {
     compact_identity_kernel<<<(unsigned)((a.m + 3) / 4), 256, 0, s>>>(a);

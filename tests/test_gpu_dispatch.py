@@ -68,7 +68,8 @@ STRICT = [
     (512, 1000, dict(upload="packed", pipeline="compact", sim_writes_mdk=1, pair_kernel="pipe", **LG1)),
     (513, 1000, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, pair_kernel="pipe", **LG1)),
     (300, 5120, dict(upload="linear", pipeline="compact", sim_writes_mdk=1, **LG1)),
-    (300, 5121, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
+    (300, 5121, dict(upload="repitched", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),   # 1.5 MB of 5121-byte rows: one linear copy + a kernel
+    (200, 5121, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),      # (below a megabyte: packed pieces)
     (64, 20000, dict(pipeline="compact", sim_kernel="flat", sim_writes_mdk=1)),
     (1000, 4000, dict(pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, **LG1)),
     (1024, 2000, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
@@ -159,6 +160,38 @@ def test_pitched_upload_of_aligned_rows(default_ctx):
     ctx.upload(c, ord("X"))
     assert np.array_equal(ctx.gaps(), oracle.gaps(a)[0])
     assert ctx.last_paths()["upload"] == "packed"
+
+
+def test_linear_copy_and_repitch_of_odd_sized_rows(default_ctx):
+    """a contiguous matrix of a megabyte or more whose rows are no multiple of 16 bytes (the BASELINE's 5000 x 5000) goes up in ONE
+    linear copy and a kernel lays the rows out at the device pitch -- also through a view a few columns narrower than its rows;
+    a view much narrower than its rows, and anything below a megabyte, takes the packed pieces"""
+    m, n = 1100, 1001
+    a = synth_msa(m, n, 78)
+    ctx = default_ctx
+    ctx.upload(a, ord("X"))
+    assert ctx.last_paths()["upload"] == "repitched"
+    assert np.array_equal(ctx.gaps(), oracle.gaps(a)[0])
+    res, seq, _ = ctx.trim(params("strict"))
+    ores, oseq, _ = oracle.trim(a, method="strict")
+    assert np.array_equal(res, ores) and np.array_equal(seq, oseq)
+    wide = np.full((m, n + 5), ord("A"), dtype=np.uint8)
+    wide[:, :n] = a
+
+    def upload_view(cols):  # (the C ABI itself: rows `n + 5` bytes apart, `cols` of them used -- Context.upload would copy the view)
+        _lib.check(ctx.lib, ctx.h, ctx.lib.msa_upload_packed(ctx.h, _lib.ptr(wide), m, cols, n + 5, ord("X")))
+        ctx.shape = (m, cols)
+
+    upload_view(n)
+    assert ctx.last_paths()["upload"] == "repitched"
+    assert np.array_equal(ctx.gaps(), oracle.gaps(a)[0])
+    upload_view(101)  # a tenth of every row: packed pieces
+    assert ctx.last_paths()["upload"] == "packed"
+    assert np.array_equal(ctx.gaps(), oracle.gaps(np.ascontiguousarray(a[:, :101]))[0])
+    big = synth_msa(5000, 5000, 1004)[:, :4999]   # (C4's shape, one column short: rows of 4999 bytes, 5000 apart)
+    ctx.upload(big, ord("X"))
+    assert ctx.last_paths()["upload"] == "repitched"
+    assert np.array_equal(ctx.gaps(), (big == ord("-")).sum(axis=0))
 
 
 def test_windowed_similarity_after_a_compact_trim_on_the_same_upload(default_ctx):

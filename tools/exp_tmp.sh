@@ -1,11 +1,6 @@
-cp pytrimal_amd/libmsastat_hip.so /tmp/shipped.so
-export SIZES=100x8000,200x6000,300x10000,500x8000,700x8000,1000x8000,1000x16000,64x20000
-python tools/sim_shapes.py 500 8000 3 1000 8000 5 200 6000 7 2>&1 | grep -v amdgpu.ids | cut -c1-330
-for rep in 1 2; do
-for v in shipped n5120; do
-  if [ $v = shipped ]; then cp /tmp/shipped.so pytrimal_amd/libmsastat_hip.so; else cp tools/_variants/$v.so pytrimal_amd/libmsastat_hip.so; fi
-  echo "== $v ($rep)"
-  python tools/small_latency.py 2>&1 | grep -v amdgpu.ids | grep "strict" | cut -c1-230
-done
-done
-cp /tmp/shipped.so pytrimal_amd/libmsastat_hip.so
+python -m pytest tests/test_gpu_dispatch.py -x -q -m gpu 2>&1 | tail -4
+python tools/upload_time.py 2>&1 | grep -v amdgpu.ids
+MSA_UPLOAD_DIRECT=0 python tools/upload_time.py 2>&1 | grep -v amdgpu.ids | grep pageable
+python bench.py --workload C4 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+r = json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: r[k] for k in r if 'ms_per_step' in k})"
