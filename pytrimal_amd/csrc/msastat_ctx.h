@@ -105,6 +105,7 @@ struct msa_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_digest = nullptr;  // behind the copies of row_digest_begin
     hipEvent_t ev_rowtot = nullptr;  // behind the copy of stage_row_totals
+    hipEvent_t ev_front = nullptr;   // behind the compact pipeline's front kernel (compact_begin sorts the columns from its counts)
     PinBuf<int32_t> h_len;           // ungapped lengths on their way to the host
     hipEvent_t ev_gaps = nullptr;  // behind the staged copy of the gap counts: waiting for it does not wait for later work
     hipEvent_t ev_upload = nullptr;  // behind the copies of msa_upload_packed_async

@@ -171,6 +171,7 @@ void msa_ctx_destroy(msa_ctx *c) {
     if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
     if (c->ev_digest) (void)hipEventDestroy(c->ev_digest);
     if (c->ev_rowtot) (void)hipEventDestroy(c->ev_rowtot);
+    if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->stream2) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipEventDestroy(c->ev_fork);

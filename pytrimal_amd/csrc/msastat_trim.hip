@@ -289,8 +289,8 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
         msak::launch_compact_front(c->stream, a);
     }
     if (sorted) {
-        if (!c->ev_rowtot) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rowtot, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->ev_rowtot, c->stream));
+        if (!c->ev_front) HIPCHK(c, hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_front, c->stream));
     }
     {
         ProfScope ps(c, "pairs");
@@ -302,7 +302,7 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
         msak::launch_compact_identity(c->stream, a);
     }
     if (sorted) {
-        HIPCHK(c, hipEventSynchronize(c->ev_rowtot));
+        HIPCHK(c, hipEventSynchronize(c->ev_front));
         const int32_t *H = c->h_cres.p;
         c->h_gaps.assign(H + ST_WORDS, H + ST_WORDS + n);
         c->h_indets.assign(H + ST_WORDS + c->state_npad, H + ST_WORDS + c->state_npad + n);
