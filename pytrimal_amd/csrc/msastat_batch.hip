@@ -147,7 +147,7 @@ bool engine_takes(const msa_batch *b, int32_t k, const msa_trim_params *ref) {
 int engine_parallel_for(msa_batch *b, int32_t total, std::function<void(int32_t, int)> fn);
 
 struct EngineLayout {  // byte offsets of one alignment's arrays in the arena
-    size_t raw, planes, ident, w, wlow, wbar, row_avg, row_max, codeT, codeR, off, trow, nvalid, simnum, simden, simstate, end;
+    size_t raw, planes, ident, w, wlow, wbar, row_avg, row_max, codeT, codeR, off, trow, nvalid, simnum, simden, simstate, cols, end;
 };
 
 int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<int32_t> &ks) {
@@ -186,6 +186,11 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     // column-major codes, no lists
     const bool cols_mode = max_m <= e->cols_max_m;
     mix(cols_mode);
+    // the wave-per-column kernel's columns dealt by weight, alignment by alignment (a counting sort per alignment on the device,
+    // behind the gap counts: workgroups of four columns of like weight, the heaviest first -- over the columns as they lie a
+    // workgroup's slots are held until its heaviest column is done: profiles/r05_engine_sort_ab.txt)
+    const bool sort_cols = !cols_mode && any_sim >= 0 && max_m <= 15000;  // (the sort's bins live in LDS)
+    mix(sort_cols);
     size_t off = align_up(res_words * 4, 4096);
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -255,6 +260,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         y.simnum = take(((size_t)n + 64) * 4);
         y.simden = take(((size_t)n + 64) * 4);
         y.simstate = multi ? take(msak::lg_state_floats(n) * 4) : 0;
+        y.cols = sort_cols ? take(((size_t)n + 64) * 4) : 0;  // (the wave-per-column kernel's columns by weight: sort_columns_batch)
         y.end = off;
     }
     if (std::find(packed.begin(), packed.end(), 1) != packed.end()) stage_bytes = raw_bytes;  // (the staging mirrors the raw region)
@@ -328,10 +334,11 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         g.wlow = d.wlow, g.wup = d.w, g.wbar = d.wbar, g.num_out = d.simnum, g.den_out = d.simden;
         g.state = multi ? reinterpret_cast<float *>(A + y.simstate) : nullptr;
         g.gate = d.gated ? d.flags + ST_GATE : nullptr;
-        g.cols = nullptr;
+        const bool sim = engine_needs(b->params + k) == 2;
+        // (only the alignments whose trim runs the similarity kernel: max_m -- the sort's LDS bins -- is taken over those)
+        g.cols = sort_cols && sim ? reinterpret_cast<const int32_t *>(A + y.cols) : nullptr;
         g.ldk = d.ldk, g.m = m, g.n = n, g.ldw = d.ldw, g.ncols = n;
         lt[i] = g;
-        const bool sim = engine_needs(b->params + k) == 2;
         auto add = [&](int f, int blocks) { pf[(size_t)f * (K + 1) + i + 1] = pf[(size_t)f * (K + 1) + i] + ((sim || f <= F_ROWTOT) ? blocks : 0); };
         add(F_FETCH, fetch[i] ? (int)(((int64_t)m * (d.ld / 16) + 255) / 256) : 0);
         add(F_GAPS, (int)((d.ld / 4 + 255) / 256) * ((m + 63) / 64));
@@ -393,6 +400,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     }
     msak::launch_fetch_rows_batch(st, bt_d, PF(F_FETCH), K, NB(F_FETCH));
     msak::launch_gap_counts_batch(st, bt_d, PF(F_GAPS), K, NB(F_GAPS));
+    if (sort_cols) msak::launch_sort_columns_batch(st, bt_d, lt_d, K, max_m);
     msak::launch_row_nongap_batch(st, bt_d, PF(F_ROWTOT), K, NB(F_ROWTOT));
     msak::launch_prep_planes_batch(st, bt_d, PF(F_PLANES), K, NB(F_PLANES));
     int min_nchunk = 1 << 30;

@@ -171,6 +171,8 @@ void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t 
 void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, const uint8_t *lut);
 void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab);
+// per alignment of a group: its columns by valid rows, most first, into lg[a].cols (a counting sort in LDS: max_m + 2 bins)
+void launch_sort_columns_batch(hipStream_t s, const BAlign *table, const LgAlign *lg, int K, int max_m);
 void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *prefix_encode, int blocks_encode, const int32_t *prefix_compact,
                             int blocks_compact, int K, const uint8_t *lut, int npos);
 void launch_w_row_means(hipStream_t s, const float *wup, int m, int ldw, float *wbar);

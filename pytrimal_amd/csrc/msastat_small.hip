@@ -744,6 +744,45 @@ __global__ __launch_bounds__(1024) void col_nongap_small_kernel(const uint8_t *_
     }
 }
 
+// msa_trim_batch's engine: the columns of every alignment of a group by weight (valid rows, most first; the columns the ">= 80 %
+// gaps" rule cuts have the fewest and come last), for the wave-per-column kernel's grid.  A workgroup per alignment, a counting sort
+// in LDS: bins by gaps + indeterminations, exclusive prefix, scatter (the order inside a bin is whatever the atomics make it: any
+// order is correct, the deal only sets the launch's time).
+__global__ __launch_bounds__(256) void sort_columns_batch_kernel(const BAlign *__restrict__ table, const LgAlign *__restrict__ lg) {
+    extern __shared__ int bins[];  // [m + 2]
+    __shared__ int part[256];
+    const BAlign d = batch_desc(table, (int)blockIdx.x);
+    int32_t *cols = const_cast<int32_t *>(lg[blockIdx.x].cols);
+    if (!cols) return;
+    const int m = d.m, n = d.n, nb = m + 2, tid = (int)threadIdx.x;
+    for (int i = tid; i < nb; i += 256) bins[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) atomicAdd(&bins[min(d.gaps[j] + d.indets[j], m) + 1], 1);
+    __syncthreads();
+    // inclusive prefix over the bins: a chunk per thread, the chunks' totals by one wave-sized pass
+    const int per = (nb + 255) / 256, lo = min(tid * per, nb), hi = min(lo + per, nb);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += bins[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int v = part[t];
+            part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        run += bins[i];
+        bins[i] = run;  // bins[k + 1] = columns with a key <= k; bins[k] = where key k starts
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) cols[atomicAdd(&bins[min(d.gaps[j] + d.indets[j], m)], 1)] = j;
+}
+
 // A contiguous host matrix whose rows are no multiple of 16 bytes (5000 x 5000: the BASELINE's C4) came up in ONE linear copy;
 // this lays the rows out at the device pitch: a thread per 16 destination bytes (byte loads: a source row starts anywhere),
 // the padding columns zeroed.  50 MB through the HBM for a 25 MB matrix: ~ 20 us.
@@ -850,6 +889,9 @@ void launch_overlap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64
 void launch_col_nongap_small(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *keep_seq, int32_t *col_nongap,
                              int32_t *h_col_nongap) {
     col_nongap_small_kernel<<<(unsigned)((ld / 4 + 63) / 64), 1024, 0, s>>>(raw, m, n, ld, keep_seq, col_nongap, h_col_nongap);
+}
+void launch_sort_columns_batch(hipStream_t s, const BAlign *table, const LgAlign *lg, int K, int max_m) {
+    if (K > 0) sort_columns_batch_kernel<<<(unsigned)K, 256, (size_t)(max_m + 2) * sizeof(int), s>>>(table, lg);
 }
 void launch_repitch_rows(hipStream_t s, const uint8_t *src, int64_t ld_src, uint8_t *dst, int64_t ld_dst, int m, int n) {
     const int64_t threads = (ld_dst >> 4) * (int64_t)m;
