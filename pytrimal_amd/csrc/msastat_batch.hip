@@ -57,7 +57,8 @@ struct msa_batch {
 // sim_pipeline_begin (strict, strictplus, automated1, a manual similarity threshold; no windows; fewer than ~4100 sequences,
 // where the pair pass has one regime) in groups: ONE device arena per group laid out alignment after alignment, ONE table of
 // descriptors, ONE launch per kernel family with blockIdx -> (alignment, block) through prefix sums, the similarity grid over
-// every column of every alignment, ONE copy of every result vector back, and nothing in between that needs the host.  Two
+// every column of every alignment (each alignment's columns by weight: a counting sort per alignment on the device, behind the
+// gap counts), ONE copy of every result vector back, and nothing in between that needs the host.  Two
 // groups are in flight: the host takes the selection decisions of group g (trim_impl on a host-only view per alignment)
 // while the device works on group g + 1.  Alignments the engine does not take, and the rare alignment whose selection needs
 // another pass over the rows, go through the workers / an ordinary context as before.
