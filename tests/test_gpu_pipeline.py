@@ -84,6 +84,10 @@ CASES = {  # name: (m, n, seed, keep) -> what Cleaner::selectMethod makes of it
     "middle": (80, 260, 4, 0.72),      # in between, mean of the row maxima below 0.5: strict
     "middle_max": (80, 260, 7, 0.85),  # in between, mean of the row maxima in [0.5, 0.65]: gappyout
     "large": (700, 900, 6, 0.45),
+    # (from 513 sequences on the default context's compact pipeline sorts its columns behind the front kernel's event: the gate
+    # up -- gappyout, the similarity kernel's waves leave at once -- and down)
+    "large_conserved": (600, 700, 8, 0.93),
+    "wide": (150, 5300, 9, 0.40),      # more columns than the chip has wave slots: sorted as well
 }
 
 
@@ -104,7 +108,7 @@ def test_automated1_gate(contexts, case):
 def test_automated1_cases_cover_both_methods():
     picked = {name: oracle.trim(family(*CASES[name]), method="automated1")[2].selected for name in CASES}
     assert set(picked.values()) == {1, 2}, picked
-    assert picked == {"conserved": 1, "diverged": 2, "few": 1, "middle": 2, "middle_max": 1, "large": 2}
+    assert picked == {"conserved": 1, "diverged": 2, "few": 1, "middle": 2, "middle_max": 1, "large": 2, "large_conserved": 1, "wide": 2}
 
 
 @pytest.mark.parametrize("kw", [dict(method="strict"), dict(method="strictplus"),
@@ -182,7 +186,7 @@ def test_trims_repeated_on_one_upload(contexts):
 def test_bad_residue_only_matters_when_similarity_is_used(contexts):
     """automated1 encodes the columns for the similarity pass before it knows whether strict will be selected: a
     symbol outside the matrix must raise exactly when the reference would have reached the similarity statistic"""
-    for name in ("conserved", "diverged"):
+    for name in ("conserved", "diverged", "large", "large_conserved"):
         a = family(*CASES[name]).copy()
         a[5, 17] = ord("J")  # not in the default matrix
         p, keepalive = params_of(AutomaticTrimmer("automated1", platform="hip"))
