@@ -42,7 +42,7 @@ MSA_COMPACT=0 MSA_ZEROCOPY_KB=0 timeout 300 python tools/small_latency.py > $OUT
 timeout 300 python tools/flat_sweep.py > $OUT/flat_sweep.jsonl 2>/dev/null
 timeout 300 python tests/measure/fixtures_time.py > $OUT/fixtures_time.jsonl 2>/dev/null
 ( cd /tmp; : > $OUT/small_kernel_stats.txt
-  for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict"; do
+  for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict" "209 1227 overlap" "209 1227 representative" "1000 4000 automated1"; do
     rm -rf /tmp/small_prof
     timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/small_prof -- python3 $ROOT/tools/small_one.py $a 200 > /tmp/small_prof.log 2>&1
     grep "per upload" /tmp/small_prof.log >> $OUT/small_kernel_stats.txt

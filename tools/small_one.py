@@ -1,5 +1,6 @@
 """One small alignment trimmed again and again through the C ABI (upload + msa_trim): the command a profiler is pointed at.
-   python tools/small_one.py [m n [method [count]]]      e.g.  rocprofv3 --kernel-trace --stats -d out -- python3 tools/small_one.py 46 1181 strict 300"""
+   python tools/small_one.py [m n [method [count]]]      e.g.  rocprofv3 --kernel-trace --stats -d out -- python3 tools/small_one.py 46 1181 strict 300
+   method: an AutomaticTrimmer method, or overlap / representative (OverlapTrimmer(80, 0.8), RepresentativeTrimmer(identity_threshold=0.75))"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,14 @@ else:
     m, n = (int(x) for x in sys.argv[1:3]) if len(sys.argv) > 2 else (46, 1181)
     a = synth_msa(m, n, 77 + m)
     ali = Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a])
-tr = AutomaticTrimmer(method, platform="hip")
+if method == "overlap":          # OverlapTrimmer(80, 0.8): front kernel + two launches behind it
+    from pytrimal_amd import OverlapTrimmer
+    tr = OverlapTrimmer(80.0, 0.8, platform="hip")
+elif method == "representative":  # RepresentativeTrimmer(identity_threshold=0.75)
+    from pytrimal_amd import RepresentativeTrimmer
+    tr = RepresentativeTrimmer(identity_threshold=0.75, platform="hip")
+else:
+    tr = AutomaticTrimmer(method, platform="hip")
 for _ in range(5):
     tr.trim(ali)
 names, dense, indet, params, keep = tr._prepare(ali)
@@ -34,7 +42,7 @@ for _ in range(20):
     ctx.upload(dense, indet)
     ctx.trim(params)
 kern = {}
-for k in ("front", "gaps", "prep", "pairs", "idstats", "encode", "sim"):
+for k in ("front", "gaps", "prep", "pairs", "idstats", "encode", "sim", "overlap", "cluster"):
     ms, cnt = ctx.prof_get(k)
     if cnt:
         kern[k] = round(ms / cnt, 4)
