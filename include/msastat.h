@@ -292,7 +292,8 @@ enum {
     MSA_PATH_SIM_SEQ = 4,        /* the plain sequential kernel (MSA_SIM_KERNEL=seq) */
     MSA_PATH_SIM_COLS = 5        /* a lane per column (groups of small alignments in msa_trim_batch) */
 };
-enum { MSA_PATH_PAIRS_NONE = 0, MSA_PATH_PAIRS_PIPE = 1 /* one row j per lane */, MSA_PATH_PAIRS_TWO_ROWS = 2 /* two rows j per lane */ };
+enum { MSA_PATH_PAIRS_NONE = 0, MSA_PATH_PAIRS_PIPE = 1 /* one row j per lane */, MSA_PATH_PAIRS_TWO_ROWS = 2 /* two rows j per lane */,
+       MSA_PATH_PAIRS_PIPE16 = 3 /* one row j per lane, sixteen rows i per tile (up to 1024 sequences) */ };
 int msa_debug_last_paths(msa_ctx *ctx, int32_t out[8]);
 
 #ifdef __cplusplus

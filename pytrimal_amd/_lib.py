@@ -454,7 +454,7 @@ class Context:
         "upload": ("none", "in_place", "linear", "pitched", "packed", "attached", "repitched"),
         "pipeline": ("none", "serial", "one_stream", "two_streams", "compact", "compact_gaps", "compact_sorted"),
         "sim_kernel": ("none", "flat", "lg", "lg_big", "seq", "cols"),
-        "pair_kernel": ("none", "pipe", "two_rows"),
+        "pair_kernel": ("none", "pipe", "two_rows", "pipe16"),
     }
 
     def last_paths(self):
@@ -479,6 +479,11 @@ class Context:
 
 class BatchClosed(RuntimeError):
     """`Batch.trim` on an object another thread has closed in the meantime (`pytrimal_amd.batch` then takes the new one)."""
+
+
+class _BatchResults(list):
+    """`Batch.trim`'s list of results; `packed` is the one uint8 vector every mask of the call is a view of."""
+    packed = None
 
 
 class Batch:
@@ -551,7 +556,8 @@ class Batch:
         kseq = (starts + ns + base).astype(np.uint64)
         infos = (TrimInfo * count)()
         rcs = np.zeros(count, dtype=np.int32)
-        out = []
+        out = _BatchResults()
+        out.packed = masks  # [residues mask, sequences mask] of every item, side by side (what trim_batch's gather sends)
         with self._lock:
             if not self.h:
                 raise BatchClosed("the batch object is closed")

@@ -109,6 +109,7 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
     collective path of a multi-GPU run -- device buffer, `dist.gather` over RCCL, unpacking -- on a one-GPU box
     (tests/measure/rccl_one_rank.py, `bench.py` under a launcher).
     """
+    _mark("start")
     distributed = shard and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
@@ -126,11 +127,13 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
         from . import _lib
 
         prepared = [trimmer._prepare(alignments[i], matrix) for i in mine]
+        _mark("prepare")
         index = device.index if isinstance(device, torch.device) and device.index is not None else None
         if index is None:
             index = int(os.environ.get("PYTRIMAL_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         todo = [k for k, (_, dense, _, _, _) in enumerate(prepared) if dense.shape[0] and dense.shape[1]]
         results = {}
+        packed_masks = None
         if todo:
             items = [(prepared[k][1], prepared[k][2], prepared[k][3]) for k in todo]
             for attempt in range(3):
@@ -145,6 +148,8 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
                 if out[3] != _lib.OK:
                     batch.check(out[3], out[2])
                 results[k] = out
+            if len(todo) == len(prepared):  # (no empty alignment in between: the library's mask vector IS the gather's payload)
+                packed_masks = getattr(outs, "packed", None)
         local = []
         for k, (names, dense, indet, params, _keep) in enumerate(prepared):
             if k in results:
@@ -158,6 +163,7 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
             else:
                 t = trimmer._finish(names, dense, alignments[mine[k]]._datatype, res, seq, info, rows, None, params)
             local.append((res, seq, t))
+    _mark("native batch")
     collect = distributed and (world > 1 or force_collectives)
     if masks_only and not collect:
         return [(np.asarray(r, dtype=bool), np.asarray(s, dtype=bool)) for r, s, _ in local]
@@ -166,38 +172,91 @@ def trim_batch(trimmer, alignments, matrix=None, *, group=None, device=None, tri
         # tail of ~4 ms behind a 35 ms batch)
         return [t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], r, s, _gap_stats(trimmer)) for i, (r, s, t) in zip(mine, local)]
     mine_trimmed = {i: t for i, (_, _, t) in zip(mine, local)}
-    local = [(r, s) for r, s, _ in local]
 
     # every rank knows every shape, so shard payload sizes are known without a size exchange
-    def payload(r):
-        return sum(len(alignments[i].residues) + len(alignments[i].sequences) for i in shard_indices(len(alignments), world, r))
-
-    width = max(payload(r) for r in range(world))
+    sizes = [(len(a.residues), len(a.sequences)) for a in alignments]
+    width = max(max((sum(n + m for n, m in sizes[r::world]) for r in range(world)), default=0), 1)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    buf = torch.zeros(max(width, 1), dtype=torch.uint8, device=device)
-    packed = _pack_masks(local)
-    if packed.size:
-        buf[:packed.size] = torch.from_numpy(packed).to(device)
-    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0, group=group)
+    box = _gather_buffers(device, world, rank, width)
+    # the shard's masks packed straight into the (page-locked) staging vector, one copy to the device, ONE gather into one
+    # [world][width] tensor, one copy back for all ranks (round 5: a fresh device tensor, a pageable copy, a tensor and a
+    # `.cpu()` per rank -- 64 x 5 KB, so every one of these is latency: profiles/r06_c5_collective.jsonl)
+    stage = box.stage_np
+    if trim_fn is None and packed_masks is not None and packed_masks.size <= stage.size:
+        stage[:packed_masks.size] = packed_masks
+    else:
+        pos = 0
+        for r, s, _ in local:
+            stage[pos:pos + len(r)] = r
+            pos += len(r)
+            stage[pos:pos + len(s)] = s
+            pos += len(s)
+    if box.send is not box.stage:
+        box.send.copy_(box.stage, non_blocking=True)
+    _mark("pack + H2D")
+    dist.gather(box.send, box.recv_list, dst=0, group=group)
+    _mark("gather")
     if rank != 0:
         return None
+    if box.recv_host is not box.recv:
+        box.recv_host.copy_(box.recv, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    flat_all = box.recv_host.numpy().view(np.bool_).copy()  # (the buffers are reused by the next call: one copy for all ranks)
     out = [None] * len(alignments)
     for r in range(world):
-        flat = gathered[r].cpu().numpy()
+        flat = flat_all[r]
         pos = 0
-        for i in shard_indices(len(alignments), world, r):
-            n, m = len(alignments[i].residues), len(alignments[i].sequences)
-            res = flat[pos:pos + n].astype(bool)
-            seq = flat[pos + n:pos + n + m].astype(bool)
+        for i in range(r, len(alignments), world):
+            n, m = sizes[i]
+            res = flat[pos:pos + n]
+            seq = flat[pos + n:pos + n + m]
             pos += n + m
             if masks_only:
                 out[i] = (res, seq)
                 continue
             t = mine_trimmed.get(i) if r == rank else None
             out[i] = t if isinstance(t, TrimmedAlignment) else _rebuild(alignments[i], res, seq, _gap_stats(trimmer))
+    _mark("D2H + unpack")
     return out
+
+
+# ---- the gather's buffers, kept between calls: one per (device, group size, rank, width) ----------------------------------
+class _GatherBuffers:
+    def __init__(self, device, world, rank, width):
+        cuda = device.type == "cuda"
+        self.stage = torch.zeros(width, dtype=torch.uint8, pin_memory=cuda)   # host side of the send buffer
+        self.stage_np = self.stage.numpy()
+        self.send = torch.zeros(width, dtype=torch.uint8, device=device) if cuda else self.stage
+        self.recv = self.recv_host = self.recv_list = None
+        if rank == 0:
+            self.recv = torch.zeros((world, width), dtype=torch.uint8, device=device)
+            self.recv_list = list(self.recv.unbind(0))
+            self.recv_host = torch.zeros((world, width), dtype=torch.uint8, pin_memory=True) if cuda else self.recv
+
+
+_GATHER = {}
+
+
+def _gather_buffers(device, world, rank, width):
+    # (the gather needs equally long tensors on every rank: every rank sizes its buffers by the same rule -- exactly `width`)
+    key = (str(device), world, rank, width)
+    box = _GATHER.get(key)
+    if box is None:
+        if len(_GATHER) >= 8:
+            _GATHER.clear()
+        box = _GATHER[key] = _GatherBuffers(device, world, rank, width)
+    return box
+
+
+# phase marks of one trim_batch call (tools/c5_collective.py): None = off
+_TRACE = None
+
+
+def _mark(what):
+    if _TRACE is not None:
+        import time
+        _TRACE.append((what, time.perf_counter()))
 
 
 def _gap_stats(trimmer):

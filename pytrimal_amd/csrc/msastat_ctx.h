@@ -133,6 +133,7 @@ struct msa_ctx {
     PinBuf<int32_t> h_cres;      // ... and its results, written by the kernels themselves into pinned host memory: the state block's
                                  // layout, then the residues per sequence (state_rpad words), MDK and Q (state_npad floats each) and
                                  // the verdict slots of the front kernel's blocks
+    int compact_cw = 64;         // columns per column block of the front kernel last launched (the slots are per block)
     bool state_zeroed = false;   // for the current alignment
     bool errkey_dirty = false;   // an encode kernel may have written the first-bad-residue key since the state was zeroed
     bool flags_dirty = false;    // a kernel that may raise a flag was enqueued since the flags were last fetched

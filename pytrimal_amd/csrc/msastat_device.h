@@ -338,6 +338,156 @@ __device__ __forceinline__ void pair_counts_pipe_body(const uint32_t *__restrict
     pair_epilogue<TI, TJ>(miss, dst, i0, j0, lane, nchunk, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, wsum);
 }
 
+// The same loop on SIXTEEN rows i per tile (round 6), two halves of eight one after the other on the SAME j planes: a chunk is
+// four phases (A and B of rows 0-7, A and B of rows 8-15), each on a group of 32 SGPRs requested one phase earlier -- the scalar
+// registers in use are what the eight-row loop holds, while the j planes (seven eighths of what a tile reads) are loaded half as
+// often per pair and there are half as many tiles, epilogues and partial-count exchanges.  (Round 2's sixteen-row tile held all
+// sixteen rows' plane words at once and serialised on its scalar loads: DESIGN A.2.)  The K waves of the workgroup add their
+// partial counts into ONE LDS tile with integer atomics (8 KB whatever K is; the eight-row loop keeps K - 1 tiles: 28 KB at K = 8).
+__device__ __forceinline__ void pair_counts_pipe16_body(const uint32_t *__restrict__ planes, int nchunk, int m_pad, int m, int ldw,
+                                                        float *__restrict__ ident, float *__restrict__ wmat, float *__restrict__ wlow,
+                                                        int *__restrict__ undef_flag, int ib, int jb, uint32_t *__restrict__ wsum) {
+    constexpr int TI = 8, H = 2;
+    typedef const __attribute__((address_space(4))) u32x8 *c8;
+    __shared__ uint32_t part[2][H][TI][64];
+    const int lane = threadIdx.x & 63;
+    const int K = (int)(blockDim.x >> 6), kw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cbeg = (int)((long)nchunk * kw / K), cend = (int)((long)nchunk * (kw + 1) / K);
+    const int i0 = ib * (TI * H);  // uniform
+    const int j0 = jb * 64;
+    if (j0 >= m_pad) return;
+    if (j0 + 63 <= i0) return;
+    if (K > 1) {
+        for (int i = threadIdx.x; i < 2 * H * TI * 64; i += (int)blockDim.x) (&part[0][0][0][0])[i] = 0u;
+        __syncthreads();
+    }
+    uint32_t miss[H][1][TI], dst[H][1][TI], d[1][TI];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int t = 0; t < TI; ++t) miss[h][0][t] = dst[h][0][t] = 0;
+    // Every address is the planes' base (a scalar pair) plus a 32-bit byte offset (the launcher keeps this kernel to plane arrays
+    // below 4 GB): `s_load_dwordx8 dst, base, offset` for the rows i, `global_load_dword dst, voffset, base` for the rows j, and
+    // the eight plane offsets are eight scalars shared by both -- sixteen 64-bit plane addresses kept alive across the four
+    // phases spilled a hundred scalar registers into the loop.
+    typedef const __attribute__((address_space(4))) char *cbytep;
+    typedef const __attribute__((address_space(1))) char *gbytep;
+    const uint32_t ps4 = (uint32_t)nchunk * (uint32_t)m_pad * 4u, mp4 = (uint32_t)m_pad * 4u;
+    uint32_t poff[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) poff[p] = (uint32_t)p * ps4;
+    const cbytep pib = (cbytep)(uint64_t)planes;
+    const gbytep pjb = (gbytep)(uint64_t)planes;
+    const uint32_t i04 = (uint32_t)i0 * 4u, jl4 = (uint32_t)(j0 + lane) * 4u;
+    struct Group {
+        u32x8 p[4];
+    };
+    auto request_a = [&](Group &g, int c, int h) {  // validity plane, planes 0..2
+        const uint32_t q = (uint32_t)c * mp4 + i04 + 32u * (uint32_t)h;
+        g.p[0] = *(c8)(pib + (q + poff[7]));
+        g.p[1] = *(c8)(pib + (q + poff[0]));
+        g.p[2] = *(c8)(pib + (q + poff[1]));
+        g.p[3] = *(c8)(pib + (q + poff[2]));
+    };
+    auto request_b = [&](Group &g, int c, int h) {  // planes 3..6
+        const uint32_t q = (uint32_t)c * mp4 + i04 + 32u * (uint32_t)h;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) g.p[p] = *(c8)(pib + (q + poff[3 + p]));
+    };
+    auto arrived = [&](Group &g, uint32_t (&pin)[1][TI]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+s"(g.p[0]), "+s"(g.p[1]), "+s"(g.p[2]), "+s"(g.p[3]), "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]),
+                       "+v"(pin[0][3]), "+v"(pin[0][4]), "+v"(pin[0][5]), "+v"(pin[0][6]), "+v"(pin[0][7]));
+    };
+    auto request_j = [&](uint32_t (&b)[8], int c) {
+        const uint32_t q = (uint32_t)c * mp4 + jl4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) b[p] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(pjb + (q + poff[p]));
+    };
+    Group ga, gb;
+    uint32_t b0[8], b1[8];
+    auto phase_a = [&](int h, const uint32_t (&b)[8]) {
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            const uint32_t vi = ga.p[0][t], nvi = ~vi;  // columns in which row i holds no residue never count as hits
+            uint32_t x = __builtin_amdgcn_bitop3_b32(nvi, ga.p[1][t], b[0], 0xF6);  // x | (y ^ z)
+            x = __builtin_amdgcn_bitop3_b32(x, ga.p[2][t], b[1], 0xF6);
+            d[0][t] = __builtin_amdgcn_bitop3_b32(x, ga.p[3][t], b[2], 0xF6);
+            dst[h][0][t] += __builtin_popcount(vi | b[7]);
+        }
+    };
+    auto phase_b = [&](int h, const uint32_t (&b)[8]) {
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            uint32_t x = __builtin_amdgcn_bitop3_b32(d[0][t], gb.p[0][t], b[3], 0xF6);
+            x = __builtin_amdgcn_bitop3_b32(x, gb.p[1][t], b[4], 0xF6);
+            x = __builtin_amdgcn_bitop3_b32(x, gb.p[2][t], b[5], 0xF6);
+            x = __builtin_amdgcn_bitop3_b32(x, gb.p[3][t], b[6], 0xF6);
+            miss[h][0][t] += __builtin_popcount(x);
+        }
+    };
+    auto step = [&](int c, uint32_t (&b)[8], uint32_t (&bn)[8]) {
+        const int cn = c + 1 < cend ? c + 1 : c;
+        arrived(ga, miss[1]);  // group A of (chunk c, rows 0-7)
+        request_b(gb, c, 0);
+        request_j(bn, cn);
+        __builtin_amdgcn_sched_barrier(0);
+        phase_a(0, b);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(gb, d);  // group B of (c, rows 0-7)
+        request_a(ga, c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        phase_b(0, b);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(ga, miss[0]);  // group A of (c, rows 8-15)
+        request_b(gb, c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        phase_a(1, b);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(gb, d);  // group B of (c, rows 8-15)
+        request_a(ga, cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        phase_b(1, b);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (cbeg < cend) {
+        request_a(ga, cbeg, 0);
+        request_j(b0, cbeg);
+        int c = cbeg;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (; c + 1 < cend; c += 2) {
+            step(c, b0, b1);
+            step(c + 1, b1, b0);
+        }
+        if (c < cend) step(c, b0, b1);
+        arrived(ga, miss[1]);  // (the last request, a repeat of the last chunk, is not used)
+    }
+    if (K > 1) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                atomicAdd(&part[0][h][t][lane], miss[h][0][t]);
+                atomicAdd(&part[1][h][t][lane], dst[h][0][t]);
+            }
+        __syncthreads();
+        // the epilogue's two halves on the workgroup's first two waves
+        if (kw >= H) return;
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+            if (h == kw) {
+#pragma unroll
+                for (int t = 0; t < TI; ++t) miss[h][0][t] = part[0][h][t][lane], dst[h][0][t] = part[1][h][t][lane];
+            }
+        if (kw == 0) pair_epilogue<TI, 1>(miss[0], dst[0], i0, j0, lane, nchunk, m, ldw, nullptr, nullptr, ident, wmat, wlow, undef_flag, wsum);
+        else pair_epilogue<TI, 1>(miss[1], dst[1], i0 + TI, j0, lane, nchunk, m, ldw, nullptr, nullptr, ident, wmat, wlow, undef_flag, wsum);
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+        pair_epilogue<TI, 1>(miss[h], dst[h], i0 + TI * h, j0, lane, nchunk, m, ldw, nullptr, nullptr, ident, wmat, wlow, undef_flag, wsum);
+}
+
 // MDK from the two sums (Similarity::calculateVectors tail): 0 for >= 80 % gaps or an empty denominator, else
 // min(1, (float)exp(-(double)Q)).  Q = num / den is bit-exact; the exponential is the device library's, which may differ
 // from the host's in the last place of the DOUBLE -- and then in the float only when the double lies within a few of

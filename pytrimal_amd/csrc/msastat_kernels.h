@@ -24,6 +24,12 @@ struct Tuning {
     int flat_u = 0;            // MSA_FLAT_U: terms per lane and scan of the flat similarity kernel (0: by size; A/B: 4, 8, 16)
     int zerocopy_kb = 96;      // MSA_ZEROCOPY_KB: rows up to this size stay in pinned host memory and the kernels read them over the link
     int mdk_host = 0;          // MSA_MDK_HOST=1: the device hands every exponential of the MDK values to the host (tests: both paths agree bit for bit)
+    int front_cw = 0;          // MSA_FRONT_CW: columns per column block of the compact pipeline's front kernel (0: by size; 64: the round-4 kernel; 16, 32)
+    int front_nt = 0;          // MSA_FRONT_NT: threads per block of the narrow front kernel (0: by size; 256, 512, 1024)
+    int front_from_m = 0;      // MSA_FRONT_FROM_M: sequences from which on the narrow front kernel runs (0: default)
+    int front_xcd = 1;         // MSA_FRONT_XCD=0: the narrow column blocks in their own order
+    int pair_ti = 0;           // MSA_PAIR_TI: rows i per tile of the pair pass (0: by size; 8, 16)
+    int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
 };
 Tuning tuning_from_env();
 void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults
@@ -35,7 +41,7 @@ struct LaunchNote {
     int lg_split = 0;     // waves of a workgroup per column (1: a wave per column)
     int lg_launches = 0;  // launches of the pass
     int lg_fin = 0;       // the kernel writes MDK and Q itself (the compact pipeline)
-    int pair_kind = 0;    // 0 none, 1 one row j per lane (software pipeline), 2 two rows j per lane
+    int pair_kind = 0;    // 0 none, 1 one row j per lane (software pipeline), 2 two rows j per lane, 3 sixteen rows i per tile
     int pair_waves = 0;   // waves per tile
 };
 LaunchNote &launch_note();
@@ -141,7 +147,13 @@ struct CompactArgs {
     int32_t lists;            // 0: codes only (the flat similarity kernel follows), 1: the compacted lists as well
     float *ident, *row_avg, *row_max;
     int32_t gated;            // automated1: the identity statistics + the selectMethod gate (compact_identity_kernel)
+    int32_t cw;               // columns per column block (compact_front_cw): the slots are per column block
+    int32_t xcd;              // the narrow column blocks that share the lines of a row dealt to one XCD
+    int32_t nt;               // threads per block of the narrow front kernel (compact_front_nt)
 };
+// columns per column block of the front kernel for this shape (64: compact_front_kernel; 16 / 32: compact_front2_kernel)
+int compact_front_cw(int m, int n, bool sim, bool rows_in_host_memory);
+int compact_front_nt(int m, int n, int cus);
 size_t compact_scratch_words(int m, int n);
 size_t compact_slot_words(int n);
 void launch_compact_front(hipStream_t s, const CompactArgs &a);

@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -232,6 +233,14 @@ __global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_pipe_kernel(const 
     int ib, jb;
     pair_tile<PAIR_TI, TJ>(n_iblocks, (int)blockIdx.x, ib, jb);
     pair_counts_pipe_body<TJ>(planes, nchunk, m_pad, m, ldw, hit_out, dst_out, ident, wmat, wlow, undef_flag, ib, jb, wsum);
+}
+__global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_pipe16_kernel(const uint32_t *__restrict__ planes, int nchunk, int m_pad, int m, int ldw,
+                                                                            float *__restrict__ ident, float *__restrict__ wmat,
+                                                                            float *__restrict__ wlow, int *__restrict__ undef_flag, int n_iblocks,
+                                                                            uint32_t *__restrict__ wsum) {
+    int ib, jb;
+    pair_tile<16, 1>(n_iblocks, (int)blockIdx.x, ib, jb);
+    pair_counts_pipe16_body(planes, nchunk, m_pad, m, ldw, ident, wmat, wlow, undef_flag, ib, jb, wsum);
 }
 // (a batch holds alignments of the one-row-per-lane regime only -- below ~4100 sequences: pair_tiles_pipe)
 __global__ __launch_bounds__(64 * PAIR_KMAX) void pair_counts_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
@@ -542,6 +551,12 @@ Tuning tuning_from_env() {
     t.flat_u = num("MSA_FLAT_U", 0);
     t.lg_rounds = num("MSA_LG_ROUNDS", -1);
     t.lg_split = num("MSA_LG_SPLIT", 0);
+    t.front_cw = num("MSA_FRONT_CW", 0);
+    t.front_nt = num("MSA_FRONT_NT", 0);
+    t.front_from_m = num("MSA_FRONT_FROM_M", 0);
+    t.front_xcd = num("MSA_FRONT_XCD", 1);
+    t.pair_ti = num("MSA_PAIR_TI", 0);
+    t.pair_k = num("MSA_PAIR_K", 0);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {
@@ -583,6 +598,9 @@ void launch_gap_counts(hipStream_t s, const uint8_t *raw, int m, int n, int64_t 
 // slots as tiles finish; below, up to eight waves per tile, at least eight chunks each (measured at 2000 x 10000, 4000 tiles:
 // 0.350 / 0.349 / 0.320 / 0.313 ms with 1 / 2 / 4 / 8 waves; 1000 x 4000: 0.074 -> 0.040; 500 x 2000: 0.033 -> 0.016; 3000 x 8000,
 // 8800 tiles: 0.514 with one wave, 0.530 with two)
+#ifndef MSA_PAIR16_FROM_M  // sequences from which on the pair pass runs sixteen rows i per tile (up to the two-rows regime)
+#define MSA_PAIR16_FROM_M 513
+#endif
 static int pair_split(long tiles, int nchunk) {
     int k = 1;
     if (tiles >= 8192) return k;
@@ -599,9 +617,29 @@ void launch_pair_counts(hipStream_t s, const uint32_t *planes, int nchunk, int m
     const unsigned tiles = (unsigned)(R * jc * (jc + 1) / 2 + (njb - jc) * nib);
     launch_note().pair_kind = two ? 2 : 1;
     launch_note().pair_waves = 1;
+    // Sixteen rows i per tile (two halves of eight on the same j planes: pair_counts_pipe16_body) from 513 sequences up to the
+    // two-rows regime: the j planes -- seven eighths of what a tile reads -- are loaded half as often per pair.  As fast as eight rows
+    // alone (profiles/r06_front_pairs_ab.txt: 1000 x 4000 43.3 / 42.4 us, 2000 x 10000 0.343 / 0.349 ms), half the traffic beyond the L2
+    // (r06_pmc_hbm_traffic.txt), and 0.25 ms off the C5 batch, where the pair pass runs beside other contexts' similarity kernels
+    // (r06_c5_front_pairs_ab.txt).  Below 513 sequences it loses (150 ... 500 rows: 13 -> 18, 19 -> 22 us: too few tiles).  K waves per
+    // tile while the launch stays within twice the chip's wave slots (2000 x 10000: K = 8 0.388 ms, K = 4 0.343).  MSA_PAIR_TI / MSA_PAIR_K: A/B.
+    const int ti_forced = tuning().pair_ti;
+    if (!two && !hit && !dst && (ti_forced == 16 || (ti_forced == 0 && m >= MSA_PAIR16_FROM_M)) &&
+        (uint64_t)planes_total() * (uint64_t)nchunk * (uint64_t)m_pad * 4u < (1ull << 32)) {  // (its plane addresses are 32-bit offsets)
+        const int nib16 = (m + 15) / 16, jc16 = (nib16 + 3) / 4 - 1;
+        const unsigned tiles16 = (unsigned)(4 * jc16 * (jc16 + 1) / 2 + (m_pad / 64 - jc16) * nib16);
+        int K = 1;
+        while (2 * K <= PAIR_KMAX && (long)tiles16 * (2 * K) <= 10240 && nchunk >= 8 * (2 * K)) K *= 2;
+        if (tuning().pair_k > 0) K = std::min(PAIR_KMAX, tuning().pair_k);
+        launch_note().pair_kind = 3;
+        launch_note().pair_waves = K;
+        pair_counts_pipe16_kernel<<<tiles16, 64 * K, 0, s>>>(planes, nchunk, m_pad, m, ldw, ident, wmat, wlow, undef_flag, nib16, wsum);
+        return;
+    }
     if (two) pair_counts_kernel<PAIR_TI, 2><<<tiles, 64, 0, s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat, wlow, undef_flag, nib);
     else {
-        const int K = pair_split(tiles, nchunk);
+        int K = pair_split(tiles, nchunk);
+        if (tuning().pair_k > 0) K = std::min(PAIR_KMAX, tuning().pair_k);
         launch_note().pair_waves = K;
         pair_counts_pipe_kernel<1><<<tiles, 64 * K, (size_t)(K - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(planes, nchunk, m_pad, m, ldw, hit, dst, ident, wmat,
                                                                                                                 wlow, undef_flag, nib, wsum);

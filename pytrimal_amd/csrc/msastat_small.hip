@@ -48,20 +48,30 @@ __device__ __forceinline__ void identity_rows_body(const float *__restrict__ ide
     if (i >= m) return;
     const float *r = ident + (size_t)i * ldw;  // ident[i][j] == ident[j][i]
     float s = 0.0f, mx = 0.0f, mn = 1.0f;      // (getCutPointClusters starts its minimum at 1)
-    for (int base = 0; base < m; base += 256) {
-        float x[4];
+    // 1024 terms requested at a time, then four steps of 256: a row of up to 1024 identities waits for memory once (round 5
+    // requested a chunk, added it up, requested the next: four round trips at 1000 sequences, and the step itself is ~40 instructions)
+    for (int base = 0; base < m; base += 1024) {
+        float x[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int t = base + 64 * c + lane;
-            const bool in = t < m && t != i;
-            const float v = in ? r[t] : 0.0f;
-            x[c] = v;
-            if (in) {
-                mx = mx < v ? v : mx;
-                mn = mn > v ? v : mn;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = base + 256 * q + 64 * c + lane;
+                x[q][c] = (t < m && t != i) ? r[t] : 0.0f;
             }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = base + 256 * q + 64 * c + lane;
+                const float v = x[q][c];
+                if (t < m && t != i) {
+                    mx = mx < v ? v : mx;
+                    mn = mn > v ? v : mn;
+                }
+            }
+            if (base + 256 * q < m) s = chunk_step(s, x[q]);
         }
-        s = chunk_step(s, x);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -92,14 +102,18 @@ __device__ __forceinline__ void identity_final_body(const float *__restrict__ ro
     if (which < 2) {  // (the compact pipeline calls this from a workgroup of eight waves)
         const float *src = which ? row_max : row_avg;
         float a = 0.0f;
-        for (int base = 0; base < m; base += 256) {
-            float xa[4];
+        for (int base = 0; base < m; base += 1024) {  // (1024 terms requested at a time: identity_rows_body)
+            float xa[4][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int t = base + 64 * c + lane;
-                xa[c] = t < m ? src[t] : 0.0f;
-            }
-            a = chunk_step(a, xa);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int t = base + 256 * q + 64 * c + lane;
+                    xa[q][c] = t < m ? src[t] : 0.0f;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (base + 256 * q < m) a = chunk_step(a, xa[q]);
         }
         if (lane == 0) {
             a = a / (float)m;
@@ -657,6 +671,192 @@ __global__ __launch_bounds__(256 * COMPACT_TEAMS_MAX) void compact_front_kernel(
     else if (threadIdx.x < 256) row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb);
 }
 
+// ---- the front kernel from 513 sequences on (round 6): NARROW column blocks -------------------------------------------------
+// At 1000 x 4000 the kernel above is 63 column blocks of 1024 threads and 92 KB of LDS, each a chain of four passes over sixteen
+// 64-row tiles: 41 us for one pass over 4 MB on a quarter of the chip, and in a batch its workgroups wait for three of a compute
+// unit's similarity workgroups to leave (profiles/r05_c5_timeline.txt: 379 us).  Here a column block owns CW = 16 (or 32) columns
+// over ALL rows and requests every one of its rows before it looks at the first:
+//   * thread = one dword (four columns) of four CONSECUTIVE rows per sweep, NS sweeps: 4 NS dword loads in flight per thread, a
+//     wave's load covers 16 rows x 16 bytes (CW = 16); the gap / indetermination counts are SWAR byte counters, widened to 16 bits
+//     and summed over the wave's lanes of the same dword by shuffles, over the waves through LDS;
+//   * the codes of a thread's four rows are one dword of the LDS array [column][row] (LDC4 = ROWS / 4 + 64 / CW dwords per column:
+//     the lanes of a wave land on 64 different banks), written once, read back coalesced by the wave that writes the column out
+//     (codes, compacted lists: as above);
+//   * the bit planes come from blocks of their own (a thread per row and 64 columns: prep_planes_core) -- the rows are in device
+//     memory at this size, a second read costs nothing, and a column block narrower than a plane word (32 columns) becomes possible;
+//   * the non-ASCII verdict is the column blocks' (they see every byte the plane blocks see).
+// 250 column blocks + 252 plane blocks + 250 row blocks of 256 active threads at 1000 x 4000 instead of 63 + 250.
+template <int ROWS, int CW, int NT>
+__device__ __forceinline__ void compact_column_block2(const CompactArgs &a, int b) {
+    constexpr int WPR = CW / 4;               // dwords per row of the block
+    constexpr int RG = NT / WPR;              // groups of four consecutive rows per sweep
+    constexpr int NS = ROWS / (4 * RG);       // sweeps
+    constexpr int LDC4 = ROWS / 4 + 64 / CW;  // dwords per column of the LDS code array
+    constexpr int NW = NT / 64;
+    static_assert(NS >= 1 && NS * 4 * RG == ROWS && (ROWS / 4) % 64 == 0, "shape of the narrow front kernel");
+    __shared__ uint8_t lut[256];
+    __shared__ uint32_t codes[CW * LDC4];
+    __shared__ uint32_t cnt[2][2][NW][WPR];  // [gaps / indeterminations][even / odd bytes][wave][dword]
+    __shared__ uint32_t firstbad[CW];
+    __shared__ uint8_t skipc[CW];
+    __shared__ int anybad;
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int word = t % WPR, rg = t / WPR;
+    const int m = a.m, n = a.n;
+    const int64_t ld = a.ld, ldk = a.ldk;
+    const int c0 = b * CW + 4 * word;
+    const bool inb = c0 < n;
+    // bytes of the thread's dword inside the alignment (columns < n)
+    const uint32_t km = !inb ? 0u : (n - c0 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * (n - c0))) - 1u));
+    uint32_t x[NS][4];
+    {
+        const uint8_t *p = a.raw + (inb ? c0 : 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * (s * RG + rg) + i;
+                x[s][i] = (row < m && inb) ? *reinterpret_cast<const uint32_t *>(p + (size_t)row * ld) : 0u;
+            }
+    }
+    for (int i = t; i < 256; i += NT) lut[i] = a.lut[i];
+    if (t < CW) firstbad[t] = 0xFFFFFFFFu;
+    if (t == 0) anybad = 0;
+    __syncthreads();
+    const uint32_t indet4 = a.indet4;
+    uint32_t g = 0, xi = 0, bad = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (s * RG + rg) + i;
+            const uint32_t v = x[s][i];
+            const uint32_t k4 = row < m ? km : 0u;
+            g += (zero_bytes(v ^ 0x2d2d2d2du) & k4) >> 7;
+            xi += (zero_bytes(v ^ indet4) & k4) >> 7;
+            bad |= v & k4 & 0x80808080u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t code = BX_SKIP;
+                if ((k4 >> (8 * k)) & 1u) {
+                    const uint32_t byte = (v >> (8 * k)) & 0xFFu;
+                    code = lut[byte];  // 8 x table row, 224 = skipped, 0xFE / 0xFF = bad symbol
+                    if (code >= 0xFEu) {
+                        atomicMin(&firstbad[4 * word + k], ((uint32_t)row << 16) | ((code & 1u) << 8) | byte);
+                        code = BX_SKIP;
+                    }
+                }
+                pk[k] |= code << (8 * i);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) codes[(4 * word + k) * LDC4 + s * RG + rg] = pk[k];
+    }
+    if (bad) anybad = 1;
+    {  // byte counters (<= 4 NS per byte) -> 16-bit fields, summed over the wave's lanes that hold the same dword of other rows
+        uint32_t f[4] = {g & 0x00FF00FFu, (g >> 8) & 0x00FF00FFu, xi & 0x00FF00FFu, (xi >> 8) & 0x00FF00FFu};
+#pragma unroll
+        for (int off = WPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] += (uint32_t)__shfl_xor((int)f[q], off, 64);
+        if (lane < WPR) {
+            cnt[0][0][wave][lane] = f[0], cnt[0][1][wave][lane] = f[1];
+            cnt[1][0][wave][lane] = f[2], cnt[1][1][wave][lane] = f[3];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool mine = lane < CW;
+        const int c = b * CW + lane;
+        uint32_t G = 0, X = 0;
+        if (mine) {
+            const int wd = lane >> 2, odd = lane & 1, sh = (lane & 2) * 8;
+            for (int w = 0; w < NW; ++w) G += (cnt[0][odd][w][wd] >> sh) & 0xFFFFu, X += (cnt[1][odd][w][wd] >> sh) & 0xFFFFu;
+            if (c < n) {
+                a.gaps[c] = (int32_t)G;
+                a.indets[c] = (int32_t)X;
+                a.hres[a.h_gaps + c] = (int32_t)G;
+                a.hres[a.h_indets + c] = (int32_t)X;
+            }
+        }
+        const bool skip = !mine || c >= n || (((float)(int32_t)G / (float)m) >= 0.8f);
+        if (mine) skipc[lane] = skip ? 1 : 0;
+        // the block's first bad residue: smallest column, then smallest row -- the key of sim_encode_cm, complemented
+        unsigned long long key = ~0ull;
+        if (!skip && firstbad[lane & (CW - 1)] != 0xFFFFFFFFu) key = ((unsigned long long)c << 40) | firstbad[lane & (CW - 1)];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other < key ? other : key;
+        }
+        if (lane == 0) {
+            const int ncb = a.ncols_pad / CW;
+            key = key == ~0ull ? 0ull : ~key;
+            a.hres[a.h_slots + 2 * b] = (int32_t)(uint32_t)key;
+            a.hres[a.h_slots + 2 * b + 1] = (int32_t)(uint32_t)(key >> 32);
+            a.hres[a.h_slots + 2 * ncb + b] = anybad;
+        }
+    }
+    __syncthreads();
+    // a wave per column, lane = row: the codes (coalesced) and the compacted lists, as sim_encode_cm and bx_compact write them
+    const uint32_t ldw4 = (uint32_t)a.ldw * 4u;
+    const int mtiles = (m + 63) / 64;
+    const uint8_t *cbytes = reinterpret_cast<const uint8_t *>(codes);
+    for (int q = wave; q < CW; q += NW) {
+        const size_t col = (size_t)b * CW + q;
+        const bool skip = skipc[q] != 0;
+        uint8_t *ct = a.codeT + col * ldk;
+        uint32_t *po = a.voff + col * ldk;
+        uint16_t *pt = a.vtrow + col * ldk;
+        int count = 0;
+        for (int kb = 0; kb < mtiles * 64; kb += 64) {
+            const int k = kb + lane;
+            const uint32_t code = (k < m && !skip) ? (uint32_t)cbytes[q * (LDC4 * 4) + k] : BX_SKIP;
+            ct[k] = (uint8_t)code;
+            if (!a.lists) continue;  // (the flat similarity kernel reads the codes alone)
+            const unsigned long long mask = __ballot(code != BX_SKIP);
+            if (code != BX_SKIP) {
+                const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                po[pos] = a.big ? (uint32_t)k : (uint32_t)k * ldw4;
+                pt[pos] = (uint16_t)((code >> 3) * 256u);
+            }
+            count += __builtin_popcountll(mask);
+        }
+        if (!a.lists) continue;
+        for (int64_t k = (int64_t)mtiles * 64 + lane; k < ldk; k += 64) ct[k] = (uint8_t)BX_SKIP;
+        for (int64_t e = count + lane; e < ldk; e += 64) {
+            po[e] = a.big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+            pt[e] = (uint16_t)(a.skiprow * 256);               // the table's zero row
+        }
+        if (lane == 0) a.nvalid[col] = count;
+    }
+}
+template <int ROWS, int CW, int NT>
+__global__ __launch_bounds__(NT) void compact_front2_kernel(CompactArgs a) {
+    const int b = (int)blockIdx.x;
+    const int ncb = a.ncols_pad / CW;
+    const int ncp = (a.nchunk + 1) / 2, npb = ncp * ((a.m_pad + 255) / 256);
+    if (b == 0) {
+        if (threadIdx.x < 32) a.flags[threadIdx.x] = 0;
+        if (threadIdx.x == 0) a.scratch[0] = 0;  // the ticket of the identity statistics
+        for (int i = threadIdx.x; i < a.m_pad + 64; i += NT) a.wsum[i] = 0u;
+    }
+    if (b < ncb) {
+        // consecutive blocks go to different XCDs: the eight (four) blocks that share the 128-byte lines of a row are dealt to ONE
+        // XCD -- XCD x = b % 8 owns a contiguous range of column groups -- so that its L2 fetches a line once
+        const int x = b & 7, q = b >> 3, full = ncb >> 3, rem = ncb & 7;
+        const int cg = a.xcd ? x * full + (x < rem ? x : rem) + q : b;
+        compact_column_block2<ROWS, CW, NT>(a, cg);
+    } else if (threadIdx.x < 256) {
+        if (b < ncb + npb) {
+            const int pb = b - ncb;
+            (void)prep_planes_core(a.raw, a.m, a.n, a.ld, a.indet4, a.planes, a.nchunk, a.m_pad, pb % ncp, pb / ncp);
+        } else row_nongap_body(a.raw, a.m, a.n, a.ld, nullptr, a.hres + a.h_rowtot, b - ncb - npb);
+    }
+}
+
 // automated1: the identity statistics -- a wave per sequence (identity_rows_body), and in the workgroup that finishes last (a
 // ticket) the two means and Cleaner::selectMethod's decision (identity_final_body): one launch for the ordinary path's two.
 __global__ __launch_bounds__(256) void compact_identity_kernel(CompactArgs a) {
@@ -852,9 +1052,52 @@ void launch_sim_lists_batch(hipStream_t s, const BAlign *table, const int32_t *p
 
 
 // words of the slots behind the state block's mirror: a first-bad-residue key (two words) and a non-ASCII word per column block
-size_t compact_slot_words(int n) { return (size_t)3 * (bx_cols_pad(n) / 64) + 2; }
+size_t compact_slot_words(int n) { return (size_t)3 * (bx_cols_pad(n) / 16) + 2; }  // (the narrowest column block: 16 columns)
 size_t compact_scratch_words(int m, int n) { return (size_t)2 + (std::max(m, 1) + 127) / 128 * 128 + 64 + 8; }
+// Columns per column block of the front kernel: 64 = compact_front_kernel (blocks of up to 1024 threads walking 64-row tiles, the
+// planes from the tile in LDS: the kernel of the alignments whose rows lie in pinned host memory -- every byte crosses the link once
+// -- and of up to 128 sequences), 16 = compact_front2_kernel from 129 sequences on when the rows are in device memory (every row of a
+// block requested at once, planes from blocks of their own: profiles/r06_front_pairs_ab.txt, front kernel at 150 x 1200 16.9 -> 10.5 us,
+// 500 x 2000 27.2 -> 15.0, 1000 x 4000 42.6 -> 17.3).  MSA_FRONT_CW / MSA_FRONT_FROM_M: A/B and tests.
+#ifndef MSA_FRONT2_FROM_M
+#define MSA_FRONT2_FROM_M 129
+#endif
+int compact_front_cw(int m, int n, bool sim, bool rows_in_host_memory) {
+    (void)n;
+    if (!sim) return 64;
+    const Tuning &t = tuning();
+    const int from = t.front_from_m > 0 ? t.front_from_m : MSA_FRONT2_FROM_M;
+    if (t.front_cw == 64 || m < from || m > 1024 || (rows_in_host_memory && t.front_from_m <= 0)) return 64;
+    return t.front_cw == 32 ? 32 : 16;
+}
+// threads per block of the narrow kernel: up to 512 sequences 512 (a sweep covers all rows); beyond, 1024 while every column block
+// has a compute unit of its own, else 512 (two blocks per unit at a time: 1024 x 8000, 501 blocks: 30.0 -> 26.9 us)
+int compact_front_nt(int m, int n, int cus) {
+    if (tuning().front_nt > 0) return tuning().front_nt;
+    return (m > 512 && bx_cols_pad(n) / 16 <= cus) ? 1024 : 512;
+}
+template <int ROWS>
+static void launch_compact_front2(hipStream_t s, const CompactArgs &a, unsigned blocks, int nt) {
+    if (a.cw == 32) {
+        if (nt <= 256) compact_front2_kernel<ROWS, 32, 256><<<blocks, 256, 0, s>>>(a);
+        else if (nt <= 512) compact_front2_kernel<ROWS, 32, 512><<<blocks, 512, 0, s>>>(a);
+        else compact_front2_kernel<ROWS, 32, 1024><<<blocks, 1024, 0, s>>>(a);
+    } else {
+        constexpr int TOP = ROWS == 512 ? 512 : 1024;  // (sixteen columns of 512 rows are one sweep of 512 threads)
+        if (nt <= 256) compact_front2_kernel<ROWS, 16, 256><<<blocks, 256, 0, s>>>(a);
+        else if (nt <= 512 || TOP == 512) compact_front2_kernel<ROWS, 16, 512><<<blocks, 512, 0, s>>>(a);
+        else compact_front2_kernel<ROWS, 16, TOP><<<blocks, TOP, 0, s>>>(a);
+    }
+}
 void launch_compact_front(hipStream_t s, const CompactArgs &a) {
+    if (a.sim && a.cw != 64) {
+        const int ncp = (a.nchunk + 1) / 2;
+        const unsigned blocks = (unsigned)(a.ncols_pad / a.cw + ncp * ((a.m_pad + 255) / 256) + (a.m + 3) / 4);
+        const int nt = a.nt > 0 ? a.nt : 512;
+        if (a.m > 512) launch_compact_front2<1024>(s, a, blocks, nt);
+        else launch_compact_front2<512>(s, a, blocks, nt);
+        return;
+    }
     const unsigned blocks = (unsigned)(a.ncols_pad / 64 + (a.m + 3) / 4);
     const int teams = std::min(COMPACT_TEAMS_MAX, std::max(1, (a.m + 63) / 64));  // a team of four waves per 64-row tile, up to four
     if (a.sim && a.m > 512) compact_front_kernel<true, 1024><<<blocks, 256 * teams, 0, s>>>(a);

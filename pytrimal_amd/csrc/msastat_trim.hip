@@ -129,6 +129,8 @@ msak::CompactArgs compact_args(msa_ctx *c) {
     a.scratch = c->cscratch.p;
     a.wsum = reinterpret_cast<uint32_t *>(c->cscratch.p + 2);
     a.ncols_pad = msak::bx_cols_pad(c->n);
+    a.cw = 64;
+    c->compact_cw = 64;
     return a;
 }
 // sizes the state block and its host mirror; the mirror's flag words start at zero (the kernels only ever raise them)
@@ -149,7 +151,7 @@ int compact_fetch(msa_ctx *c, bool sim) {
     if (sim) {
         // the verdicts of the front kernel's blocks -> the two flag words (what atomicOr / atomicMax leave there in the ordinary path)
         const int32_t *S = H + ST_WORDS + 4 * c->state_npad + c->state_rpad;
-        const int ncb = msak::bx_cols_pad(n) / 64;
+        const int ncb = msak::bx_cols_pad(n) / c->compact_cw;
         int bad = 0;
         unsigned long long key = 0;
         for (int i = 0; i < ncb; ++i) {
@@ -253,6 +255,9 @@ int compact_begin(msa_ctx *c, const int32_t *vhash, const float *dist, int npos,
     }
     msak::CompactArgs a = compact_args(c);
     a.sim = 1;
+    a.cw = c->compact_cw = msak::compact_front_cw(m, n, true, c->raw == c->h_raw.p);
+    a.xcd = c->tuning.front_xcd;
+    a.nt = msak::compact_front_nt(m, n, c->cus);
     a.lut = c->lut.p;
     a.planes = c->planes.p, a.nchunk = c->nchunk, a.m_pad = c->m_pad;
     a.codeT = c->codeT.p, a.ldk = msak::bx_ldk(m);

@@ -2,7 +2,10 @@
 the default switches, the serial flow, the side stream at any size, row-index lists, the sequential similarity kernel, host
 exponentials + packed uploads) against
 the oracle's trim -- masks, selected method, identity means, cut points.
-  python tests/fuzz/fuzz_trim.py [seconds=120] [seed=1]      (prints one JSON line; exit code 1 on the first mismatch)"""
+  python tests/fuzz/fuzz_trim.py [seconds=120] [seed=1] [tall]     (prints one JSON line; exit code 1 on the first mismatch)
+`tall` (round 6): 700 ... 2300 sequences x 16 ... 96 columns, dense around the dispatch thresholds at 1024 / 1025 (the compact
+pipeline hands over to the ordinary one) and 1799 / 1800 (six rounds of the similarity kernel per launch) and around 512 / 513 (the
+narrow front kernel, the sixteen-row pair tiles): the paths the BASELINE's C3 and C5 take, on random data, every trimmer kind."""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -14,6 +17,7 @@ from pytrimal_amd.matrix import SimilarityMatrix
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
 rng = np.random.default_rng(seed)
 AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a strict trim must raise where the oracle does
@@ -24,9 +28,12 @@ EXTRA = np.frombuffer(b"BZJUO", dtype=np.uint8)  # in no default matrix: a stric
 CONTEXTS = [dict(), dict(MSA_FLAT_MAX_M="512"), dict(MSA_FLAT_MAX_M="0", MSA_MDK_HOST="1"), dict(MSA_COMPACT="0", MSA_ZEROCOPY_KB="0"),
             dict(MSA_PIPELINE="0"), dict(MSA_PIPELINE="3"), dict(MSA_LG_BIG="1"), dict(MSA_SIM_KERNEL="seq"),
             dict(MSA_MDK_HOST="1", MSA_UPLOAD_DIRECT="0"), dict(MSA_LG_ROUNDS="1"), dict(MSA_LG_SPLIT="3"),
-            dict(MSA_LG_SPLIT="8", MSA_LG_ROUNDS="2")]
+            dict(MSA_LG_SPLIT="8", MSA_LG_ROUNDS="2"),
+            # (round 6) the front kernel and the pair tiles of 513 ... 1024 sequences: round 5's kernels, and the new ones in other shapes
+            dict(MSA_FRONT_CW="64", MSA_PAIR_TI="8"), dict(MSA_FRONT_CW="32", MSA_FRONT_NT="256", MSA_PAIR_K="2"),
+            dict(MSA_FRONT_CW="16", MSA_FRONT_NT="512", MSA_FRONT_XCD="0", MSA_PAIR_TI="16", MSA_PAIR_K="8", MSA_FRONT_FROM_M="130")]
 SWITCHES = ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_COMPACT",
-            "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB")
+            "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K")
 ctxs = []
 for env in CONTEXTS:
     for k in SWITCHES:
@@ -46,6 +53,17 @@ def alignment():
     n = int(rng.choice([1, 5, 31, 33, 64, 100, 257, 600, 1500])) + int(rng.integers(0, 7))
     if m <= 140 and rng.random() < 0.03:
         n = 5121 + int(rng.integers(0, 64))  # (more columns than the chip has wave slots: the compact pipeline sorts them)
+    if TALL:
+        r = rng.random()
+        if r < 0.2:
+            m = int(rng.choice([1023, 1024, 1025, 1026]))
+        elif r < 0.4:
+            m = int(rng.choice([1798, 1799, 1800, 1801]))
+        elif r < 0.5:
+            m = int(rng.choice([511, 512, 513, 514]))
+        else:
+            m = int(rng.integers(700, 2301))
+        n = int(rng.integers(16, 97))
     keep = float(rng.choice([0.2, 0.45, 0.6, 0.7, 0.85, 0.97]))
     root = AA[rng.integers(0, 20, n)]
     a = np.where(rng.random((m, n)) < keep, root[None, :], AA[rng.integers(0, 20, (m, n))])
@@ -88,6 +106,8 @@ def settings(m, n):
         if rng.random() < 0.3 and n >= 16:
             kw[str(rng.choice(["window", "gap_window", "similarity_window"]))] = int(rng.integers(1, max(2, min(6, n // 4))))
         return kw
+    if kind == 8 and m >= 2 and TALL and rng.random() < 0.5:  # (clusters=K probes the clustering a dozen times: every other case)
+        return dict(identity_threshold=float(rng.choice([0.2, 0.4, 0.6, 0.9])))
     if kind == 8 and m >= 2:
         return dict(identity_threshold=float(rng.choice([0.2, 0.4, 0.6, 0.9]))) if rng.random() < 0.6 else dict(clusters=int(rng.integers(1, m + 1)))
     return dict(residue_overlap=float(rng.choice([0.3, 0.6, 0.9])), sequence_overlap=float(rng.choice([20, 50, 80])))
@@ -140,4 +160,4 @@ while time.time() - t0 < budget:
     cases += 1
     raised += expect is not None
 print(json.dumps({"mismatch": False, "cases": cases, "contexts_per_case": len(ctxs), "cases_where_both_raise": int(raised),
-                  "seconds": round(time.time() - t0, 1), "seed": seed}))
+                  "seconds": round(time.time() - t0, 1), "seed": seed, "mode": "tall" if TALL else "default"}))

@@ -7,7 +7,11 @@ threshold in pytrimal_amd/csrc fails this file until the table is updated with i
 Thresholds covered (DESIGN.md section 11 lists them): rows read in place up to 96 KB; flat similarity kernel up to 128 rows
 (96 beyond 2560 columns: both waves of every column resident); compact pipeline up to 1024 rows, from 513 rows or 5121 columns on
 with the columns dealt by weight; side stream from m^2 n = 2 * 10^9; a launch every six rounds from 1800 rows; a workgroup per column from 2048 rows when the columns leave
-wave slots free; front kernel alone for gap-only trims up to 1024 rows and 4 MB; two rows per lane in the pair pass from 4096 rows."""
+wave slots free; front kernel alone for gap-only trims up to 1024 rows and 4 MB; sixteen rows i per tile of the pair pass from 513 rows,
+two rows j per lane from 4096 rows.
+
+The boundaries in columns are multiples of the device's compute units (10 and 20 per unit): the table is written for the MI355X's
+256 and is skipped on a device (or a partition of one) that reports another count."""
 import numpy as np
 import pytest
 
@@ -19,11 +23,19 @@ pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
                 "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
-                "MSA_DEVICE_CLUSTERS", "MSA_TRACE")
+                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K")
+
+
+def _compute_units():
+    import torch
+
+    return torch.cuda.get_device_properties(0).multi_processor_count
 
 
 @pytest.fixture
 def default_ctx(monkeypatch):
+    if _compute_units() != 256:
+        pytest.skip("the dispatch table is written for 256 compute units (its column boundaries are 10 and 20 per unit)")
     for name in MSA_SWITCHES:
         monkeypatch.delenv(name, raising=False)
     c = _lib.Context(0)
@@ -66,18 +78,18 @@ STRICT = [
     # --- compact pipeline: columns as they lie up to 512 rows and cus * 20 columns (every wave resident), dealt by weight beyond
     #     either; the ordinary pipeline from 1025 rows
     (512, 1000, dict(upload="packed", pipeline="compact", sim_writes_mdk=1, pair_kernel="pipe", **LG1)),
-    (513, 1000, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, pair_kernel="pipe", **LG1)),
+    (513, 1000, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, pair_kernel="pipe16", **LG1)),
     (300, 5120, dict(upload="linear", pipeline="compact", sim_writes_mdk=1, **LG1)),
     (300, 5121, dict(upload="repitched", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),   # 1.5 MB of 5121-byte rows: one linear copy + a kernel
     (200, 5121, dict(upload="packed", pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),      # (below a megabyte: packed pieces)
     (64, 20000, dict(pipeline="compact", sim_kernel="flat", sim_writes_mdk=1)),
-    (1000, 4000, dict(pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, **LG1)),
+    (1000, 4000, dict(pipeline="compact_sorted", sim_writes_mdk=1, sim_launches=1, pair_kernel="pipe16", pair_waves_per_tile=8, **LG1)),
     (1024, 2000, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
     (1024, 5121, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)),
     # --- side stream from m^2 n = 2e9
     (1025, 1903, dict(pipeline="one_stream", **LG1)),
     (1025, 1904, dict(pipeline="two_streams", **LG1)),
-    (1025, 2000, dict(pipeline="two_streams", **LG1)),
+    (1025, 2000, dict(pipeline="two_streams", pair_kernel="pipe16", pair_waves_per_tile=4, **LG1)),
     # --- a launch every six rounds from 1800 rows (29 rounds: one launch, or five)
     (1799, 700, dict(pipeline="two_streams", sim_launches=1, **LG1)),
     (1800, 700, dict(pipeline="two_streams", sim_launches=5, **LG1)),
@@ -85,8 +97,10 @@ STRICT = [
     (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
     (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=6)),
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
-    # --- pair pass: one row j per lane below 4096 rows (m_pad / 128 * ceil(m / 8) / 2 < 8192), two from there on
-    (4088, 64, dict(pair_kernel="pipe", pair_waves_per_tile=1, sim_kernel="lg")),
+    # --- pair pass: eight rows i per tile up to 512 rows, sixteen from 513 on (K waves per tile while tiles x K <= 10240); one row j
+    #     per lane below 4096 rows (m_pad / 128 * ceil(m / 8) / 2 < 8192), two from there on
+    (2000, 2100, dict(pair_kernel="pipe16", pair_waves_per_tile=4, sim_kernel="lg")),
+    (4088, 64, dict(pair_kernel="pipe16", pair_waves_per_tile=1, sim_kernel="lg")),
     (4096, 64, dict(pair_kernel="two_rows", pair_waves_per_tile=1, sim_kernel="lg")),
 ]
 
