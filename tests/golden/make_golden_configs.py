@@ -8,6 +8,8 @@ runs, where the oracle itself takes too long for a test:
   C3  AutomaticTrimmer('automated1')                                synth_msa(2000, 10000, 1003)
   C4  RepresentativeTrimmer(identity_threshold=0.5)                 synth_msa(5000, 5000, 1004)
   C5  AutomaticTrimmer('automated1') x 64                           synth_msa(1000, 4000, 2000 + k), k = 0..63
+  C3.s1004 .. C3.s1010 (round 6)  AutomaticTrimmer('automated1')    synth_msa(2000, 10000, 1003 + rank), rank = 1..7: the alignments
+      the ranks 1 .. 7 of `bench.py --workload C3 --gpus 8` trim (`seed + rank`)
 Stored per configuration: packed kept-column / kept-sequence masks, the selectMethod means (bit patterns), the
 cut points, and for C2 / C3 the similarity quotient Q of every column (bit patterns).
 
@@ -48,6 +50,13 @@ def c5_one(k):
     return k, np.packbits(res), np.packbits(seq), avgmax, np.array([info.selected, info.gap_cut], dtype=np.int32)
 
 
+def c3_rank(seed):
+    res, seq, info = oracle.trim(synth_msa(2000, 10000, seed), method="automated1")
+    rec = {}
+    record(rec, f"C3.s{seed}", res, seq, info)
+    return rec
+
+
 def main():
     out = {}
     a = synth_msa(500, 2000, 1002)
@@ -61,6 +70,8 @@ def main():
     with Pool(min(8, os.cpu_count() or 1)) as pool:
         for k, res, seq, avgmax, cuts in pool.imap_unordered(c5_one, range(64)):
             out[f"C5.{k}.res"], out[f"C5.{k}.seq"], out[f"C5.{k}.avgmax_bits"], out[f"C5.{k}.cuts"] = res, seq, avgmax, cuts
+        for rec in pool.imap_unordered(c3_rank, range(1004, 1011)):
+            out.update(rec)
     np.savez_compressed(os.path.join(HERE, "configs.npz"), **out)
     print(f"wrote {len(out)} arrays to tests/golden/configs.npz")
 

@@ -70,6 +70,29 @@ def test_c3_trim_golden(golden):
     assert np.array([info.sim_cut], dtype=np.float32).view(np.uint32).tolist() == golden["C3.simcut_bits"].tolist()
 
 
+def test_c3_rank_seeds_golden(golden):
+    """The alignments the ranks 1 .. 7 of `bench.py --workload C3 --gpus 8` trim (`seed + rank`: bench.py): masks, selectMethod's
+    means and the cut points of `automated1` at the headline's full size for seeds 1004 .. 1010 (round 5's suite knew seed 1003 only)."""
+    m, n = 2000, 10000
+    mx = SimilarityMatrix.aa()
+    vhash, dist = np.ascontiguousarray(mx._vhash, dtype=np.int32), np.ascontiguousarray(mx._dist, dtype=np.float32)
+    ctx = _lib.Context(0)
+    try:
+        p = _lib.TrimParams(_lib.METHOD_CODES["automated1"], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0,
+                            vhash.ctypes.data, dist.ctypes.data, len(mx))
+        for seed in range(1004, 1011):
+            key = f"C3.s{seed}"
+            ctx.upload(synth_msa(m, n, seed), ord("X"))
+            res, seq, info = ctx.trim(p)
+            assert np.array_equal(res, np.unpackbits(golden[f"{key}.res"])[:n].astype(bool)), f"{key}: kept-column mask"
+            assert np.array_equal(seq, np.unpackbits(golden[f"{key}.seq"])[:m].astype(bool)), f"{key}: kept-sequence mask"
+            assert np.array([info.avg_seq, info.max_seq], dtype=np.float32).view(np.uint32).tolist() == golden[f"{key}.avgmax_bits"].tolist(), key
+            assert [info.selected_method, info.gap_cut] == golden[f"{key}.cuts"].tolist(), key
+            assert np.array([info.sim_cut], dtype=np.float32).view(np.uint32).tolist() == golden[f"{key}.simcut_bits"].tolist(), key
+    finally:
+        ctx.close()
+
+
 def test_c4_representative_golden(golden):
     a = synth_msa(5000, 5000, 1004)
     t = RepresentativeTrimmer(identity_threshold=0.5, platform="hip").trim(ali_of(a))

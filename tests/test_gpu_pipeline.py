@@ -244,6 +244,24 @@ def test_random_trims_against_the_oracle(seed):
     assert line["mismatch"] is False and line["cases"] > 100
 
 
+def test_random_tall_trims_against_the_oracle():
+    """tests/fuzz/fuzz_trim.py in its `tall` mode (round 6): 700 ... 2300 sequences, dense around 1024 / 1025, 1799 / 1800 and
+    512 / 513 -- the compact pipeline with its columns dealt by weight, the hand-over to the ordinary pipeline, six rounds per launch,
+    the narrow front kernel and the sixteen-row pair tiles, i.e. the paths the BASELINE's C3 and C5 take -- on random data, every
+    trimmer kind, fifteen contexts per case, the oracle per case."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_trim.py"), "10", "33", "tall"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mismatch"] is False and line["mode"] == "tall" and line["cases"] > 30, line
+
+
 def test_public_api_from_threads_against_the_oracle():
     """tests/fuzz/fuzz_threads.py: four threads trimming random protein / DNA / RNA alignments through the four trimmer classes
     (type detection, default matrices, per-thread contexts) against the oracle's trim at the same time."""

@@ -6,6 +6,7 @@ OUT=gpurun_out/fuzz.txt
 run() { echo -n "$* -> " >> $OUT; timeout 2400 "$@" 2>/dev/null | tail -1 >> $OUT; }
 run python tests/fuzz/fuzz_trim.py ${1:-200} 707
 run python tests/fuzz/fuzz_trim.py ${1:-200} 808
+run python tests/fuzz/fuzz_trim.py ${3:-600} 909 tall
 run python tools/cross_check.py 600 13
 run python tests/fuzz/fuzz_threads.py ${2:-150} 4
 run python tests/fuzz/fuzz_batch.py ${2:-150} 505
