@@ -67,6 +67,7 @@ struct Engine {
         int32_t k;            // index in the call
         size_t res_word;      // offset (words) of its block in the result region: flags[16] gaps[npad] indets[npad] rowtot[mpad] mdk[n] q[n]
         int npad, mpad;
+        size_t extra_word;    // ... and of what its kind adds behind them (engine_needs 3 - 5)
     };
     struct Lane {
         // two queues per group: uploads and the short VALU-bound kernels (counts, planes, pair pass, lists) at HIGH priority,
@@ -98,13 +99,16 @@ inline size_t align_up(size_t x, size_t q) { return (x + q - 1) / q * q; }
 
 // Can the engine take alignment k?  (the similarity pipeline's conditions, one pair-pass regime, 32-bit list offsets, rows the
 // copy engine takes in one piece or that are small enough to pack on the way)
-// what a column-mode trim needs of the device: 0 not a column-mode trim the engine knows, 1 the gap statistics alone (gappyout,
-// nogaps, noallgaps, a manual gap threshold), 2 the similarity pipeline as well
+// what a trim needs of the device: 0 not a trim the engine knows, 1 the gap statistics alone (gappyout, nogaps, noallgaps, a
+// manual gap threshold), 2 the similarity pipeline as well, 3 - 5 the trimmers that remove sequences (below)
 int engine_needs(const msa_trim_params *p) {
     const int method = p->method;
-    const bool column_mode = method != MSA_METHOD_NODUPLICATESEQS && p->clusters == -1 && p->max_identity == -1 &&
-                             !(p->residue_overlap != -1 && p->sequence_overlap != -1);
-    if (!column_mode) return 0;
+    // the trimmers that remove sequences (round 6): their statistics come back with the group's one copy as well, and the
+    // selection runs on the host-only view -- 3 OverlapTrimmer (the overlap counts of every sequence), 4 RepresentativeTrimmer
+    // (the identities: clustered on the host, threshold mode and clusters=K alike), 5 noduplicateseqs (row digests)
+    if (method == MSA_METHOD_NODUPLICATESEQS) return 5;
+    if (p->clusters != -1 || p->max_identity != -1) return 4;
+    if (p->residue_overlap != -1 && p->sequence_overlap != -1) return 3;
     if (method == MSA_METHOD_STRICT || method == MSA_METHOD_STRICTPLUS || method == MSA_METHOD_AUTOMATED1 ||
         (method == MSA_METHOD_NONE && p->similarity_threshold != -1))
         return 2;
@@ -122,8 +126,15 @@ bool engine_takes(const msa_batch *b, int32_t k, const msa_trim_params *ref) {
     if (!needs) return false;
     int gap_hw = p->gap_window, sim_hw = p->similarity_window;
     if (p->window != -1) gap_hw = sim_hw = p->window;
-    if (gap_hw > 0) return false;
-    if (needs == 1) return (double)m * n <= 4e6;  // (the gap statistics alone: small alignments, where launches are the cost)
+    // (a gap window is host work on the counts -- unless the similarity pipeline follows: its ">= 80 % gaps" cut reads the windowed
+    // counts on the device)
+    if (gap_hw > 0 && needs == 2) return false;
+    if (gap_hw > n / 4) return false;  // (an error return: the ordinary path reports it)
+    if (needs == 1 || needs == 3 || needs == 5) return (double)m * n <= 4e6;  // (one pass over the rows: small alignments, where launches are the cost)
+    if (needs == 4) {  // the pair pass, and m x m identities in the group's copy back
+        const int m_pad4 = round_up(m, 128);
+        return m <= 1024 && msak::pair_pipe_regime(m, m_pad4) && (double)m * m * n <= b->engine_max_work;
+    }
     if (sim_hw > n / 4) return false;
     if (!p->vhash || !p->dist || p->npos < 1 || p->npos > 28) return false;
     // one set of tables per call: the first taken alignment's
@@ -177,7 +188,11 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         it.mpad = round_up(m + 64, 64);
         it.res_word = res_words;
         res_words += 16 + (size_t)2 * it.npad + it.mpad + (size_t)2 * it.npad;
-        if (engine_needs(b->params + k) == 2) max_m = std::max(max_m, m), any_sim = i;
+        const int kind = engine_needs(b->params + k);
+        if (kind == 2) max_m = std::max(max_m, m), any_sim = i;
+        // what the kind brings back beside the common vectors: overlap counts [mpad]; identities [m][ldw]; lengths [mpad] + hashes
+        it.extra_word = res_words;
+        res_words += kind == 3 ? (size_t)it.mpad : kind == 4 ? (size_t)m * round_up(m, 64) : kind == 5 ? (size_t)5 * it.mpad : 0;
         mix(((uint64_t)(uint32_t)m << 32) | (uint32_t)n);
         mix(b->params[k].method == MSA_METHOD_AUTOMATED1);
         mix(engine_needs(b->params + k));
@@ -236,7 +251,15 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         const size_t ld = round_up(n, 64), nchunk = (n + 31) / 32, m_pad = round_up(m, 128), ldw = round_up(m, 64);
         const size_t ncp = msak::bx_cols_pad(n), ldk = msak::bx_ldk(m);
         EngineLayout &y = lay[i];
-        if (engine_needs(b->params + k) < 2) {  // the gap statistics alone: the rows are all it needs on the device
+        const int kind = engine_needs(b->params + k);
+        if (kind == 4) {  // RepresentativeTrimmer: planes and the pair pass; the identities land in the result region
+            y.ident = y.w = y.wlow = y.wbar = y.row_avg = y.row_max = y.codeT = y.codeR = y.off = y.trow = y.nvalid = y.simnum = y.simden =
+                y.simstate = y.cols = 0;
+            y.planes = take(((size_t)msak::planes_total() * nchunk * m_pad + 64) * 4);
+            y.end = off;
+            continue;
+        }
+        if (kind != 2) {  // the gap statistics (and what one more pass over the rows computes): the rows are all it needs on the device
             y.planes = y.ident = y.w = y.wlow = y.wbar = y.row_avg = y.row_max = y.codeT = y.codeR = y.off = y.trow = y.nvalid = y.simnum =
                 y.simden = y.simstate = 0;
             y.end = off;
@@ -271,7 +294,7 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     HIPCHK(tc, L.arena.reserve(arena_bytes));
     mix((uint64_t)(uintptr_t)L.arena.p);
     // tables: [BAlign K][LgAlign K][prefix arrays: F x (K + 1)]
-    enum { F_FETCH, F_GAPS, F_ROWTOT, F_PLANES, F_PAIRS, F_WMEANS, F_IDROWS, F_ENCODE, F_COMPACT, F_FINISH, F_COLS, F_COUNT };  // (F_ENCODE / F_COLS: by mode)
+    enum { F_FETCH, F_GAPS, F_ROWTOT, F_PLANES, F_PAIRS, F_WMEANS, F_IDROWS, F_ENCODE, F_COMPACT, F_FINISH, F_COLS, F_OVERLAP, F_DIGEST, F_COUNT };  // (F_ENCODE / F_COLS: by mode)
     const size_t meta_bytes = align_up((size_t)K * sizeof(msak::BAlign), 256) + align_up((size_t)K * sizeof(msak::LgAlign), 256) +
                               align_up((size_t)F_COUNT * (K + 1) * sizeof(int32_t), 256);
     HIPCHK(tc, L.meta.reserve(meta_bytes));
@@ -312,10 +335,14 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         d.indets = d.gaps + it.npad;
         d.rowtot = d.indets + it.npad;
         d.mdk = reinterpret_cast<float *>(d.rowtot + it.mpad);
-        d.gated = b->params[k].method == MSA_METHOD_AUTOMATED1;
+        d.kind = engine_needs(b->params + k);
+        d.extra = res_d + it.extra_word;
+        d.gated = d.kind == 2 && b->params[k].method == MSA_METHOD_AUTOMATED1;
         d.ident = d.gated ? reinterpret_cast<float *>(A + y.ident) : nullptr;
         d.w = reinterpret_cast<float *>(A + y.w);
         d.wlow = reinterpret_cast<float *>(A + y.wlow);
+        if (d.kind == 4) d.ident = reinterpret_cast<float *>(d.extra), d.w = nullptr, d.wlow = nullptr;
+        if (d.kind == 3) d.ov_need = static_cast<int>(std::ceil(b->params[k].residue_overlap * static_cast<float>(m - 1)));
         d.wbar = reinterpret_cast<float *>(A + y.wbar);
         d.row_avg = reinterpret_cast<float *>(A + y.row_avg);
         d.row_max = reinterpret_cast<float *>(A + y.row_max);
@@ -335,12 +362,16 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         g.wlow = d.wlow, g.wup = d.w, g.wbar = d.wbar, g.num_out = d.simnum, g.den_out = d.simden;
         g.state = multi ? reinterpret_cast<float *>(A + y.simstate) : nullptr;
         g.gate = d.gated ? d.flags + ST_GATE : nullptr;
-        const bool sim = engine_needs(b->params + k) == 2;
+        const bool sim = d.kind == 2;
         // (only the alignments whose trim runs the similarity kernel: max_m -- the sort's LDS bins -- is taken over those)
         g.cols = sort_cols && sim ? reinterpret_cast<const int32_t *>(A + y.cols) : nullptr;
         g.ldk = d.ldk, g.m = m, g.n = n, g.ldw = d.ldw, g.ncols = n;
         lt[i] = g;
-        auto add = [&](int f, int blocks) { pf[(size_t)f * (K + 1) + i + 1] = pf[(size_t)f * (K + 1) + i] + ((sim || f <= F_ROWTOT) ? blocks : 0); };
+        auto add = [&](int f, int blocks) {
+            const bool runs = sim || f <= F_ROWTOT || (d.kind == 4 && (f == F_PLANES || f == F_PAIRS)) || (d.kind == 3 && f == F_OVERLAP) ||
+                              (d.kind == 5 && f == F_DIGEST);
+            pf[(size_t)f * (K + 1) + i + 1] = pf[(size_t)f * (K + 1) + i] + (runs ? blocks : 0);
+        };
         add(F_FETCH, fetch[i] ? (int)(((int64_t)m * (d.ld / 16) + 255) / 256) : 0);
         add(F_GAPS, (int)((d.ld / 4 + 255) / 256) * ((m + 63) / 64));
         add(F_ROWTOT, (m + 3) / 4);
@@ -352,6 +383,8 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
         add(F_COMPACT, cols_mode ? 0 : (d.ncols_pad + 3) / 4);
         add(F_FINISH, (n + 255) / 256);
         add(F_COLS, cols_mode ? (n + 63) / 64 : n);
+        add(F_OVERLAP, d.kind == 3 ? (m + 3) / 4 : 0);
+        add(F_DIGEST, d.kind == 5 ? (m + 3) / 4 : 0);
     }
     auto PF = [&](int f) { return pf_d + (size_t)f * (K + 1); };
     auto NB = [&](int f) { return pf[(size_t)f * (K + 1) + K]; };
@@ -403,10 +436,14 @@ int engine_enqueue(msa_batch *b, Engine *e, Engine::Lane &L, const std::vector<i
     msak::launch_gap_counts_batch(st, bt_d, PF(F_GAPS), K, NB(F_GAPS));
     if (sort_cols) msak::launch_sort_columns_batch(st, bt_d, lt_d, K, max_m);
     msak::launch_row_nongap_batch(st, bt_d, PF(F_ROWTOT), K, NB(F_ROWTOT));
+    msak::launch_overlap_rows_batch(st, bt_d, PF(F_OVERLAP), K, NB(F_OVERLAP));
+    msak::launch_row_digest_batch(st, bt_d, PF(F_DIGEST), K, NB(F_DIGEST));
     msak::launch_prep_planes_batch(st, bt_d, PF(F_PLANES), K, NB(F_PLANES));
     int min_nchunk = 1 << 30;
-    for (int i = 0; i < K; ++i)
-        if (engine_needs(b->params + ks[i]) == 2) min_nchunk = std::min(min_nchunk, (b->n[ks[i]] + 31) / 32);
+    for (int i = 0; i < K; ++i) {
+        const int kind = engine_needs(b->params + ks[i]);
+        if (kind == 2 || kind == 4) min_nchunk = std::min(min_nchunk, (b->n[ks[i]] + 31) / 32);
+    }
     msak::launch_pair_counts_batch(st, bt_d, PF(F_PAIRS), K, NB(F_PAIRS), min_nchunk);
     msak::launch_w_row_means_batch(st, bt_d, PF(F_WMEANS), K, NB(F_WMEANS));
     msak::launch_identity_stats_batch(st, bt_d, PF(F_IDROWS), K, NB(F_IDROWS));
@@ -449,6 +486,24 @@ void engine_select_item(msa_batch *b, Engine::Lane &L, const Engine::Item &it, m
     v->h_f32.p = reinterpret_cast<float *>(flags + 16 + 2 * it.npad + it.mpad);
     v->pairflag_state = 2;
     v->have_gaps = true;
+    // what the trimmers that remove sequences read (engine_needs 3 - 5)
+    const int kind = engine_needs(b->params + k);
+    const int32_t *extra = res + it.extra_word;
+    v->ov_valid = false;
+    v->pref_ident = nullptr, v->pref_lengths = nullptr, v->pref_hashes = nullptr;
+    if (kind == 3) {  // Cleaner::calculateSpuriousVector's values, as overlap() derives them from the counts
+        v->ov_vals.resize(m);
+        for (int i = 0; i < m; ++i) v->ov_vals[i] = static_cast<float>(extra[i]) / n;
+        v->ov_key = b->params[k].residue_overlap;
+        v->ov_valid = true;
+        v->ov_colcnt = false;
+    } else if (kind == 4) {
+        v->pref_ident = reinterpret_cast<const float *>(extra);
+        v->ldw = round_up(m, 64);
+    } else if (kind == 5) {
+        v->pref_lengths = extra;
+        v->pref_hashes = reinterpret_cast<const unsigned long long *>(extra + it.mpad);
+    }
     msa_trim_info local;
     msa_trim_info *info = b->info ? b->info + k : &local;
     int rc;

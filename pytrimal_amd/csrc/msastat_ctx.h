@@ -198,6 +198,9 @@ struct msa_ctx {
     bool prefetched = false;
     const uint8_t *host_rows = nullptr;  // ... and the caller's rows (host memory), for the rare selection that looks at residues again
     int64_t host_ld = 0;
+    const float *pref_ident = nullptr;               // (RepresentativeTrimmer in the engine) the identities [m][ldw] in the result buffer
+    const int32_t *pref_lengths = nullptr;           // (noduplicateseqs in the engine) the rows' ungapped lengths ...
+    const unsigned long long *pref_hashes = nullptr;  // ... and their two hashes each
 
     // host copies valid for the current alignment
     std::vector<int32_t> h_gaps, h_indets;

@@ -114,6 +114,13 @@ struct BAlign {
     int32_t m, n, nchunk, m_pad, ldw, ncols_pad;
     uint32_t indet4;
     int32_t gated;            // automated1: the identity statistics decide on the device whether the similarity values are needed
+    // what the alignment's trim needs of the device (msa_trim_batch's engine: engine_needs): 1 the gap statistics alone, 2 the
+    // similarity pipeline, 3 OverlapTrimmer's counts as well (ov_need, -> extra[m]), 4 the identities (ident points into the
+    // result region: RepresentativeTrimmer clusters on the host-only view), 5 row digests (noduplicateseqs: extra = lengths
+    // [round_up(m + 64, 64)], then two 64-bit hashes per row)
+    int32_t kind;
+    int32_t ov_need;          // kind 3: ceil(residue_overlap x (m - 1)) -- sequences that must agree with a residue
+    int32_t *extra;
 };
 // The compact pipeline of one small alignment (msa_trim): THREE launches -- everything that reads the rows (gap counts, row
 // totals, planes, codes + lists), the pair pass (which also sums the rows' weights), the similarity kernel with the MDK values
@@ -180,6 +187,10 @@ void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t 
 void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, int min_nchunk);  // min_nchunk: over the group
 void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_w_row_means_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+// OverlapTrimmer's counts (kind 3: a wave per sequence, the closed form over the group's gap / indetermination counts) and
+// noduplicateseqs' row digests (kind 5), for every such alignment of a group
+void launch_overlap_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
+void launch_row_digest_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_identity_stats_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks);
 void launch_sim_encode_rm_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, const uint8_t *lut);
 void launch_similarity_cols_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int total, const void *tab);

@@ -365,10 +365,9 @@ __global__ __launch_bounds__(256) void col_nongap_kernel(const uint8_t *__restri
 }
 
 // per-row ungapped length + 2x64-bit row hash (duplicate detection, representative ordering)
-__global__ __launch_bounds__(256) void row_digest_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
-                                                         int32_t *__restrict__ lengths,
-                                                         unsigned long long *__restrict__ hashes) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void row_digest_body(const uint8_t *__restrict__ raw, int m, int n, int64_t ld, int32_t *__restrict__ lengths,
+                                                unsigned long long *__restrict__ hashes, int bx) {
+    const int row = bx * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= m) return;
     const uint8_t *p = raw + (size_t)row * ld;
@@ -396,6 +395,47 @@ __global__ __launch_bounds__(256) void row_digest_kernel(const uint8_t *__restri
         hashes[2 * row] = h1;
         hashes[2 * row + 1] = h2;
     }
+}
+__global__ __launch_bounds__(256) void row_digest_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                         int32_t *__restrict__ lengths,
+                                                         unsigned long long *__restrict__ hashes) {
+    row_digest_body(raw, m, n, ld, lengths, hashes, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void row_digest_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int mpad = (d.m + 64 + 63) / 64 * 64;  // (the engine's row padding: lengths [mpad], then the hashes, 8-byte aligned)
+    row_digest_body(d.raw, d.m, d.n, d.ld, d.extra, reinterpret_cast<unsigned long long *>(d.extra + mpad), local);
+}
+// OverlapTrimmer in a batch: Cleaner::calculateSpuriousVector's closed form, a wave per sequence, over the group's own gap and
+// indetermination counts (overlap_small_kernel's walk: four columns per lane and load)
+__global__ __launch_bounds__(256) void overlap_rows_batch_kernel(const BAlign *__restrict__ table, const int32_t *__restrict__ prefix, int K) {
+    int local;
+    const BAlign d = batch_desc(table, batch_find(prefix, K, (int)blockIdx.x, local));
+    const int row = local * 4 + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int m = d.m, n = d.n, need = d.ov_need;
+    if (row >= m) return;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(d.raw + (size_t)row * d.ld);
+    int cnt = 0;
+    for (int c4 = lane; c4 * 4 < n; c4 += 64) {
+        const uint32_t x = p[c4];
+        const i4 g4 = *reinterpret_cast<const i4 *>(d.gaps + 4 * c4), x4 = *reinterpret_cast<const i4 *>(d.indets + 4 * c4);
+        const uint32_t isg = zero_bytes(x ^ 0x2d2d2d2du), isi = zero_bytes(x ^ d.indet4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c4 * 4 + k < n) {
+                const int g = g4[k], xi = x4[k];
+                const bool gap = (isg >> (8 * k + 7)) & 1u, ind = (isi >> (8 * k + 7)) & 1u;
+                const int agree = gap ? g : (ind ? xi : m - g - xi);  // sequences that hold the same kind of symbol, this one included
+                cnt += (agree - 1) >= need ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if (lane == 0) d.extra[row] = cnt;
 }
 
 // exact row equality for candidate pairs (hash-equal rows)
@@ -669,6 +709,12 @@ void launch_prep_planes_batch(hipStream_t s, const BAlign *table, const int32_t 
 void launch_pair_counts_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks, int min_nchunk) {
     const int W = pair_split(blocks, min_nchunk);  // (one value for the launch: by the tiles of the whole group)
     if (blocks > 0) pair_counts_batch_kernel<<<blocks, 64 * W, (size_t)(W - 1) * 2 * PAIR_TI * 64 * sizeof(uint32_t), s>>>(table, prefix, K);
+}
+void launch_overlap_rows_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) overlap_rows_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
+}
+void launch_row_digest_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
+    if (blocks > 0) row_digest_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K);
 }
 void launch_sim_finish_batch(hipStream_t s, const BAlign *table, const int32_t *prefix, int K, int blocks) {
     if (blocks > 0) sim_finish_batch_kernel<<<blocks, 256, 0, s>>>(table, prefix, K, tuning().mdk_host);

@@ -635,8 +635,13 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
     const int m = c->m;
     std::vector<int32_t> lengths;
     std::vector<unsigned long long> hashes;
-    int rc = row_digest(c, lengths, &hashes);
-    if (rc) return rc;
+    if (c->prefetched) {  // (the batch engine's host-only view: the digests came back with the group's copy)
+        if (!c->pref_hashes || !c->host_rows) return MSA_E_FALLBACK;
+        hashes.assign(c->pref_hashes, c->pref_hashes + 2 * (size_t)m);
+    } else {
+        int rc = row_digest(c, lengths, &hashes);
+        if (rc) return rc;
+    }
     // candidate pairs: for each row i, the first later row x with equal digest
     struct Key {
         unsigned long long a, b;
@@ -658,6 +663,13 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
     }
     const int npairs = static_cast<int>(pairs.size() / 2);
     if (npairs == 0) return MSA_OK;
+    if (c->prefetched) {  // rows of equal digests compared where they lie, on the host (rare, and the rows are the caller's)
+        for (int p = 0; p < npairs; ++p) {
+            const uint8_t *x = c->host_rows + (size_t)pairs[2 * p] * c->host_ld, *y = c->host_rows + (size_t)pairs[2 * p + 1] * c->host_ld;
+            if (std::memcmp(x, y, (size_t)c->n) == 0) keep_seq[std::min(pairs[2 * p], pairs[2 * p + 1])] = 0;
+        }
+        return MSA_OK;
+    }
     HIPCHK(c, c->pairs.reserve(pairs.size()));
     HIPCHK(c, c->equal.reserve(npairs));
     HIPCHK(c, hipMemcpyAsync(c->pairs.p, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -676,7 +688,7 @@ int remove_duplicates(msa_ctx *c, uint8_t *keep_seq) {
 // round-based independent-set kernel on the device, mask to the host (m bytes).
 int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
     const int m = c->m;
-    if (m < 2) return MSA_E_FALLBACK;
+    if (m < 2 || c->prefetched) return MSA_E_FALLBACK;  // (a host-only view clusters on the host, from the identities it holds)
     // the ungapped lengths first (msa_trim staged them), then the pair pass: the processing order is sorted on the
     // host while it runs
     int rc = stage_row_totals(c);
@@ -717,7 +729,7 @@ int device_representatives(msa_ctx *c, float max_identity, uint8_t *keep_seq) {
 // selectMethod mean, same order of operations), every probe is one run of the device clustering: no m*m transfer.
 int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
     const int m = c->m;
-    if (m < 2 || clusters < 1) return MSA_E_FALLBACK;
+    if (m < 2 || clusters < 1 || c->prefetched) return MSA_E_FALLBACK;
     // below ~2000 sequences the m*m copy (< 16 MB) is cheaper than a synchronisation per probe: host path
     if (c->tuning.device_clusters == 0 || (m < 2000 && c->tuning.device_clusters < 0)) return MSA_E_FALLBACK;
     int rc = run_pairs(c, true, false, false);
@@ -790,6 +802,12 @@ int device_cluster_count(msa_ctx *c, int clusters, uint8_t *keep_seq) {
 }
 
 int fetch_ident(msa_ctx *c, std::vector<float> &host) {  // dense m*m copy of the identity matrix
+    if (c->prefetched) {
+        if (!c->pref_ident) return MSA_E_FALLBACK;
+        host.resize((size_t)c->m * c->m);
+        for (int i = 0; i < c->m; ++i) std::memcpy(host.data() + (size_t)i * c->m, c->pref_ident + (size_t)i * c->ldw, sizeof(float) * c->m);
+        return MSA_OK;
+    }
     int rc = run_pairs(c, true, false, false);
     if (rc) return rc;
     host.resize((size_t)c->m * c->m);

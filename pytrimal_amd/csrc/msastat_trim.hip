@@ -443,9 +443,12 @@ int trim_impl(msa_ctx *c, const msa_trim_params *p, uint8_t *keep_res, uint8_t *
                             (method == MSA_METHOD_NONE && p->similarity_threshold != -1);
     const bool pipelined = column_mode && (sim_always || method == MSA_METHOD_AUTOMATED1) && sim_pipeline_applies(c, p, sim_hw);
     if (c->prefetched) {
-        // (the engine only takes these: the similarity pipeline, or a trim that needs the gap statistics alone; no windows)
-        if (gap_hw != 0 || (int)c->h_gaps.size() != n || !(pipelined || engine_needs(p) == 1)) return MSA_E_FALLBACK;
-        gaps_w = c->h_gaps;
+        // (what the engine takes: the similarity pipeline without a gap window, a trim that needs the gap statistics alone, the
+        // trimmers that remove sequences -- their statistics are in the view: engine_needs)
+        const int kind = engine_needs(p);
+        if ((int)c->h_gaps.size() != n || !((pipelined && gap_hw == 0) || kind == 1 || kind >= 3)) return MSA_E_FALLBACK;
+        gaps_w.resize(n);
+        if ((rc = msah::window_i32(c->h_gaps.data(), n, gap_hw, gaps_w.data()))) return rc;
         c->pipe_active = pipelined;
         c->pipe_gated = pipelined && method == MSA_METHOD_AUTOMATED1;
     } else if (pipelined && compact_sim_applies(c, gap_hw) &&

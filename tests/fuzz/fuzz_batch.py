@@ -39,13 +39,15 @@ def alignment():
         a[0, : max(1, n // 40)] = ord("A")
     if rng.random() < 0.1:
         a[rng.integers(0, m), rng.integers(0, n)] = ord("O")  # not in the matrix: a similarity trim must raise
+    if rng.random() < 0.2 and m > 3:  # duplicated rows
+        a[rng.integers(0, m)] = a[rng.integers(0, m)]
     return np.ascontiguousarray(a)
 
 
 METHODS = ["strict", "strictplus", "automated1", "gappyout", "nogaps", "noallgaps"]
 
 
-def settings():
+def settings(m=6):
     r = rng.random()
     if r < 0.6:
         return dict(method=str(rng.choice(METHODS)))
@@ -54,11 +56,17 @@ def settings():
     if r < 0.8:
         return dict(similarity_threshold=float(rng.choice([0.1, 0.4])), gap_threshold=float(rng.choice([0.5, 0.8])),
                     conservation_percentage=float(rng.choice([20, 60])))
+    if r < 0.84:
+        return dict(method="strict", window=int(rng.integers(1, 4)))  # (a gap window in front of the similarity pipeline: not the engine's)
     if r < 0.87:
-        return dict(method="strict", window=int(rng.integers(1, 4)))  # (windows: not the engine's)
-    if r < 0.94:
-        return dict(residue_overlap=0.6, sequence_overlap=50.0)
-    return dict(identity_threshold=float(rng.choice([0.3, 0.6])))
+        return dict(gap_threshold=float(rng.choice([0.3, 0.8])), gap_window=int(rng.integers(1, 3)))  # (... on a gap-only trim: the engine's)
+    if r < 0.92:
+        return dict(residue_overlap=float(rng.choice([0.3, 0.6, 0.9])), sequence_overlap=float(rng.choice([20.0, 50.0, 80.0])))
+    if r < 0.95:
+        return dict(method="noduplicateseqs")
+    if r < 0.98:
+        return dict(identity_threshold=float(rng.choice([0.3, 0.6])))
+    return dict(clusters=int(rng.integers(1, min(m, 6) + 1)))
 
 
 def params_for(kw):
@@ -73,6 +81,10 @@ def params_for(kw):
         P.conservation_percentage = kw["conservation_percentage"]
     if "window" in kw:
         P.window = kw["window"]
+    if "gap_window" in kw:
+        P.gap_window = kw["gap_window"]
+    if "clusters" in kw:
+        P.clusters = kw["clusters"]
     if "residue_overlap" in kw:
         P.residue_overlap, P.sequence_overlap = kw["residue_overlap"], kw["sequence_overlap"]
     if "identity_threshold" in kw:
@@ -92,10 +104,10 @@ failures = []
 while time.time() < t_end and not failures:
     count = int(rng.choice([2, 5, 17, 60, 300]))
     if count > 60:
-        items = [(alignment(), settings()) for _ in range(12)]
+        items = [(a, settings(a.shape[0])) for a in (alignment() for _ in range(12))]
         items = [items[int(i)] for i in rng.integers(0, 12, count)]  # (many alignments, few distinct ones: the oracle is the slow side)
     else:
-        items = [(alignment(), settings()) for _ in range(count)]
+        items = [(a, settings(a.shape[0])) for a in (alignment() for _ in range(count))]
     batch = batch_engine if rng.random() < 0.5 else batch_default
     out = batch.trim([(a, ord("X"), params_for(kw)) for a, kw in items])
     memo = {}

@@ -183,12 +183,13 @@ def test_native_batch_equals_one_by_one():
 def test_batch_engine_against_single_trims(monkeypatch, cols_max):
     """`msa_trim_batch`'s engine (one launch per kernel family for a whole group of alignments, the selection on host-only
     views) on 60 alignments of random shapes up to 500 x 900 with gap-heavy rows and columns, the trimmers it takes (the
-    similarity pipeline, and the trims that need the gap statistics alone) --
+    similarity pipeline, the trims that need the gap statistics alone, and -- round 6 -- OverlapTrimmer, RepresentativeTrimmer in both
+    modes, noduplicateseqs and gap windows on gap-only trims) --
     against one trim at a time, which goes through an ordinary context.  cols_max: the row count up to which a group's
     similarity statistic runs with a lane per column (default 128; 0: the wave-per-column kernel for every group)."""
     import warnings
 
-    from pytrimal_amd import ManualTrimmer, _lib
+    from pytrimal_amd import ManualTrimmer, OverlapTrimmer, RepresentativeTrimmer, _lib
     from pytrimal_amd import batch as batch_mod
     from pytrimal_amd.batch import trim_batch
 
@@ -206,12 +207,19 @@ def test_batch_engine_against_single_trims(monkeypatch, cols_max):
             a[0, : max(1, n // 50)] = ord("A")
         if k % 7 == 0:
             a[:, rng.integers(0, n, max(1, n // 4))] = ord("-")
+        if k % 6 == 0 and m > 4:  # duplicated rows (noduplicateseqs: the later one stays)
+            a[m - 1] = a[1]
+            a[m // 2] = a[1]
         alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in np.ascontiguousarray(a)]))
     for trimmer in (AutomaticTrimmer("strict", platform="hip"), AutomaticTrimmer("automated1", platform="hip"),
                     AutomaticTrimmer("strictplus", platform="hip"), ManualTrimmer(similarity_threshold=0.3, platform="hip"),
                     AutomaticTrimmer("gappyout", platform="hip"), AutomaticTrimmer("nogaps", platform="hip"),
                     AutomaticTrimmer("noallgaps", platform="hip"), ManualTrimmer(gap_threshold=0.7, platform="hip"),
-                    ManualTrimmer(gap_threshold=0.6, similarity_threshold=0.2, conservation_percentage=40, platform="hip")):
+                    ManualTrimmer(gap_threshold=0.6, similarity_threshold=0.2, conservation_percentage=40, platform="hip"),
+                    # (round 6) the trimmers that remove sequences, and a gap window on a gap-only trim: the engine's as well
+                    OverlapTrimmer(60.0, 0.5, platform="hip"), OverlapTrimmer(30.0, 0.9, platform="hip"),
+                    RepresentativeTrimmer(identity_threshold=0.3, platform="hip"), RepresentativeTrimmer(clusters=3, platform="hip"),
+                    AutomaticTrimmer("noduplicateseqs", platform="hip"), ManualTrimmer(gap_threshold=0.7, gap_window=2, platform="hip")):
         with warnings.catch_warnings(record=True) as from_batch:
             warnings.simplefilter("always")
             trim_batch(trimmer, alis, threads=3)

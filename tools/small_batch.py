@@ -1,5 +1,5 @@
 """Many small alignments through trim_batch: `count` x (m x n), strict, ms per batch with the engine (batched kernels) and
-with the workers alone (MSA_BATCH_ENGINE=0).   python tools/small_batch.py [count m n]"""
+with the workers alone (MSA_BATCH_ENGINE=0).   python tools/small_batch.py [count m n [method | overlap | representative]]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,14 @@ alis = []
 for k in range(count):
     a = synth_msa(m, n, 7000 + k)
     alis.append(Alignment([b"s%d" % i for i in range(a.shape[0])], [bytes(r) for r in a]))
-tr = AutomaticTrimmer(method, platform="hip")
+if method == "overlap":  # (round 6: the trimmers that remove sequences go through the engine as well)
+    from pytrimal_amd import OverlapTrimmer
+    tr = OverlapTrimmer(60.0, 0.5, platform="hip")
+elif method == "representative":
+    from pytrimal_amd import RepresentativeTrimmer
+    tr = RepresentativeTrimmer(identity_threshold=0.5, platform="hip")
+else:
+    tr = AutomaticTrimmer(method, platform="hip")
 trim_batch(tr, alis, threads=4, masks_only=True)
 ts = []
 for _ in range(5):
