@@ -78,8 +78,9 @@ def similarity_kernel_clock(a, vhash, dist):
 
     lib = _lib.load()
     lib.msa_debug_bx_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    saved = {k: os.environ.get(k) for k in ("MSA_SIM_MODE",)}
+    saved = {k: os.environ.get(k) for k in ("MSA_SIM_MODE", "MSA_DIAGNOSTICS")}
     os.environ["MSA_SIM_MODE"] = "64"
+    os.environ["MSA_DIAGNOSTICS"] = "1"  # (the switches are honoured only under this one)
     try:
         c = _lib.Context(0 if "LOCAL_RANK" not in os.environ else int(os.environ["LOCAL_RANK"]))
     finally:

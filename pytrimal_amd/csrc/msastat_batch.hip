@@ -617,7 +617,8 @@ int engine_run(msa_batch *b, const std::vector<int32_t> &ks) {
             e->views.push_back(v);
         }
         e->trace = std::getenv("MSA_TRACE") != nullptr;
-        if (const char *ev = std::getenv("MSA_BATCH_COLS_MAX")) e->cols_max_m = std::min(128, std::atoi(ev));  // (the kernel's LDS tile)
+        if (msak::diagnostics_enabled())
+            if (const char *ev = std::getenv("MSA_BATCH_COLS_MAX")) e->cols_max_m = std::min(128, std::atoi(ev));  // (the kernel's LDS tile)
         b->engine = e;
     }
     Engine *e = b->engine;
@@ -768,9 +769,11 @@ int msa_batch_create(int device, int32_t workers, msa_batch **out) {
     msa_batch *b = new (std::nothrow) msa_batch();
     if (!b) return MSA_E_NOMEM;
     b->device = device;
-    if (const char *e = std::getenv("MSA_BATCH_ENGINE")) b->use_engine = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MSA_BATCH_ENGINE_MAX")) b->engine_max_work = std::atof(e);
-    if (const char *e = std::getenv("MSA_BATCH_ENGINE_MIN")) b->engine_min_count = std::atoi(e);
+    if (msak::diagnostics_enabled()) {  // (MSA_DIAGNOSTICS: msastat_kernels.hip)
+        if (const char *e = std::getenv("MSA_BATCH_ENGINE")) b->use_engine = std::atoi(e) != 0;
+        if (const char *e = std::getenv("MSA_BATCH_ENGINE_MAX")) b->engine_max_work = std::atof(e);
+        if (const char *e = std::getenv("MSA_BATCH_ENGINE_MIN")) b->engine_min_count = std::atoi(e);
+    }
     for (int w = 0; w < workers; ++w) {
         msa_ctx *c = nullptr;
         const int rc = msa_ctx_create(device, &c);

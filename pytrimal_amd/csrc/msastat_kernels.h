@@ -5,7 +5,7 @@
 
 namespace msak {
 
-// Diagnostic switches (environment variables MSA_*), read ONCE when a context is created and handed to the
+// Diagnostic switches (environment variables MSA_*; honoured only when MSA_DIAGNOSTICS is set: tuning_from_env), read ONCE when a context is created and handed to the
 // launch wrappers through a thread-local pointer for the duration of an API call (contexts are per thread).
 struct Tuning {
     int sim_kernel = 0;        // MSA_SIM_KERNEL=seq: the plain sequential similarity kernel (1) instead of the binade-exact one (tests)
@@ -32,6 +32,7 @@ struct Tuning {
     int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
 };
 Tuning tuning_from_env();
+bool diagnostics_enabled();  // MSA_DIAGNOSTICS is set (and the build has the switches): the other MSA_* variables are read
 void set_tuning(const Tuning *t);  // thread-local; nullptr = defaults
 const Tuning *current_tuning();    // what set_tuning last received on this thread
 const Tuning &tuning();

@@ -570,8 +570,21 @@ LaunchNote &launch_note() {
     static thread_local LaunchNote note;
     return note;
 }
+// MSA_DIAGNOSTICS gates every switch but MSA_TRACE: a process that does not set it gets the default dispatch whatever else its
+// environment holds (the switches exist for the parity suite -- which runs every path of THIS binary, the one that ships -- and for the
+// A/B tools; none is needed in production, and a stray MSA_SIM_KERNEL=seq would cost a factor of ten).  -DMSA_NO_DIAGNOSTICS (make
+// DIAGNOSTICS=0) compiles the reading out altogether.
+bool diagnostics_enabled() {
+#ifdef MSA_NO_DIAGNOSTICS
+    return false;
+#else
+    return getenv("MSA_DIAGNOSTICS") != nullptr;
+#endif
+}
 Tuning tuning_from_env() {
     Tuning t;
+    t.trace = getenv("MSA_TRACE") != nullptr;
+    if (!diagnostics_enabled()) return t;
     auto num = [](const char *name, int dflt) {
         const char *e = getenv(name);
         return e ? atoi(e) : dflt;
@@ -579,7 +592,6 @@ Tuning tuning_from_env() {
     if (const char *k = getenv("MSA_SIM_KERNEL")) t.sim_kernel = k[0] == 's' ? 1 : 0;  // "seq": the plain sequential cross-check kernel
     t.sim_mode = num("MSA_SIM_MODE", 0);
     t.device_clusters = num("MSA_DEVICE_CLUSTERS", -1);
-    t.trace = getenv("MSA_TRACE") != nullptr;
     t.pipeline = num("MSA_PIPELINE", 1);
     t.upload_direct = num("MSA_UPLOAD_DIRECT", 1);
     t.lg_r0 = num("MSA_LG_R0", -1);

@@ -15,6 +15,9 @@ except Exception:  # pragma: no cover
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the library honours its MSA_* diagnostic switches (tests/test_gpu_parity.py KERNELS, the fuzzers) only when this one is set;
+# with none of the others set it changes nothing: the default-dispatch tests still run what ships
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")
 
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

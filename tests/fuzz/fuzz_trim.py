@@ -9,6 +9,7 @@ narrow front kernel, the sixteen-row pair tiles): the paths the BASELINE's C3 an
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 import oracle

@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 
 import torch  # noqa: F401,E402  (first HIP runtime in the process, see pytrimal_amd/_lib.py)
 

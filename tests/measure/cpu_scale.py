@@ -1,6 +1,7 @@
 """The CPU port (the oracle) on 16..128 host threads: columns/s of oracle.trim('automated1') over column slices of C3."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np, oracle
 from multiprocessing.pool import ThreadPool
 from pytrimal_amd.synth import synth_msa

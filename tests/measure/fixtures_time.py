@@ -3,6 +3,7 @@ CPU oracle's time for the same trim (one core), masks compared.   python tests/m
 import json, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch  # noqa: F401

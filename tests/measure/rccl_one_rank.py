@@ -12,6 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -58,7 +59,7 @@ same_objects = all(o.residues_mask == s.residues_mask and o.sequences_mask == s.
 same_again = all(o.residues_mask == s.residues_mask and o.sequences_mask == s.sequences_mask for o, s in zip(again, single))
 oracle_ok = bool(np.array_equal(masks[0][0], res.astype(bool)) and np.array_equal(masks[0][1], seq.astype(bool)))
 print(json.dumps({"backend": dist.get_backend(), "world": world, "all_reduce": float(t[0].item()), "hip_library_loaded_first": bool(loaded_before),
-                  "trimmer_repr": repr(trimmer), "gathered_masks_equal_single": bool(same_masks), "gathered_objects_equal_single": bool(same_objects),
+                  "trimmer_repr": repr(trimmer), "trimmer_platform": trimmer.platform, "gathered_masks_equal_single": bool(same_masks), "gathered_objects_equal_single": bool(same_objects),
                   "trims_after_rccl_equal": bool(same_again), "oracle_equal": oracle_ok,
                   "kept_columns": [int(np.sum(r)) for r, _ in masks]}), flush=True)
 dist.destroy_process_group()

@@ -359,6 +359,19 @@ def _free_port():
         return sock.getsockname()[1]
 
 
+def _run_under_launcher(args, timeout):
+    """`python -m torch.distributed.run --nproc-per-node 1 ... <args>` on a port that was free a moment ago; another process may
+    have taken it since (the socket is closed before the launcher binds it), so a rendezvous that fails to bind is tried again on
+    another port instead of surfacing as a test failure."""
+    out = None
+    for _ in range(3):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port())] + args, capture_output=True, text=True, timeout=timeout, env=_launcher_env())
+        if out.returncode == 0 or not any(w in out.stderr for w in ("Address already in use", "EADDRINUSE", "failed to bind")):
+            break
+    return out
+
+
 def test_rccl_one_rank_collectives():
     """RCCL for real, on this box's one GPU: a one-rank `nccl` process group created in a process where libmsastat_hip.so is
     already loaded and has computed (tests/measure/rccl_one_rank.py, a fresh child: the launcher runs before any GPU call) --
@@ -367,13 +380,13 @@ def test_rccl_one_rank_collectives():
     trims and the oracle, and single trims again with RCCL alive."""
     import json
 
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "measure", "rccl_one_rank.py")],
-                         capture_output=True, text=True, timeout=600, env=_launcher_env())
+    out = _run_under_launcher([os.path.join(ROOT, "tests", "measure", "rccl_one_rank.py")], 600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["all_reduce"] == 1.0 and rec["hip_library_loaded_first"] is True
-    assert rec["trimmer_repr"] == "AutomaticTrimmer('automated1', platform='hip')" or "automated1" in rec["trimmer_repr"]
+    # (the broadcast trimmer: the method, and the platform -- spelled out in the repr only where 'hip' is not what "detect" picks)
+    assert rec["trimmer_repr"] in ("AutomaticTrimmer('automated1', platform='hip')", "AutomaticTrimmer('automated1')"), rec["trimmer_repr"]
+    assert rec["trimmer_platform"] == "hip"
     assert rec["gathered_masks_equal_single"] is True and rec["gathered_objects_equal_single"] is True
     assert rec["trims_after_rccl_equal"] is True and rec["oracle_equal"] is True
 
@@ -384,10 +397,7 @@ def test_bench_one_rank_under_the_launcher_uses_rccl():
     gather of the 64 masks over RCCL, ONE JSON line whose `config.backend` says so."""
     import json
 
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C5", "--steps", "1",
-                          "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, env=_launcher_env())
+    out = _run_under_launcher([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "C5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], 900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -4,6 +4,7 @@ size where the device work is small (500 x 2000), beside the same trims through 
 import cProfile, os, pstats, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, _lib

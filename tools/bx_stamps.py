@@ -5,6 +5,7 @@ unless the variable is set): with a launch every six rounds a "wave" would be a 
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import _lib

@@ -9,6 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch  # noqa: E402,F401
 from pytrimal_amd import Alignment, AutomaticTrimmer  # noqa: E402
 from pytrimal_amd.batch import trim_batch  # noqa: E402

@@ -11,6 +11,7 @@ call), native batch, pack + H2D, gather (RCCL), D2H + unpack; and the two fences
 import json, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -1,5 +1,6 @@
 import json, os, sys, time
 sys.path.insert(0, "/root/repo")
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch
 from pytrimal_amd import Alignment, AutomaticTrimmer
 from pytrimal_amd.batch import trim_batch

@@ -1,5 +1,6 @@
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 os.environ["MSA_SIM_MODE"] = "64"
 import numpy as np, torch
 from pytrimal_amd import _lib

@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, "/root/repo")
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch
 from pytrimal_amd import Alignment, RepresentativeTrimmer
 from pytrimal_amd.synth import synth_msa

@@ -3,6 +3,7 @@ wave ended (stamped instantiation, MSA_SIM_MODE=64: record [5] = {XCC, SE / SH /
     python tools/cu_loads.py m n seed"""
 import ctypes, json, os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np, torch  # noqa: F401
 from pytrimal_amd import _lib
 from pytrimal_amd.synth import synth_msa

@@ -4,6 +4,7 @@ flat kernel (MSA_FLAT_MAX_M=512) and with the wave-per-column kernel (MSA_FLAT_M
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer, _lib
 from pytrimal_amd.synth import synth_msa

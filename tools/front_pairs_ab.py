@@ -7,6 +7,7 @@ MSA_FRONT_CW / MSA_FRONT_NT / MSA_FRONT_XCD / MSA_PAIR_TI / MSA_PAIR_K, alternat
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import _lib

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel timeline of the C5 batch on one GPU through the native batch path (tools/batch_timeline.py reads the csv)
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 W=${1:-4}
 OUT=$ROOT/gpurun_out/c5tl

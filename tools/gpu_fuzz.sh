@@ -1,5 +1,6 @@
 #!/bin/bash
 # the randomised checks of a round, recorded as profiles/<tag>_fuzz.txt
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=gpurun_out/fuzz.txt
 : > $OUT

@@ -1,6 +1,7 @@
 #!/bin/bash
 # profiles of a round: bench lines, rocprofv3 kernel stats and PMC HBM traffic per workload, SQ counters of C3.
 #   bash tools/gpu_profiles.sh r05     -> gpurun_out/r05/; tools/summarise_profiles.py r05 turns it into profiles/r05_*.
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05}
 OUT=$ROOT/gpurun_out/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel + copy timeline of one steady-state step per workload (tools/step_timeline.py reads the csv)
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/tl
 rm -rf $OUT; mkdir -p $OUT

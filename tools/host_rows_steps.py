@@ -3,6 +3,7 @@ slabs against the pair pass:   rocprofv3 --kernel-trace --memory-copy-trace ... 
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import AutomaticTrimmer, RepresentativeTrimmer, Alignment, _lib

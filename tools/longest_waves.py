@@ -1,5 +1,6 @@
 import ctypes, os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np, torch
 from pytrimal_amd import _lib
 from pytrimal_amd.synth import synth_msa

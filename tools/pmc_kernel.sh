@@ -1,9 +1,15 @@
 #!/bin/bash
-# SQ / TA / L2 counters of one kernel family under any command (three rocprofv3 --pmc passes, kernel trace only):
+# SQ / TA / L2 counters of one kernel family under a PROGRAM (three rocprofv3 --pmc passes, kernel trace only).  What follows the
+# kernel name goes straight behind `rocprofv3 ... --`, so its first word must be the interpreter or binary itself (python3, ./ubench):
+# the profiler's preloaded library has initialised the GPU before the program starts, and `env X=1 ...`, `timeout ...`, `bash -c`,
+# `taskset`, `numactl` or a `#!/usr/bin/env` script would be an exec hop behind that (refused on this pool).  Variables go in front
+# of `bash tools/pmc_kernel.sh`.
 #   bash tools/pmc_kernel.sh similarity_lg python3 tools/sim_once.py 1000 4000 2000
 #   bash tools/pmc_kernel.sh similarity_lg python3 tools/c5_batch.py 4
 # Prints per launch averages and the busy fractions of VALU, scalar unit, texture addresser / data, LDS, and the L2 hit rate.
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 K=$1; shift
+case "$(basename "$1")" in env|timeout|bash|sh|taskset|numactl|nice|stdbuf) echo "pmc_kernel.sh: '$1' is a launcher, not the program: put variables in front of this script" >&2; exit 2;; esac
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp

@@ -3,6 +3,7 @@ batch's wall time with the cyclic garbage collector on / off (its passes run und
 container the process holds -- the alignments' thousands of names and sequences included)."""
 import cProfile, gc, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer
 from pytrimal_amd.batch import trim_batch

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, first A/B on the GPU box: the narrow front kernel and the sixteen-row pair tiles against round 5's kernels
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r06_ab1
 mkdir -p $OUT; cd $ROOT

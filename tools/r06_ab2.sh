@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, second A/B: check of every front / pair variant, the narrow front kernel below 513 sequences, sixteen-row pair tiles at C3,
 # the identity statistics with 1024 terms in flight, the collective path
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r06_ab2
 mkdir -p $OUT; cd $ROOT

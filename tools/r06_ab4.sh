@@ -1,4 +1,5 @@
 #!/bin/bash
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r06_ab4
 mkdir -p $OUT; cd $ROOT

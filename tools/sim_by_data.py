@@ -7,6 +7,7 @@ bit with the plain sequential kernel (MSA_SIM_KERNEL=seq).
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch  # noqa: F401

@@ -1,5 +1,6 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np, torch
 from pytrimal_amd import _lib
 from pytrimal_amd.matrix import SimilarityMatrix

@@ -3,6 +3,7 @@ events (all launches of a pass together), Q compared bit for bit with the one-la
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import _lib

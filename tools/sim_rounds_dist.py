@@ -3,6 +3,7 @@ setting), settings alternating: mean / median / min / max of the kernel's time o
 import json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import _lib

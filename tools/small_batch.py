@@ -3,6 +3,7 @@ with the workers alone (MSA_BATCH_ENGINE=0).   python tools/small_batch.py [coun
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer
 from pytrimal_amd.batch import trim_batch

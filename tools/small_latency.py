@@ -3,6 +3,7 @@ and C ABI, by size and method.   python tools/small_latency.py > profiles/rNN_sm
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch  # noqa: F401
 from pytrimal_amd import Alignment, AutomaticTrimmer, ManualTrimmer, _lib

@@ -3,6 +3,7 @@
 without the per-kernel event pairs (msa_prof_enable) -- what the measurement itself costs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np
 import torch
 from pytrimal_amd import _lib

@@ -2,6 +2,7 @@
 the ramp after idle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MSA_DIAGNOSTICS", "1")  # (the library reads its MSA_* diagnostic switches only under this one)
 import numpy as np, torch
 from pytrimal_amd import _lib
 from pytrimal_amd.matrix import SimilarityMatrix

@@ -1,5 +1,6 @@
 #!/bin/bash
 # builds tools/ubench_lstrip (loops generated into /tmp/lstrip_loops.h)
+export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 set -e
 cd "$(dirname "$0")/.."
 : > /tmp/lstrip_loops.h
