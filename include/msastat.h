@@ -295,6 +295,10 @@ enum {
 enum { MSA_PATH_PAIRS_NONE = 0, MSA_PATH_PAIRS_PIPE = 1 /* one row j per lane */, MSA_PATH_PAIRS_TWO_ROWS = 2 /* two rows j per lane */,
        MSA_PATH_PAIRS_PIPE16 = 3 /* one row j per lane, sixteen rows i per tile (up to 1024 sequences) */ };
 int msa_debug_last_paths(msa_ctx *ctx, int32_t out[8]);
+/* 1 when the library honours its MSA_* diagnostic switches in this process: the build has them (not -DMSA_NO_DIAGNOSTICS) and
+ * the environment variable MSA_DIAGNOSTICS is set.  Without it every context and batch object takes the default dispatch
+ * whatever else the environment holds (MSA_TRACE, which only prints, is always read).  Needs no device. */
+int msa_debug_switches_enabled(void);
 
 #ifdef __cplusplus
 }

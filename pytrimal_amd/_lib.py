@@ -45,7 +45,7 @@ EXPORTS = [
     "msa_clean_similarity", "msa_clean_both", "msa_clean_strict", "msa_select_method",
     "msa_representatives", "msa_cutpoint_clusters", "msa_trim", "msa_trim_only_gaps_rows", "msa_batch_create", "msa_batch_destroy", "msa_batch_workers", "msa_trim_batch",
     "msa_batch_only_gaps_rows", "msa_batch_last_hip_error", "msa_prof_get", "msa_prof_reset",
-    "msa_prof_enable", "msa_debug_sim_launches", "msa_debug_last_paths", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
+    "msa_prof_enable", "msa_debug_sim_launches", "msa_debug_last_paths", "msa_debug_switches_enabled", "msa_fasta_scan", "msa_fasta_fill", "msa_clustal_scan", "msa_clustal_fill",
 ]
 
 

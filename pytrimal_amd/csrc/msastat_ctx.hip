@@ -518,6 +518,8 @@ void msa_prof_reset(msa_ctx *c) {
 // kernel launches of the context's last similarity pass (bench.py reports it beside the pass's time: a profiler lists launches)
 int msa_debug_sim_launches(msa_ctx *c) { return c ? c->sim_launches : 0; }
 
+int msa_debug_switches_enabled(void) { return msak::diagnostics_enabled() ? 1 : 0; }
+
 int msa_debug_last_paths(msa_ctx *c, int32_t out[8]) {
     if (!c || !out) return MSA_E_INVALID;
     std::copy_n(c->paths, 8, out);

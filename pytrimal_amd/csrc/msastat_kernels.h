@@ -30,6 +30,7 @@ struct Tuning {
     int front_xcd = 1;         // MSA_FRONT_XCD=0: the narrow column blocks in their own order
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per tile of the pair pass (0: by size; 8, 16)
     int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
+    int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
 };
 Tuning tuning_from_env();
 bool diagnostics_enabled();  // MSA_DIAGNOSTICS is set (and the build has the switches): the other MSA_* variables are read
@@ -67,6 +68,9 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
                           const int32_t *gaps_w, uint8_t *codeT, unsigned long long *err_key);
 void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vtrow,
                        int32_t *nvalid);
+// the two above in one pass (up to ~10 000 rows; false: not applicable, run the two)
+bool launch_sim_lists_fused(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, const int32_t *gaps_w, uint8_t *codeT,
+                            int ldw, int npos, uint32_t *voff, uint16_t *vtrow, int32_t *nvalid, unsigned long long *err_key);
 void launch_identity_stats(hipStream_t s, const float *ident, int m, int ldw, float *row_avg, float *row_max,
                            float *out2, float *row_min = nullptr, int *gate = nullptr);
 // One alignment as the similarity kernel sees it (device pointers).  By value for a single alignment, as a table in

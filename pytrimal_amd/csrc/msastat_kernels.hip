@@ -609,6 +609,7 @@ Tuning tuning_from_env() {
     t.front_xcd = num("MSA_FRONT_XCD", 1);
     t.pair_ti = num("MSA_PAIR_TI", 0);
     t.pair_k = num("MSA_PAIR_K", 0);
+    t.lists_fused = num("MSA_LISTS_FUSED", 1);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

@@ -857,6 +857,118 @@ __global__ __launch_bounds__(NT) void compact_front2_kernel(CompactArgs a) {
     }
 }
 
+// ---- codes + lists in ONE pass, any alignment whose sixteen-column block fits the LDS (round 6) -------------------------------
+// sim_encode_cm + bx_compact are two passes with the column-major codes written to memory and read back in between (and byte loads
+// behind a 64 x 64 transposition): 0.28 ms at 2000 x 10000 on the side stream, 0.60 at 3583 x 7287 -- beside a pair pass of 0.63,
+// one step from the critical path.  The narrow column block of compact_front2_kernel does the same work in one pass: sixteen
+// columns over ALL rows, dword loads of four consecutive rows per thread and sweep (the next sweep's requested before this one's
+// are looked at), the codes in an LDS array [column][row], then a wave per column writes codes and lists out, coalesced.  The
+// ">= 80 % gaps" cut comes from the gap counts of the kernel in front (windowed or not), the first bad residue goes to the
+// context's key by atomicMax as the other encode kernels report it.  Dynamic LDS: 16 x (round_up(ceil(m / 4), 64) + 4) dwords
+// (m = 2000: 33 KB, 3583: 58 KB, 8000: 131 KB): up to ~10 000 rows, beyond which the two-pass kernels stay.
+__global__ __launch_bounds__(1024) void sim_lists_fused_kernel(const uint8_t *__restrict__ raw, int m, int n, int64_t ld,
+                                                               const uint8_t *__restrict__ lut_g, const int32_t *__restrict__ gaps_w,
+                                                               uint8_t *__restrict__ codeT, int64_t ldk, int ncols_pad, uint32_t ldw4,
+                                                               uint32_t *__restrict__ voff, uint16_t *__restrict__ vtrow, int skiprow,
+                                                               int32_t *__restrict__ nvalid, int big, unsigned long long *__restrict__ err_key,
+                                                               int ldc4) {
+    constexpr int CW = 16, WPR = 4, NT = 1024, RG = NT / WPR, NW = NT / 64;
+    extern __shared__ uint32_t fused_codes[];  // [CW][ldc4]
+    __shared__ uint8_t lut[256];
+    __shared__ uint8_t skipc[CW];
+    const int ncb = ncols_pad / CW;
+    // (the blocks that share the 128-byte lines of a row dealt to one XCD: compact_front2_kernel)
+    const int bx = (int)blockIdx.x, xq = bx >> 3, xx = bx & 7, full = ncb >> 3, rem = ncb & 7;
+    const int b = xx * full + (xx < rem ? xx : rem) + xq;
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int word = t % WPR, rg = t / WPR;
+    const int c0 = b * CW + 4 * word;
+    if (t < 256) lut[t] = lut_g[t];
+    if (t < CW) {
+        const int c = b * CW + t;
+        skipc[t] = (c >= n || (((float)gaps_w[c] / (float)m) >= 0.8f)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool live = c0 < n && !(skipc[4 * word] & skipc[4 * word + 1] & skipc[4 * word + 2] & skipc[4 * word + 3]);
+    const uint32_t km = c0 >= n ? 0u : (n - c0 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * (n - c0))) - 1u));
+    uint32_t keep = 0;  // bytes of the dword whose column is evaluated
+#pragma unroll
+    for (int k = 0; k < 4; ++k) keep |= skipc[4 * word + k] ? 0u : (0xFFu << (8 * k));
+    keep &= km;
+    const uint8_t *p = raw + (c0 < n ? c0 : 0);
+    const int nsweeps = (m + 4 * RG - 1) / (4 * RG);
+    uint32_t nx[4];
+    auto request = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (s * RG + rg) + i;
+            nx[i] = (live && row < m) ? *reinterpret_cast<const uint32_t *>(p + (size_t)row * ld) : 0u;
+        }
+    };
+    request(0);
+    for (int s = 0; s < nsweeps; ++s) {
+        uint32_t x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = nx[i];
+        if (s + 1 < nsweeps) request(s + 1);
+        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (s * RG + rg) + i;
+            const uint32_t k4 = row < m ? keep : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t code = BX_SKIP;
+                if ((k4 >> (8 * k)) & 1u) {
+                    const uint32_t byte = (x[i] >> (8 * k)) & 0xFFu;
+                    code = lut[byte];  // 8 x table row, 224 = skipped, 0xFE / 0xFF = bad symbol
+                    if (code >= 0xFEu) {
+                        const unsigned long long key = ((unsigned long long)(c0 + k) << 40) | ((unsigned long long)row << 16) |
+                                                       ((unsigned long long)(code & 1u) << 8) | byte;
+                        atomicMax(err_key, ~key);  // (kept complemented: 0 = none, the largest complement = the first residue)
+                        code = BX_SKIP;
+                    }
+                }
+                pk[k] |= code << (8 * i);
+            }
+        }
+        const int rgi = s * RG + rg;
+        if (4 * rgi < m) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fused_codes[(4 * word + k) * ldc4 + rgi] = pk[k];
+        }
+    }
+    __syncthreads();
+    const int mtiles = (m + 63) / 64;
+    const uint8_t *cbytes = reinterpret_cast<const uint8_t *>(fused_codes);
+    for (int q = wave; q < CW; q += NW) {
+        const size_t col = (size_t)b * CW + q;
+        const bool skip = skipc[q] != 0;
+        uint8_t *ct = codeT + col * ldk;
+        uint32_t *po = voff + col * ldk;
+        uint16_t *pt = vtrow + col * ldk;
+        int count = 0;
+        for (int kb = 0; kb < mtiles * 64; kb += 64) {
+            const int k = kb + lane;
+            const uint32_t code = (k < m && !skip) ? (uint32_t)cbytes[(size_t)q * ldc4 * 4 + k] : BX_SKIP;
+            ct[k] = (uint8_t)code;
+            const unsigned long long mask = __ballot(code != BX_SKIP);
+            if (code != BX_SKIP) {
+                const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                po[pos] = big ? (uint32_t)k : (uint32_t)k * ldw4;
+                pt[pos] = (uint16_t)((code >> 3) * 256u);
+            }
+            count += __builtin_popcountll(mask);
+        }
+        for (int64_t k = (int64_t)mtiles * 64 + lane; k < ldk; k += 64) ct[k] = (uint8_t)BX_SKIP;
+        for (int64_t e = count + lane; e < ldk; e += 64) {
+            po[e] = big ? (uint32_t)m : (uint32_t)m * ldw4;  // row m of W: zeros
+            pt[e] = (uint16_t)(skiprow * 256);               // the table's zero row
+        }
+        if (lane == 0) nvalid[col] = count;
+    }
+}
+
 // automated1: the identity statistics -- a wave per sequence (identity_rows_body), and in the workgroup that finishes last (a
 // ticket) the two means and Cleaner::selectMethod's decision (identity_final_body): one launch for the ordinary path's two.
 __global__ __launch_bounds__(256) void compact_identity_kernel(CompactArgs a) {
@@ -1020,6 +1132,20 @@ void launch_sim_encode_cm(hipStream_t s, const uint8_t *raw, int m, int n, int64
     const int ncp = bx_cols_pad(n);
     dim3 grid((unsigned)(ncp / 64), (unsigned)(ldk / 64));
     sim_encode_cm_kernel<<<grid, 256, 0, s>>>(raw, m, n, ld, lut, gaps_w, codeT, ldk, ncp, err_key);
+}
+
+// codes + lists of every column in one pass (sim_lists_fused_kernel), where a sixteen-column block's codes fit the LDS; false: the
+// caller runs launch_sim_encode_cm + launch_bx_compact (more than ~10 000 rows, or MSA_LISTS_FUSED=0)
+bool launch_sim_lists_fused(hipStream_t s, const uint8_t *raw, int m, int n, int64_t ld, const uint8_t *lut, const int32_t *gaps_w, uint8_t *codeT,
+                            int ldw, int npos, uint32_t *voff, uint16_t *vtrow, int32_t *nvalid, unsigned long long *err_key) {
+    const int ldc4 = ((m + 3) / 4 + 63) / 64 * 64 + 4;
+    const size_t dyn = (size_t)16 * ldc4 * 4;
+    if (!gaps_w || tuning().lists_fused == 0 || dyn > (size_t)150 * 1024) return false;
+    if (set_max_lds_once((const void *)sim_lists_fused_kernel, (int)dyn)) return false;
+    const int ncp = bx_cols_pad(n);
+    sim_lists_fused_kernel<<<(unsigned)(ncp / 16), 1024, dyn, s>>>(raw, m, n, ld, lut, gaps_w, codeT, bx_ldk(m), ncp, (uint32_t)ldw * 4u, voff, vtrow,
+                                                                  npos, nvalid, lg_big(m, ldw) ? 1 : 0, err_key, ldc4);
+    return true;
 }
 
 void launch_bx_compact(hipStream_t s, const uint8_t *codeT, int m, int n, int ldw, int npos, uint32_t *voff, uint16_t *vtrow,

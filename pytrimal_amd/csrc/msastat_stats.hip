@@ -280,8 +280,11 @@ int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t s
     HIPCHK(c, c->bx_nvalid.reserve((size_t)msak::bx_cols_pad(n) + 64));
     {
         ProfScope pe(c, "encode", st);
-        msak::launch_sim_encode_cm(st, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
-        msak::launch_bx_compact(st, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_trow.p, c->bx_nvalid.p);
+        if (!msak::launch_sim_lists_fused(st, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->ldw, npos, c->bx_off.p, c->bx_trow.p,
+                                          c->bx_nvalid.p, c->errkey.p)) {
+            msak::launch_sim_encode_cm(st, c->raw, m, n, c->ld, c->lut.p, gw_dev, c->codeT.p, c->errkey.p);
+            msak::launch_bx_compact(st, c->codeT.p, m, n, c->ldw, npos, c->bx_off.p, c->bx_trow.p, c->bx_nvalid.p);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return MSA_OK;

@@ -259,3 +259,23 @@ int main(void) {
     want = oracle.gaps_window(np.array([0, 3, 6, 3, 0, 0, 9, 0], dtype=np.int32), 1)
     assert [int(x) for x in windowed.split()] == want.tolist()
     assert mask == "".join("1" if x <= 3 else "0" for x in [0, 3, 6, 3, 0, 0, 9, 0])
+
+
+def test_diagnostic_switches_need_the_master_variable():
+    """The MSA_* diagnostic switches are honoured only in a process that sets MSA_DIAGNOSTICS (a stray MSA_SIM_KERNEL=seq in a
+    production environment must not cost a factor of ten): `msa_debug_switches_enabled` reads the variable at call time, in a
+    fresh process with and without it (this suite sets it in conftest.py)."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.msa_debug_switches_enabled.restype = ctypes.c_int; "
+            "print(L.msa_debug_switches_enabled())")
+    from pytrimal_amd import _lib
+
+    for env_extra, want in ((dict(MSA_DIAGNOSTICS="1"), "1"), (dict(), "0")):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MSA_")}
+        env.update(env_extra)
+        env["MSA_SIM_KERNEL"] = "seq"  # (never enough by itself)
+        out = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip() == want
