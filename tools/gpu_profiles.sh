@@ -3,7 +3,7 @@
 #   bash tools/gpu_profiles.sh r05     -> gpurun_out/r05/; tools/summarise_profiles.py r05 turns it into profiles/r05_*.
 export MSA_DIAGNOSTICS=1  # (the library reads its MSA_* diagnostic switches only under this one)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
@@ -43,7 +43,7 @@ MSA_COMPACT=0 MSA_ZEROCOPY_KB=0 timeout 300 python tools/small_latency.py > $OUT
 timeout 300 python tools/flat_sweep.py > $OUT/flat_sweep.jsonl 2>/dev/null
 timeout 300 python tests/measure/fixtures_time.py > $OUT/fixtures_time.jsonl 2>/dev/null
 ( cd /tmp; : > $OUT/small_kernel_stats.txt
-  for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict" "209 1227 overlap" "209 1227 representative" "1000 4000 automated1"; do
+  for a in "46 1181 strict" "100 1000 automated1" "209 1227 strictplus" "500 2000 strict" "209 1227 overlap" "209 1227 representative" "1000 4000 automated1" "600 2500 automated1"; do
     rm -rf /tmp/small_prof
     timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/small_prof -- python3 $ROOT/tools/small_one.py $a 200 > /tmp/small_prof.log 2>&1
     grep "per upload" /tmp/small_prof.log >> $OUT/small_kernel_stats.txt
@@ -66,6 +66,13 @@ for w in C3 C2 C4; do cp $ROOT/gpurun_out/tl/timeline_$w.txt $OUT/ 2>/dev/null; 
 timeout 120 python tools/sim_fixture_stamps.py > $OUT/sim_fixture_stamps.txt 2>/dev/null
 timeout 300 python tools/sim_overlap.py > $OUT/sim_overlap.jsonl 2>/dev/null
 RESIDENT=1 timeout 300 python tools/sim_overlap.py >> $OUT/sim_overlap.jsonl 2>/dev/null   # (W stays: a pass is the layout kernels + the similarity kernel)
+# round 6: the collective path at one rank (RCCL), the front kernel / pair tiles by variant, the engine by trimmer kind, the strip loop
+timeout 600 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 tools/c5_collective.py 15 > $OUT/c5_collective.jsonl 2> $OUT/c5_collective.err
+SHAPES=1000x4000,600x2500 timeout 600 python tools/front_pairs_ab.py time > $OUT/front_pairs_ab.jsonl 2>/dev/null
+for meth in gappyout overlap representative noduplicateseqs strict; do
+  timeout 300 python tools/small_batch.py 1024 100 1000 $meth 2>/dev/null; MSA_BATCH_ENGINE=0 timeout 300 python tools/small_batch.py 1024 100 1000 $meth 2>/dev/null
+done > $OUT/small_batch_engine_kinds.jsonl
+( bash tools/ubench_lstrip.sh > /dev/null 2>&1 && timeout 300 tools/ubench_lstrip > $OUT/ubench_lstrip.txt 2>&1 )
 ls $OUT | head -60
 # keep only the small csv files (the merge back is limited to 64 MiB)
 find $OUT -name "*kernel_trace.csv" -size +4M -delete

@@ -4,7 +4,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
@@ -26,7 +26,7 @@ def counters(d):
 
 
 family = {  # kernel -> the name bench.py's roofline uses
-    "msak::similarity_lg_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::pair_counts_pipe_kernel": "pairs",
+    "msak::similarity_lg_kernel": "sim", "msak::pair_counts_kernel": "pairs", "msak::pair_counts_pipe_kernel": "pairs", "msak::pair_counts_pipe16_kernel": "pairs", "msak::sim_lists_fused_kernel": "encode",
     "msak::gap_counts_kernel": "gaps",
     "msak::prep_planes_kernel": "prep", "msak::identity_rows_kernel": "idstats", "msak::sim_encode_cm_kernel": "encode",
     "msak::bx_compact_kernel": "encode", "msak::cluster_mis_kernel": "cluster", "msak::cluster_adjacency_kernel": "cluster",
@@ -106,12 +106,15 @@ ub = os.path.join(SRC, "ubench_wstream.txt")
 if os.path.exists(ub):
     shutil.copy(ub, os.path.join(DST, TAG + "_ubench_wstream.txt"))
 for name in ("ubench_wform.txt", "sim_shapes.jsonl", "sim_shapes_one_wave_per_column.jsonl", "small_batch.jsonl", "c5_engine.jsonl", "c5_counts.jsonl",
-             "small_latency.jsonl", "small_latency_ordinary_launch_sequence.jsonl", "flat_sweep.jsonl", "fixtures_time.jsonl", "small_kernel_stats.txt", "cold_upload.jsonl"):
+             "small_latency.jsonl", "small_latency_ordinary_launch_sequence.jsonl", "flat_sweep.jsonl", "fixtures_time.jsonl", "small_kernel_stats.txt", "cold_upload.jsonl",
+             "front_pairs_ab.jsonl", "small_batch_engine_kinds.jsonl", "ubench_lstrip.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 for name in ("bx_stamps.jsonl", "ab_switches.txt", "timeline_C3.txt", "timeline_C2.txt", "timeline_C4.txt", "reference_shape.jsonl",
              "c5_batch.jsonl", "upload.txt", "sim_by_data.jsonl", "c5_timeline.txt", "bench_REF.json", "pmc_sim.txt", "sim_fixture_stamps.txt", "sim_overlap.jsonl"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
+if os.path.exists(os.path.join(SRC, "c5_collective.jsonl")):  # (profiles/<tag>_c5_collective.jsonl is the hand-assembled A/B with round 5's path)
+    shutil.copy(os.path.join(SRC, "c5_collective.jsonl"), os.path.join(DST, TAG + "_c5_collective_at_profile_run.jsonl"))
 print("\n".join(lines[-40:]))
 print("\n".join(out))
