@@ -647,7 +647,7 @@ def main():
                 rate = wbytes / (kernels[dom]["ms_avg"] * 1e-3) / 1e9
                 roofline["w_stream"] = {
                     "bound": "vector-memory pipeline (L1/TA), 256-byte global_load_dword wave-loads of L2-resident W rows "
-                             "(texture addresser 0.77 - 0.86 busy, VALU 0.63 - 0.72 at 2000 x 10000 by run and clock: profiles/r05_pmc_sim.txt)",
+                             "(texture addresser 0.86 busy, texture data 0.88, VALU 0.71, L2 hit rate 0.967 at 2000 x 10000: profiles/r06_pmc_sim.txt)",
                     "partner_steps": wsteps, "bytes": wbytes, "achieved": round(rate, 1), "peak": W_STREAM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(rate / W_STREAM_PEAK_GBS, 4),
                     "frac_of_peak_with_the_loop_valu_work": round(rate / W_STREAM_PEAK_WITH_VALU_GBS, 4),

@@ -1196,11 +1196,15 @@ int compact_front_cw(int m, int n, bool sim, bool rows_in_host_memory) {
     if (t.front_cw == 64 || m < from || m > 1024 || (rows_in_host_memory && t.front_from_m <= 0)) return 64;
     return t.front_cw == 32 ? 32 : 16;
 }
-// threads per block of the narrow kernel: up to 512 sequences 512 (a sweep covers all rows); beyond, 1024 while every column block
-// has a compute unit of its own, else 512 (two blocks per unit at a time: 1024 x 8000, 501 blocks: 30.0 -> 26.9 us)
+// threads per block of the narrow kernel: 512.  Alone, a block of 1024 threads (one sweep over 1024 rows) is 2 us faster at
+// 1000 x 4000 (17.3 against 19.3 us); beside other contexts' similarity kernels -- five waves per SIMD that leave the register file
+// no room for a sixth -- a block must find all of its waves' slots on ONE compute unit, and eight waves find them sooner than
+// sixteen: the C5 batch 22.1 - 22.3 -> 21.75 ms (profiles/r06_c5_front_threads_ab.txt; 256 threads: 21.9), and at 1024 x 8000
+// (501 column blocks) 512 is the faster alone as well (26.9 against 30.0 us).
 int compact_front_nt(int m, int n, int cus) {
+    (void)m, (void)n, (void)cus;
     if (tuning().front_nt > 0) return tuning().front_nt;
-    return (m > 512 && bx_cols_pad(n) / 16 <= cus) ? 1024 : 512;
+    return 512;
 }
 template <int ROWS>
 static void launch_compact_front2(hipStream_t s, const CompactArgs &a, unsigned blocks, int nt) {

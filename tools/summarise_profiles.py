@@ -115,6 +115,6 @@ for name in ("bx_stamps.jsonl", "ab_switches.txt", "timeline_C3.txt", "timeline_
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, TAG + "_" + name))
 if os.path.exists(os.path.join(SRC, "c5_collective.jsonl")):  # (profiles/<tag>_c5_collective.jsonl is the hand-assembled A/B with round 5's path)
-    shutil.copy(os.path.join(SRC, "c5_collective.jsonl"), os.path.join(DST, TAG + "_c5_collective_at_profile_run.jsonl"))
+    shutil.copy(os.path.join(SRC, "c5_collective.jsonl"), os.path.join(DST, TAG + "_c5_collective_final_build.jsonl"))
 print("\n".join(lines[-40:]))
 print("\n".join(out))
