@@ -17,8 +17,8 @@ import torch
 import torch.distributed as dist
 from pytrimal_amd import Alignment, AutomaticTrimmer
 from pytrimal_amd import batch as B
-if os.environ.get("BATCH_R05"):  # round 5's collective path (a copy of its batch.py beside the package: A/B only)
-    from pytrimal_amd import _batch_r05 as B
+# (profiles/r06_c5_collective.jsonl also holds this tool's legs on round 5's collective path: `git show e3198f1:pytrimal_amd/batch.py`
+# loaded as `B` in place of the module above, same box)
 from pytrimal_amd.synth import synth_msa
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 15
