@@ -31,6 +31,7 @@ struct Tuning {
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per tile of the pair pass (0: by size; 8, 16)
     int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
     int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
+    int lg_halves = 1;         // MSA_LG_HALVES: 1 the columns of a multi-launch similarity pass as two staggered halves where it pays (lg_halves), 0 never, 2 always (tests)
 };
 Tuning tuning_from_env();
 bool diagnostics_enabled();  // MSA_DIAGNOSTICS is set (and the build has the switches): the other MSA_* variables are read
@@ -91,7 +92,13 @@ struct LgAlign {
     int32_t m, n, ldw, ncols;
     int32_t mdk_host;        // (with mdk_out) MSA_MDK_HOST: every exponential goes to the host as a NaN
 };
-int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out);
+struct LgSide {  // a second stream and two events of the caller's: tall alignments run their columns as two staggered halves
+    hipStream_t s2;
+    hipEvent_t fork, join;
+};
+int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out, const LgSide *side = nullptr);
+bool lg_halves(int m, int ncols, int cus, bool with_state);
+int lg_halves_rounds(int m);  // rounds per launch of the two halves
 bool lg_finishes(const LgAlign &one, int cus);  // launch_similarity_lg will honour one.mdk_out (else the caller runs sim_finish)
 int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int32_t *colprefix, int K, int ncols_total, int max_m, int npos,
                                const void *tab, bool with_state, int *launches_out);

@@ -610,6 +610,7 @@ Tuning tuning_from_env() {
     t.pair_ti = num("MSA_PAIR_TI", 0);
     t.pair_k = num("MSA_PAIR_K", 0);
     t.lists_fused = num("MSA_LISTS_FUSED", 1);
+    t.lg_halves = num("MSA_LG_HALVES", 1);
     return t;
 }
 int set_max_lds_once(const void *kernel, int bytes) {

@@ -292,6 +292,20 @@ int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t s
 // 2. the column list (built on the host into h_simcols)
 int sim_order_enqueue(msa_ctx *c, const SimOrder &ord, hipStream_t st) {
     HIPCHK(c, c->simcols.reserve((size_t)ord.npad + 8));
+    // a tall alignment whose columns run as two staggered halves (msak::lg_halves): the list's even entries, then its odd ones --
+    // each half by weight, the two of the same weight
+    c->sim_halves = msak::lg_halves(c->m, ord.npad, c->cus, true);
+    if (c->sim_halves) {
+        if (!c->stream2) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        std::vector<int32_t> tmp(c->h_simcols.p, c->h_simcols.p + ord.npad);
+        int k = 0;
+        for (int i = 0; i < ord.npad; i += 2) c->h_simcols.p[k++] = tmp[i];
+        for (int i = 1; i < ord.npad; i += 2) c->h_simcols.p[k++] = tmp[i];
+    }
     if (ord.npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * ord.npad, hipMemcpyHostToDevice, st));
     return MSA_OK;
 }
@@ -323,7 +337,9 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
                                 a.num_out = c->simnum.p, a.den_out = c->simden.p, a.state = c->simstate.p;
                                 a.gate = gate, a.cols = c->simcols.p;
                                 a.ldk = msak::bx_ldk(m), a.m = m, a.n = n, a.ldw = c->ldw, a.ncols = ord.npad;
-                                return msak::launch_similarity_lg(c->stream, a, npos, c->tab.p, c->cus, &c->sim_launches);
+                                msak::LgSide side = {c->stream2, c->ev_fork, c->ev_join};
+                                return msak::launch_similarity_lg(c->stream, a, npos, c->tab.p, c->cus, &c->sim_launches,
+                                                                  c->sim_halves && c->stream2 ? &side : nullptr);
                             }();
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }

@@ -1,5 +1,6 @@
-"""DESIGN.md's headline figures against the committed profiles they cite (tools/check_design_numbers.py: the table at the end of
-DESIGN section 8): a figure edited in the text without its file, or a refreshed file without the text, fails here."""
+"""DESIGN.md's headline figures against the committed profiles they cite (tools/check_design_numbers.py: the table of
+profiles/FIGURES.md, every quoted value of which must occur in DESIGN.md's text): a figure edited in the text without its file, or a
+refreshed file without the text, fails here."""
 import os
 import subprocess
 import sys

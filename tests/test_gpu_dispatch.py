@@ -7,7 +7,7 @@ threshold in pytrimal_amd/csrc fails this file until the table is updated with i
 Thresholds covered (DESIGN.md section 11 lists them): rows read in place up to 96 KB; flat similarity kernel up to 128 rows
 (96 beyond 2560 columns: both waves of every column resident); compact pipeline up to 1024 rows, from 513 rows or 5121 columns on
 with the columns dealt by weight; side stream from m^2 n = 2 * 10^9; a launch every six rounds from 1800 rows; a workgroup per column from 2048 rows when the columns leave
-wave slots free; front kernel alone for gap-only trims up to 1024 rows and 4 MB; sixteen rows i per tile of the pair pass from 513 rows,
+wave slots free; the columns of a multi-launch similarity pass as two staggered halves where that pays; front kernel alone for gap-only trims up to 1024 rows and 4 MB; sixteen rows i per tile of the pair pass from 513 rows,
 two rows j per lane from 4096 rows.
 
 The boundaries in columns are multiples of the device's compute units (10 and 20 per unit): the table is written for the MI355X's
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
                 "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
-                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED")
+                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES")
 
 
 def _compute_units():
@@ -95,8 +95,13 @@ STRICT = [
     (1800, 700, dict(pipeline="two_streams", sim_launches=5, **LG1)),
     # --- a workgroup per column: min(8, wave slots / columns, rows / 1024) waves
     (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
-    (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=6)),
+    (2048, 500, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=6)),
+    # --- the columns as two staggered halves on two streams (2 x 6 + 1 launches): a workgroup per column from two columns per
+    #     compute unit on (up to 14 336 rows), a wave per column when the columns outnumber the wave slots (2560 ... 4608 rows)
+    (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=13)),
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
+    (2600, 5400, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=7)),
+    (2600, 5700, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=15)),
     # --- pair pass: eight rows i per tile up to 512 rows, sixteen from 513 on (K waves per tile while tiles x K <= 10240); one row j
     #     per lane below 4096 rows (m_pad / 128 * ceil(m / 8) / 2 < 8192), two from there on
     (2000, 2100, dict(pair_kernel="pipe16", pair_waves_per_tile=4, sim_kernel="lg")),

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""DESIGN.md section 8 ends with a table `figure | quoted | file | key`: every quoted headline figure with the committed profile it
-comes from.  This script reads that table and compares: a quoted value passes when it equals the file's value rounded to the
+"""profiles/FIGURES.md holds the table `figure | quoted | file | key` of DESIGN.md section 8: every quoted headline figure with the
+committed profile it comes from (inside DESIGN.md itself through round 5).  This script reads that table and compares: a quoted value passes when it equals the file's value rounded to the
 quoted number of significant digits (or lies within 1.5 % of it).  Keys: `a.b.c` walks a JSON object; for .jsonl files
 `k1=v1,k2=v2:field` picks the record whose fields print as given.     python tools/check_design_numbers.py   (exit code 1 on a mismatch)"""
 import json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-text = open(os.path.join(ROOT, "DESIGN.md")).read()
+text = open(os.path.join(ROOT, "profiles", "FIGURES.md")).read()
 start = text.index("**Figures checked by `tools/check_design_numbers.py`**")
 rows = re.findall(r"^\| ([^|]+) \| ([^|]+) \| `([^`]+)` \| `([^`]+)` \|$", text[start:], flags=re.M)
 
@@ -30,8 +30,15 @@ def lookup(path, key):
     return obj
 
 
+design = open(os.path.join(ROOT, "DESIGN.md")).read()
 bad = 0
 for figure, quoted, path, key in rows:
+    # (the figure must be what DESIGN.md's text says: the quoted string -- or, for a time kept in seconds, its milliseconds -- occurs there)
+    qs = quoted.strip()
+    alt = f"{float(qs) * 1e3:g}" if key.endswith(":median") else qs
+    if qs not in design and alt not in design:
+        print(f"NOT IN DESIGN.md  {figure.strip()}: {qs}")
+        bad += 1
     q = float(quoted.replace("·10", "e").strip())
     try:
         v = float(lookup(path, key))
