@@ -640,9 +640,10 @@ def main():
                 lib.msa_debug_sim_launches.argtypes = [ctypes.c_void_p]
                 roofline["kernel_launches_per_pass"] = max(1, int(lib.msa_debug_sim_launches(ctx.h)))
                 # (what `rocprofv3 --stats` lists as the kernel's average duration -- while the launches of a pass run one after the
-                # other.  Round 6: from 5120 evaluated columns on the columns of a pass run as TWO staggered halves on two streams,
-                # 2 x 6 + 1 launches at 2000 rows, whose durations overlap: their sum exceeds the pass, and `ms_avg` -- HIP events
-                # around the whole sequence on the context's stream, the join included -- is the pass)
+                # other, as they do at C2 / C3 / C5.  Round 6: at 2560 - 4608 rows with more columns than wave slots, and for tall
+                # alignments with 512 columns or more, the columns of a pass run as TWO staggered halves on two streams -- an odd
+                # number of launches whose durations overlap: their sum exceeds the pass, and `ms_avg` -- HIP events around the
+                # whole sequence on the context's stream, the join included -- is the pass)
                 roofline["kernel_launches_overlap"] = bool(roofline["kernel_launches_per_pass"] > 1 and roofline["kernel_launches_per_pass"] % 2 == 1)
                 roofline["ms_avg_per_kernel_launch"] = round(kernels[dom]["ms_avg"] / roofline["kernel_launches_per_pass"], 4)
             if dom == "sim" and args.workload != "C5":
