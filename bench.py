@@ -644,7 +644,8 @@ def main():
                 # alignments with 512 columns or more, the columns of a pass run as TWO staggered halves on two streams -- an odd
                 # number of launches whose durations overlap: their sum exceeds the pass, and `ms_avg` -- HIP events around the
                 # whole sequence on the context's stream, the join included -- is the pass)
-                roofline["kernel_launches_overlap"] = bool(roofline["kernel_launches_per_pass"] > 1 and roofline["kernel_launches_per_pass"] % 2 == 1)
+                one_sequence = max(1, -(-((m - 1 + 63) // 64) // 6)) if m >= 1800 else 1  # (a launch per six rounds from 1800 rows on)
+                roofline["kernel_launches_overlap"] = bool(roofline["kernel_launches_per_pass"] > one_sequence)
                 roofline["ms_avg_per_kernel_launch"] = round(kernels[dom]["ms_avg"] / roofline["kernel_launches_per_pass"], 4)
             if dom == "sim" and args.workload != "C5":
                 # what bounds it: the stream of W rows through the L1 / texture-addresser pipeline (all L2 hits), not HBM

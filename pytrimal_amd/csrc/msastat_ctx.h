@@ -134,7 +134,9 @@ struct msa_ctx {
                                  // layout, then the residues per sequence (state_rpad words), MDK and Q (state_npad floats each) and
                                  // the verdict slots of the front kernel's blocks
     int compact_cw = 64;         // columns per column block of the front kernel last launched (the slots are per block)
-    bool sim_halves = false;     // the column list of the similarity kernel is laid out as evens, odds (two staggered halves: msak::lg_halves)
+    bool sim_halves = false;     // the column list of the similarity kernel is laid out part by part (staggered parts: msak::lg_halves)
+    hipStream_t part_stream[2] = {nullptr, nullptr};  // streams of a third and fourth part (MSA_LG_PARTS; the second part runs on stream2)
+    hipEvent_t part_join[2] = {nullptr, nullptr};
     bool state_zeroed = false;   // for the current alignment
     bool errkey_dirty = false;   // an encode kernel may have written the first-bad-residue key since the state was zeroed
     bool flags_dirty = false;    // a kernel that may raise a flag was enqueued since the flags were last fetched

@@ -178,6 +178,12 @@ void msa_ctx_destroy(msa_ctx *c) {
         (void)hipEventDestroy(c->ev_join);
         (void)hipStreamDestroy(c->stream2);
     }
+    for (int p = 0; p < 2; ++p)
+        if (c->part_stream[p]) {
+            (void)hipStreamSynchronize(c->part_stream[p]);
+            (void)hipEventDestroy(c->part_join[p]);
+            (void)hipStreamDestroy(c->part_stream[p]);
+        }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -31,6 +31,7 @@ struct Tuning {
     int pair_ti = 0;           // MSA_PAIR_TI: rows i per tile of the pair pass (0: by size; 8, 16)
     int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
     int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
+    int lg_parts = 2;          // MSA_LG_PARTS: staggered parts of such a pass (2, 3, 4)
     int lg_halves = 1;         // MSA_LG_HALVES: 1 the columns of a multi-launch similarity pass as two staggered halves where it pays (lg_halves), 0 never, 2 always (tests)
 };
 Tuning tuning_from_env();
@@ -92,10 +93,12 @@ struct LgAlign {
     int32_t m, n, ldw, ncols;
     int32_t mdk_host;        // (with mdk_out) MSA_MDK_HOST: every exponential goes to the host as a NaN
 };
-struct LgSide {  // a second stream and two events of the caller's: tall alignments run their columns as two staggered halves
-    hipStream_t s2;
-    hipEvent_t fork, join;
+struct LgSide {  // further streams and events of the caller's: the columns of a multi-launch pass as `parts` staggered parts (lg_halves)
+    int parts;           // 2 (3, 4: MSA_LG_PARTS); part 0 runs on the launcher's own stream
+    hipStream_t s[3];    // the streams of the parts 1 ..
+    hipEvent_t fork, join[3];
 };
+int lg_parts();  // parts of a pass that lg_halves says is to be staggered (2; MSA_LG_PARTS: 3, 4)
 int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out, const LgSide *side = nullptr);
 bool lg_halves(int m, int ncols, int cus, bool with_state);
 int lg_halves_rounds(int m);  // rounds per launch of the two halves

@@ -292,19 +292,25 @@ int sim_lists_enqueue(msa_ctx *c, int npos, const int32_t *gw_dev, hipStream_t s
 // 2. the column list (built on the host into h_simcols)
 int sim_order_enqueue(msa_ctx *c, const SimOrder &ord, hipStream_t st) {
     HIPCHK(c, c->simcols.reserve((size_t)ord.npad + 8));
-    // a tall alignment whose columns run as two staggered halves (msak::lg_halves): the list's even entries, then its odd ones --
-    // each half by weight, the two of the same weight
+    // a pass whose columns run as staggered parts on as many streams (msak::lg_halves; two parts, MSA_LG_PARTS: up to four): the list
+    // part by part -- part p = its entries p, p + P, ...: every part by weight, all of the same weight
     c->sim_halves = msak::lg_halves(c->m, ord.npad, c->cus, true);
     if (c->sim_halves) {
+        const int P = msak::lg_parts();
         if (!c->stream2) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
+        for (int p = 0; p < P - 2; ++p)
+            if (!c->part_stream[p]) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->part_stream[p], hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->part_join[p], hipEventDisableTiming));
+            }
         std::vector<int32_t> tmp(c->h_simcols.p, c->h_simcols.p + ord.npad);
         int k = 0;
-        for (int i = 0; i < ord.npad; i += 2) c->h_simcols.p[k++] = tmp[i];
-        for (int i = 1; i < ord.npad; i += 2) c->h_simcols.p[k++] = tmp[i];
+        for (int p = 0; p < P; ++p)
+            for (int i = p; i < ord.npad; i += P) c->h_simcols.p[k++] = tmp[i];
     }
     if (ord.npad) HIPCHK(c, hipMemcpyAsync(c->simcols.p, c->h_simcols.p, sizeof(int32_t) * ord.npad, hipMemcpyHostToDevice, st));
     return MSA_OK;
@@ -337,7 +343,8 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
                                 a.num_out = c->simnum.p, a.den_out = c->simden.p, a.state = c->simstate.p;
                                 a.gate = gate, a.cols = c->simcols.p;
                                 a.ldk = msak::bx_ldk(m), a.m = m, a.n = n, a.ldw = c->ldw, a.ncols = ord.npad;
-                                msak::LgSide side = {c->stream2, c->ev_fork, c->ev_join};
+                                msak::LgSide side = {msak::lg_parts(), {c->stream2, c->part_stream[0], c->part_stream[1]}, c->ev_fork,
+                                                     {c->ev_join, c->part_join[0], c->part_join[1]}};
                                 return msak::launch_similarity_lg(c->stream, a, npos, c->tab.p, c->cus, &c->sim_launches,
                                                                   c->sim_halves && c->stream2 ? &side : nullptr);
                             }();

@@ -96,9 +96,9 @@ STRICT = [
     # --- a workgroup per column: min(8, wave slots / columns, rows / 1024) waves
     (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
     (2048, 500, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=6)),
-    # --- the columns as two staggered halves on two streams (2 x 6 + 1 launches): a workgroup per column from two columns per
+    # --- the columns as two staggered halves on two streams (6 + 6 launches at 2048 rows, 7 + 8 at 2600): a workgroup per column from two columns per
     #     compute unit on (up to 14 336 rows), a wave per column when the columns outnumber the wave slots (2560 ... 4608 rows)
-    (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=13)),
+    (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=12)),
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
     (2600, 5400, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=7)),
     (2600, 5700, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=15)),

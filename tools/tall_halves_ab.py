@@ -22,7 +22,8 @@ for m, n, seed in shapes:
     a = synth_msa(m, n, seed)
     out = {}
     for rnd in range(2):
-        for name, env in (("one sequence", {"MSA_LG_HALVES": "0"}), ("halves", {"MSA_LG_HALVES": "2"}), ("default", {})):
+        PARTS = os.environ.get("PARTS", "2")  # (MSA_LG_PARTS of the "halves" leg: 2, 3, 4)
+        for name, env in (("one sequence", {"MSA_LG_HALVES": "0"}), ("halves", {"MSA_LG_HALVES": "2", "MSA_LG_PARTS": PARTS}), ("default", {})):
             if name == "default" and rnd:
                 continue
             os.environ.pop("MSA_LG_HALVES", None)
@@ -32,6 +33,7 @@ for m, n, seed in shapes:
             ctx = _lib.Context(0)
             os.environ.pop("MSA_LG_HALVES", None)
             os.environ.pop("MSA_LG_ROUNDS", None)
+            os.environ.pop("MSA_LG_PARTS", None)
             ctx.upload(a, ord("X"))
             mdk, q = ctx.similarity(vhash, dist)
             ctx.prof_enable(True)
@@ -50,4 +52,4 @@ for m, n, seed in shapes:
                       "wall_ms_one_sequence": [r[1] for r in out["one sequence"]], "wall_ms_halves": [r[1] for r in out["halves"]],
                       "launches": [out["one sequence"][0][4]["sim_launches"], out["halves"][0][4]["sim_launches"]],
                       "default_rule_launches": out["default"][0][4]["sim_launches"], "sim_ms_default": out["default"][0][0],
-                      "waves_per_column": out["halves"][0][4]["sim_waves_per_column"], "q_and_mdk_bit_identical": bool(same)}), flush=True)
+                      "waves_per_column": out["halves"][0][4]["sim_waves_per_column"], "parts": int(os.environ.get("PARTS", "2")), "q_and_mdk_bit_identical": bool(same)}), flush=True)
