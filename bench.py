@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MSA statistics path (BASELINE.json metric).
 
-Workloads (BASELINE.json configs; `--workload`; default: C3 = the headline at one GPU, C5 = BASELINE config 5 when
-`--gpus N` > 1):
-  C3  AutomaticTrimmer('automated1') on a synthetic 2 000 x 10 000 protein MSA (seed 1003 + rank)
+Workloads (BASELINE.json configs; `--workload`; default: C3 = the headline, at every N -- one alignment per GPU per step, weak
+scaling, so that the lines of a 1 / 2 / 4 / 8 run hold the same per-GPU work; BASELINE config 5, the batch of 64 sharded over the
+ranks, is timed behind it and rides in the same line as `c5_batch`):
+  C3  AutomaticTrimmer('automated1') on a synthetic 2 000 x 10 000 protein MSA (seed 1003 + rank: all eight golden)
   C2  ManualTrimmer(gap_threshold=0.5, similarity_threshold=0.5) on 500 x 2 000 (seed 1002 + rank)
   C4  RepresentativeTrimmer(identity_threshold=0.5) on 5 000 x 5 000 (seed 1004 + rank)
   C5  the batch of 64 alignments of 1 000 x 4 000 (seeds 2000..2063), AutomaticTrimmer('automated1'), through
@@ -340,6 +341,8 @@ def main():
                     help="default: C3 (the headline) at one GPU, C5 (BASELINE config 5, strong scaling) with --gpus N > 1")
     ap.add_argument("--out", default=None, help="REF: also write the four result lines to this file (JSON lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5-leg", action="store_true",
+                    help="C3 only: do not time BASELINE config 5 (the batch of 64 sharded over the ranks) behind the headline")
     ap.add_argument("--cpu-sample-cols", type=int, default=10000,
                     help="columns of the workload's alignment the CPU baseline is timed on (default: all of them at C3: ~7 s per flavour)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -348,8 +351,12 @@ def main():
                          "multi-rank code path on a one-GPU box; the line it prints is marked and is not a multi-GPU measurement")
     args = ap.parse_args()
     if args.workload is None:
-        # BASELINE.json's multi-GPU config is the batch of 64 (config 5): that is what a scaling run measures unless told otherwise
-        args.workload = "C5" if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else "C3"
+        # The headline (C3) at every N: one alignment per GPU per step -- `value` of an N-GPU line is then N x the same per-GPU work
+        # as the 1-GPU line's (weak scaling: the two divide into an efficiency).  BASELINE config 5 -- the batch of 64 sharded over
+        # the ranks, strong scaling -- is timed behind it at every N and reported in the same line as `c5_batch` (--no-c5-leg skips
+        # it; `--workload C5` makes it the line's `value`).  Until round 6 a run with N > 1 defaulted to C5, so that the lines of a
+        # 1 / 2 / 4 / 8 scaling run held two different workloads.
+        args.workload = "C3"
 
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args)  # does not return
@@ -431,15 +438,19 @@ def main():
         dist.all_reduce(t)
         ranks_seen = int(t.item())
 
-    if args.workload == "C5":
+    def run_c5_batch(steps, warmup, with_public_api=True):
+        """BASELINE config 5: the batch of 64 alignments of 1000 x 4000 through `trim_batch`, sharded round-robin over the ranks
+        (strong scaling: the batch is the same whatever the number of ranks), from host rows to the masks gathered on rank 0.
+        Returns seconds for `steps` steps (max over ranks), the same through the public objects, rank 0's one-GPU reference
+        (world > 1) and the last step's masks."""
         from pytrimal_amd.batch import trim_batch
 
+        m5, n5, seed5 = WORKLOADS["C5"]
         alis = []
         for k in range(C5_BATCH):
-            a = synth_msa(m, n, seed + k)
-            alis.append(Alignment([b"s%d" % i for i in range(m)], [bytes(r) for r in a]))
+            a5 = synth_msa(m5, n5, seed5 + k)
+            alis.append(Alignment([b"s%d" % i for i in range(m5)], [bytes(r) for r in a5]))
         trimmer = AutomaticTrimmer("automated1", platform="hip")
-        units_per_step = C5_BATCH * n  # the whole batch, however many ranks share it: strong scaling
 
         def step(masks_only=True):
             # from host rows to the masks gathered on rank 0 (what the gather moves: BASELINE's "RCCL broadcast/gather of
@@ -448,21 +459,23 @@ def main():
             return trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, masks_only=masks_only,
                               force_collectives=dist is not None)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             out = step()
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
-        step(False)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        public_api_s = None
+        if with_public_api:
             step(False)
-        fence()
-        public_api_s = max_over_ranks(time.perf_counter() - t0)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(False)
+            fence()
+            public_api_s = max_over_ranks(time.perf_counter() - t0)
         # the same batch on ONE GPU (rank 0 alone, the others wait): the strong-scaling reference, so that a line of an
         # N-GPU run carries the 1-GPU number of the very same workload beside its own
         single_gpu_s = None
@@ -470,10 +483,17 @@ def main():
             if rank == 0:
                 trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, shard=False, masks_only=True)
                 t0 = time.perf_counter()
-                for _ in range(max(1, min(args.steps, 5))):
+                for _ in range(max(1, min(steps, 5))):
                     trim_batch(trimmer, alis, device=None if args.share_gpu else device, threads=4, shard=False, masks_only=True)
-                single_gpu_s = (time.perf_counter() - t0) / max(1, min(args.steps, 5))
+                single_gpu_s = (time.perf_counter() - t0) / max(1, min(steps, 5))
             fence()
+        kept = int(sum(int(res.sum()) for res, _ in out)) if rank == 0 else None
+        return elapsed, public_api_s, single_gpu_s, kept
+
+    c5_leg = None
+    if args.workload == "C5":
+        units_per_step = C5_BATCH * n  # the whole batch, however many ranks share it: strong scaling
+        elapsed, public_api_s, single_gpu_s, kept = run_c5_batch(args.steps, args.warmup)
         # kernel times of one alignment of the batch (profiled separately: the batch runs on per-thread contexts)
         a = synth_msa(m, n, seed + rank)
         ctx.prof_enable(True)
@@ -481,7 +501,6 @@ def main():
             ctx.upload(a, ord("X"))
             _, _, info = ctx.trim(params)
         ctx.prof_enable(False)
-        kept = int(sum(int(res.sum()) for res, _ in out)) if rank == 0 else None
     else:
         a = synth_msa(m, n, seed + rank)
         ld = (n + 63) // 64 * 64
@@ -491,11 +510,20 @@ def main():
         cdev = "cpu" if args.share_gpu else device  # where the collectives' tensors live
         gathered = [torch.empty(n, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
         units_per_step = world * n  # one alignment per rank per step: weak scaling
+        # the rank's kept-column mask on its way to rank 0: one page-locked staging vector and one device vector for the whole
+        # run (a tensor per step from pageable memory: an allocation and a staged copy per step)
+        mask_host = torch.empty(n, dtype=torch.uint8).pin_memory() if dist is not None and not args.share_gpu else None
+        mask_dev = torch.empty(n, dtype=torch.uint8, device=device) if mask_host is not None else None
 
         def finish(keep_res):
-            if dist is not None:
-                mask = torch.from_numpy(keep_res.view(np.uint8)).to(cdev)
-                dist.gather(mask, gathered, dst=0)
+            if dist is None:
+                return
+            if mask_host is None:  # (--share-gpu: gloo, host tensors)
+                dist.gather(torch.from_numpy(keep_res.view(np.uint8)), gathered, dst=0)
+                return
+            mask_host.numpy()[:] = keep_res.view(np.uint8)
+            mask_dev.copy_(mask_host, non_blocking=True)
+            dist.gather(mask_dev, gathered, dst=0)
 
         def step():
             # attach drops every derived buffer: each step recomputes the whole path from the bytes
@@ -598,6 +626,11 @@ def main():
             trimmer_obj.trim(fresh)
             cold.append(time.perf_counter() - t0)
         cold_s = max_over_ranks(float(np.median(cold)))
+        if args.workload == "C3" and not args.no_c5_leg:
+            # BASELINE config 5 behind the headline, at every N: the batch of 64 sharded over the ranks (strong scaling)
+            k5 = max(1, min(args.steps, 10))
+            e5, _, single5, kept5 = run_c5_batch(k5, max(1, min(args.warmup, 2)), with_public_api=False)
+            c5_leg = {"seconds": e5, "steps": k5, "single_gpu_s": single5, "kept": kept5}
 
     if args.workload in ("C2", "C3") and rank == 0:
         sim_clock = similarity_kernel_clock(a, vhash, dmat)
@@ -717,6 +750,20 @@ def main():
             "kernels_ms_source": ("HIP events: pairs and sim over the timed (host-rows) region, the other kernels over 5 untimed steps after it"
                                   if args.workload != "C5" else "HIP events over 3 untimed trims of one alignment of the batch"),
         }
+        if c5_leg is not None:
+            m5, n5, seed5 = WORKLOADS["C5"]
+            out["c5_batch"] = {
+                "workload": (f"BASELINE config 5: AutomaticTrimmer('automated1') on the batch of {C5_BATCH} synthetic {m5} seq x {n5} col protein "
+                             f"MSAs (seeds {seed5}..{seed5 + C5_BATCH - 1}) through trim_batch(threads=4), sharded round-robin over {world} "
+                             f"rank(s), from host rows to the masks gathered on rank 0"),
+                "value": round(C5_BATCH * n5 * c5_leg["steps"] / c5_leg["seconds"], 2), "unit": "columns/s", "scaling": "strong",
+                "ms_per_step": round(c5_leg["seconds"] / c5_leg["steps"] * 1e3, 4), "steps": c5_leg["steps"], "n_gpus": world,
+                "kept_columns": c5_leg["kept"], "kept_columns_ok": c5_leg["kept"] == 192501,  # (tests/golden/configs.npz: the 64 masks)
+                "note": "timed behind the headline with the same fences and the max over ranks; value(N) / value(1) of this object over "
+                        "the lines of a 1 / 2 / 4 / 8 run is config 5's strong-scaling speed-up",
+            }
+            if c5_leg["single_gpu_s"]:
+                out["c5_batch"]["same_batch_on_rank0_alone_ms"] = round(c5_leg["single_gpu_s"] * 1e3, 4)
         if args.workload == "C5" and world > 1 and single_gpu_s:
             out["strong_scaling_reference_1gpu"] = {
                 "value": round(units_per_step / single_gpu_s, 2), "unit": "columns/s", "ms_per_step": round(single_gpu_s * 1e3, 4),

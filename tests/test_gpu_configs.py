@@ -311,7 +311,7 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     import json
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "C5", "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -323,7 +323,7 @@ def test_bench_multi_rank_code_path_on_one_gpu():
 
 
 def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
-    """`python bench.py --gpus 8 --share-gpu --steps 2`: what the driver's 8-GPU scaling run starts, on this box's one GPU --
+    """`python bench.py --gpus 8 --share-gpu --workload C5 --steps 2`: eight ranks on this box's one GPU --
     the launcher, eight ranks x four worker contexts, config 5 sharded 8 x 8, the gather of the masks, the max-over-ranks
     timing, ONE JSON line, a clean exit of every rank -- in well under the time such a run may take.  (RCCL itself needs a
     GPU per rank; the process group runs over gloo and the line says so.)"""
@@ -332,7 +332,7 @@ def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.perf_counter()
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--workload", "C5", "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=600, env=env)
     seconds = time.perf_counter() - t0
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
@@ -343,6 +343,27 @@ def test_bench_eight_ranks_dress_rehearsal_on_one_gpu():
     assert rec["config"]["ranks_seen"] == 8 and rec["config"]["kept_columns"] == 192501 and rec["config"]["kept_columns_ok"] is True
     assert rec["strong_scaling_reference_1gpu"]["value"] > 0 and rec["value"] > 0
     assert seconds < 180, f"the eight-rank run took {seconds:.0f} s"
+
+
+def test_bench_default_of_a_scaling_run_on_one_gpu():
+    """`python bench.py --gpus 2 --share-gpu --steps 2` with NO --workload: what the driver's scaling run starts for N > 1.  The
+    line's `value` is the headline workload (C3, one alignment per rank per step: weak scaling, N x the 1-GPU line's work) and
+    BASELINE config 5 -- the batch of 64 sharded over the ranks -- rides in the same line as `c5_batch`, all 64 masks golden."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 2 and "C3" in rec["config"]["workload"]
+    assert rec["config"]["ranks_seen"] == 2 and rec["config"]["selected_method"] == "strict" and rec["value"] > 0
+    assert rec["config"]["kept_columns"] == int(np.unpackbits(np.load(os.path.join(ROOT, "tests", "golden", "configs.npz"))["C3.res"])[:10000].sum())  # (rank 0's alignment)
+    c5 = rec["c5_batch"]
+    assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["kept_columns"] == 192501 and c5["kept_columns_ok"] is True
+    assert c5["value"] > 0 and c5["same_batch_on_rank0_alone_ms"] > 0
 
 
 def _launcher_env():
