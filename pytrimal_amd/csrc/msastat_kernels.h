@@ -32,6 +32,7 @@ struct Tuning {
     int pair_k = 0;            // MSA_PAIR_K: waves per tile of the pair pass (0: by size)
     int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
     int lg_parts = 2;          // MSA_LG_PARTS: staggered parts of such a pass (2, 3, 4)
+    int lg_pipe = 1;           // MSA_LG_PIPE: 1 the waves of a split column run ahead of the stitching where it pays (lg_pipe), 0 never, 2 whenever a column is split (tests)
     int lg_halves = 1;         // MSA_LG_HALVES: 1 the columns of a multi-launch similarity pass as two staggered halves where it pays (lg_halves), 0 never, 2 always (tests)
 };
 Tuning tuning_from_env();
@@ -41,7 +42,7 @@ const Tuning *current_tuning();    // what set_tuning last received on this thre
 const Tuning &tuning();
 // What the launch wrappers last chose on this thread (diagnostics: msa_debug_last_paths copies it into the context).
 struct LaunchNote {
-    int sim_kind = 0;     // 0 none, 1 flat, 2 wave-per-column (byte offsets), 3 wave-per-column (row indices), 4 sequential, 5 lane-per-column (batches)
+    int sim_kind = 0;     // 0 none, 1 flat, 2 wave-per-column (byte offsets), 3 wave-per-column (row indices), 4 sequential, 5 lane-per-column (batches), 6 / 7: 2 / 3 with the waves of a split column running ahead of the stitching
     int lg_split = 0;     // waves of a workgroup per column (1: a wave per column)
     int lg_launches = 0;  // launches of the pass
     int lg_fin = 0;       // the kernel writes MDK and Q itself (the compact pipeline)
@@ -106,6 +107,7 @@ bool lg_finishes(const LgAlign &one, int cus);  // launch_similarity_lg will hon
 int launch_similarity_lg_batch(hipStream_t s, const LgAlign *table, const int32_t *colprefix, int K, int ncols_total, int max_m, int npos,
                                const void *tab, bool with_state, int *launches_out);
 int lg_split(int m, int ncols, int cus);  // waves per column the launcher picks
+bool lg_pipe(int m, int ncols, int cus);  // ... as loop waves of the pipelined kernel (+ a service wave), not of the barrier scheme
 int lg_rounds_per_launch(int m);          // rounds per launch (0: everything in one launch)
 size_t lg_state_floats(int n);
 // One alignment of a batch as the batched kernels see it (device pointers): msa_trim_batch uploads a table of these and,

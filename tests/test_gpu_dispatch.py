@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
                 "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
-                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES")
+                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE")
 
 
 def _compute_units():
@@ -91,22 +91,31 @@ STRICT = [
     (1025, 1904, dict(pipeline="two_streams", **LG1)),
     (1025, 2000, dict(pipeline="two_streams", pair_kernel="pipe16", pair_waves_per_tile=4, **LG1)),
     # --- a launch every six rounds from 1800 rows (29 rounds: one launch, or five)
-    (1799, 700, dict(pipeline="two_streams", sim_launches=1, **LG1)),
-    (1800, 700, dict(pipeline="two_streams", sim_launches=5, **LG1)),
-    # --- a workgroup per column: min(8, wave slots / columns, rows / 1024) waves
-    (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
-    (2048, 500, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=6)),
-    # --- the columns as two staggered halves on two streams (6 + 6 launches at 2048 rows, 7 + 8 at 2600): a workgroup per column from two columns per
-    #     compute unit on (up to 14 336 rows), a wave per column when the columns outnumber the wave slots (2560 ... 4608 rows)
-    (2048, 1000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=12)),
+    (1799, 1500, dict(pipeline="two_streams", sim_launches=1, **LG1)),
+    (1800, 1500, dict(pipeline="two_streams", sim_launches=5, **LG1)),
+    # --- few columns, up to 9000 rows (round 6): S loop waves + a service wave per column, no barrier -- 12 up to a column per compute
+    #     unit, 7 up to two, 3 up to five (evaluated columns: ~92 % of n here), none with less than 256 rows; one launch up to 3600 rows
+    (1799, 700, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
+    (1500, 300, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
+    (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
+    (2048, 500, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=7, sim_launches=1)),
+    (2048, 1500, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=12)),   # (more than five columns per compute unit: the barrier scheme's two, as two staggered halves)
+    (3328, 200, dict(sim_kernel="lg_pipe", sim_waves_per_column=12, sim_launches=1)),
+    (3700, 500, dict(sim_kernel="lg_pipe", sim_waves_per_column=7, sim_launches=10)),
+    (3700, 1000, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=21)),   # (... as two staggered halves: 10 + 11)
+    # --- a workgroup per column with a barrier per round beyond 9000 rows: min(8 -- 12 up to 256 columns --, wave slots / columns, rows / 1024) waves
+    (9216, 64, dict(sim_kernel="lg", sim_waves_per_column=9)),
+    (9216, 300, dict(sim_kernel="lg", sim_waves_per_column=8)),
+    # --- the columns as two staggered halves on two streams (7 + 8 launches at 2600 rows): a wave per column when the columns outnumber the
+    #     wave slots (2560 ... 4608 rows)
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
     (2600, 5400, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=7)),
     (2600, 5700, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=15)),
     # --- pair pass: eight rows i per tile up to 512 rows, sixteen from 513 on (K waves per tile while tiles x K <= 10240); one row j
     #     per lane below 4096 rows (m_pad / 128 * ceil(m / 8) / 2 < 8192), two from there on
     (2000, 2100, dict(pair_kernel="pipe16", pair_waves_per_tile=4, sim_kernel="lg")),
-    (4088, 64, dict(pair_kernel="pipe16", pair_waves_per_tile=1, sim_kernel="lg")),
-    (4096, 64, dict(pair_kernel="two_rows", pair_waves_per_tile=1, sim_kernel="lg")),
+    (4088, 64, dict(pair_kernel="pipe16", pair_waves_per_tile=1, sim_kernel="lg_pipe")),
+    (4096, 64, dict(pair_kernel="two_rows", pair_waves_per_tile=1, sim_kernel="lg_pipe")),
 ]
 
 
@@ -144,7 +153,7 @@ def test_default_dispatch_of_a_gap_only_trim(default_ctx, m, n, pipe):
 
 # msa_similarity by itself: the compact pipeline where it applies, else its own serial launch sequence
 SIMILARITY = [(100, 700, dict(pipeline="compact", sim_kernel="flat")), (400, 700, dict(pipeline="compact", sim_writes_mdk=1, **LG1)),
-              (513, 700, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)), (1025, 700, dict(pipeline="serial", sim_writes_mdk=0, **LG1)),
+              (513, 700, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1)), (1025, 700, dict(pipeline="serial", sim_writes_mdk=0, sim_kernel="lg_pipe", sim_waves_per_column=3)),
               (400, 5121, dict(pipeline="compact_sorted", sim_writes_mdk=1, **LG1))]
 
 
