@@ -91,15 +91,16 @@ STRICT = [
     (1025, 1904, dict(pipeline="two_streams", **LG1)),
     (1025, 2000, dict(pipeline="two_streams", pair_kernel="pipe16", pair_waves_per_tile=4, **LG1)),
     # --- a launch every six rounds from 1800 rows (29 rounds: one launch, or five)
-    (1799, 1500, dict(pipeline="two_streams", sim_launches=1, **LG1)),
-    (1800, 1500, dict(pipeline="two_streams", sim_launches=5, **LG1)),
+    (1799, 1800, dict(pipeline="two_streams", sim_launches=1, **LG1)),
+    (1800, 1800, dict(pipeline="two_streams", sim_launches=5, **LG1)),
     # --- few columns, up to 9000 rows (round 6): S loop waves + a service wave per column, no barrier -- 12 up to a column per compute
-    #     unit, 7 up to two, 3 up to five (evaluated columns: ~92 % of n here), none with less than 256 rows; one launch up to 3600 rows
-    (1799, 700, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
+    #     unit (and a quarter), 7 up to two (and a half), 3 up to six (evaluated columns: ~92 % of n here), none with less than 256 rows; one launch up to 3600 rows
+    (1799, 900, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
     (1500, 300, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
     (2047, 1000, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
     (2048, 500, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=7, sim_launches=1)),
-    (2048, 1500, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=12)),   # (more than five columns per compute unit: the barrier scheme's two, as two staggered halves)
+    (2048, 1500, dict(pipeline="two_streams", sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=1)),
+    (2048, 1800, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=2, sim_launches=12)),   # (more than six columns per compute unit: the barrier scheme's two, as two staggered halves)
     (3328, 200, dict(sim_kernel="lg_pipe", sim_waves_per_column=12, sim_launches=1)),
     (3700, 500, dict(sim_kernel="lg_pipe", sim_waves_per_column=7, sim_launches=10)),
     (3700, 1000, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=21)),   # (... as two staggered halves: 10 + 11)
