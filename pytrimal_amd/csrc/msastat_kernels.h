@@ -33,6 +33,7 @@ struct Tuning {
     int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
     int lg_parts = 2;          // MSA_LG_PARTS: staggered parts of such a pass (2, 3, 4)
     int lg_pipe = 1;           // MSA_LG_PIPE: 1 the waves of a split column run ahead of the stitching where it pays (lg_pipe), 0 never, 2 whenever a column is split (tests)
+    int lg_pipe_k = 1;         // MSA_LG_PIPE_K: sub-rounds per round of that kernel (1 .. 8)
     int lg_halves = 1;         // MSA_LG_HALVES: 1 the columns of a multi-launch similarity pass as two staggered halves where it pays (lg_halves), 0 never, 2 always (tests)
 };
 Tuning tuning_from_env();

@@ -612,6 +612,7 @@ Tuning tuning_from_env() {
     t.lists_fused = num("MSA_LISTS_FUSED", 1);
     t.lg_halves = num("MSA_LG_HALVES", 1);
     t.lg_pipe = num("MSA_LG_PIPE", 1);
+    t.lg_pipe_k = num("MSA_LG_PIPE_K", 1);
     t.lg_parts = num("MSA_LG_PARTS", 2);
     return t;
 }

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
                 "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
-                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE")
+                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K")
 
 
 def _compute_units():

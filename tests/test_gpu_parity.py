@@ -36,7 +36,7 @@ def ctx_with(monkeypatch):
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT",
                      "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD",
-                     "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE"):
+                     "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -418,12 +418,14 @@ KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLA
            # (round 6, late) a forced split up to twelve now runs as loop waves + a service wave (similarity_lg_pipe_body); MSA_LG_PIPE=0: the
            # barrier scheme of rounds 4 - 6
            dict(MSA_LG_SPLIT="2", MSA_LG_PIPE="0"), dict(MSA_LG_SPLIT="8", MSA_LG_PIPE="0", MSA_LG_ROUNDS="2"), dict(MSA_LG_SPLIT="3", MSA_LG_ROUNDS="0"),
-           dict(MSA_LG_SPLIT="7", MSA_LG_ROUNDS="2"), dict(MSA_LG_SPLIT="12", MSA_LG_BIG="1"),
+           dict(MSA_LG_SPLIT="7", MSA_LG_ROUNDS="2"), dict(MSA_LG_SPLIT="12", MSA_LG_BIG="1"), dict(MSA_LG_SPLIT="5", MSA_LG_PIPE_K="3"),
+           dict(MSA_LG_SPLIT="2", MSA_LG_PIPE="3", MSA_LG_PIPE_K="8", MSA_LG_ROUNDS="1"),
            dict(MSA_COMPACT="0", MSA_LG_HALVES="2", MSA_LG_ROUNDS="3", MSA_LG_SPLIT="4", MSA_LG_PIPE="0"),
            dict(MSA_SIM_KERNEL="seq")]
 KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "compact-flat-512-u4", "compact-flat-512-u8", "compact-flat-512-u16", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
               "lg-split-16-big", "lg-lists-in-two-passes", "lg-round5-front-pairs", "narrow-front-32-pairs-16", "lg-halves", "lg-halves-split-4",
-              "lg-barrier-split-2", "lg-barrier-split-8-rounds", "lg-pipe-3-one-launch", "lg-pipe-7-rounds", "lg-pipe-12-big", "lg-barrier-halves-split-4", "seq"]
+              "lg-barrier-split-2", "lg-barrier-split-8-rounds", "lg-pipe-3-one-launch", "lg-pipe-7-rounds", "lg-pipe-12-big", "lg-pipe-5-subrounds-3",
+              "lg-pipe-2-lockstep-subrounds-8", "lg-barrier-halves-split-4", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
