@@ -292,7 +292,9 @@ enum {
     MSA_PATH_SIM_SEQ = 4,        /* the plain sequential kernel (MSA_SIM_KERNEL=seq) */
     MSA_PATH_SIM_COLS = 5,       /* a lane per column (groups of small alignments in msa_trim_batch) */
     MSA_PATH_SIM_LG_PIPE = 6,    /* out[3] loop waves and a service wave per column, no barrier (few columns, up to 9000 rows), byte offsets */
-    MSA_PATH_SIM_LG_BIG_PIPE = 7 /* ... row indices in the lists */
+    MSA_PATH_SIM_LG_BIG_PIPE = 7, /* ... row indices in the lists */
+    MSA_PATH_SIM_LG_XSEG = 8,    /* tall alignments of few columns: wave w of every column on XCD w, increments and sums through memory */
+    MSA_PATH_SIM_LG_BIG_XSEG = 9 /* ... row indices in the lists */
 };
 enum { MSA_PATH_PAIRS_NONE = 0, MSA_PATH_PAIRS_PIPE = 1 /* one row j per lane */, MSA_PATH_PAIRS_TWO_ROWS = 2 /* two rows j per lane */,
        MSA_PATH_PAIRS_PIPE16 = 3 /* one row j per lane, sixteen rows i per tile (up to 1024 sequences) */ };

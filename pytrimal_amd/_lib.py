@@ -453,7 +453,7 @@ class Context:
     PATH_NAMES = {
         "upload": ("none", "in_place", "linear", "pitched", "packed", "attached", "repitched"),
         "pipeline": ("none", "serial", "one_stream", "two_streams", "compact", "compact_gaps", "compact_sorted"),
-        "sim_kernel": ("none", "flat", "lg", "lg_big", "seq", "cols", "lg_pipe", "lg_big_pipe"),
+        "sim_kernel": ("none", "flat", "lg", "lg_big", "seq", "cols", "lg_pipe", "lg_big_pipe", "lg_xseg", "lg_big_xseg"),
         "pair_kernel": ("none", "pipe", "two_rows", "pipe16"),
     }
 

@@ -170,6 +170,7 @@ struct msa_ctx {
     DevBuf<int32_t> gaps_w;
     DevBuf<float> mdk, simnum, simden;  // mdk: MDK [n] followed by Q [n]
     bool compact_sorted = false;        // the last compact pipeline dealt the columns to its similarity kernel by weight (paths[1])
+    DevBuf<char> xsegbuf;               // the XCD-per-segment kernel's rings and flags (msak::lg_xseg_bytes)
     DevBuf<float> simstate;             // the similarity kernel's per-column state between its launches (many rows: a few rounds per launch)
     DevView<unsigned long long> errkey;  // first bad residue of the similarity pass, complemented (0 = none): state block
     DevView<int> errflag;                // prep_planes' non-ASCII flag (state block)

@@ -33,6 +33,8 @@ struct Tuning {
     int lists_fused = 1;       // MSA_LISTS_FUSED=0: codes and lists by sim_encode_cm + bx_compact at every size (tests, A/B)
     int lg_parts = 2;          // MSA_LG_PARTS: staggered parts of such a pass (2, 3, 4)
     int lg_pipe = 1;           // MSA_LG_PIPE: 1 the waves of a split column run ahead of the stitching where it pays (lg_pipe), 0 never, 2 whenever a column is split (tests)
+    int lg_xseg = 1;           // MSA_LG_XSEG: 1 tall alignments of few columns with an XCD per segment (lg_xseg), 0 never, 2 whenever the columns are few enough (tests)
+    int lg_xseg_kx = 0;        // MSA_LG_XSEG_KX: loop waves of a column per XCD of that kernel (0: by the number of columns; 1, 2, 4)
     int lg_pipe_k = 1;         // MSA_LG_PIPE_K: sub-rounds per round of that kernel (1 .. 8)
     int lg_halves = 1;         // MSA_LG_HALVES: 1 the columns of a multi-launch similarity pass as two staggered halves where it pays (lg_halves), 0 never, 2 always (tests)
 };
@@ -43,7 +45,7 @@ const Tuning *current_tuning();    // what set_tuning last received on this thre
 const Tuning &tuning();
 // What the launch wrappers last chose on this thread (diagnostics: msa_debug_last_paths copies it into the context).
 struct LaunchNote {
-    int sim_kind = 0;     // 0 none, 1 flat, 2 wave-per-column (byte offsets), 3 wave-per-column (row indices), 4 sequential, 5 lane-per-column (batches), 6 / 7: 2 / 3 with the waves of a split column running ahead of the stitching
+    int sim_kind = 0;     // 0 none, 1 flat, 2 wave-per-column (byte offsets), 3 wave-per-column (row indices), 4 sequential, 5 lane-per-column (batches), 6 / 7: 2 / 3 with the waves of a split column running ahead of the stitching, 8 / 9: 2 / 3 with an XCD per segment
     int lg_split = 0;     // waves of a workgroup per column (1: a wave per column)
     int lg_launches = 0;  // launches of the pass
     int lg_fin = 0;       // the kernel writes MDK and Q itself (the compact pipeline)
@@ -100,8 +102,18 @@ struct LgSide {  // further streams and events of the caller's: the columns of a
     hipStream_t s[3];    // the streams of the parts 1 ..
     hipEvent_t fork, join[3];
 };
+struct LgXsegBufs {  // device memory of the XCD-per-segment kernel of tall alignments (similarity_lg_xseg_kernel: lg_xseg, lg_xseg_bytes, lg_xseg_bufs)
+    float *dep;     // [columns][4 rounds][8 waves][4][64]: the increments on their way to the column's service wave
+    float *eslots;  // [columns][4][4]: the exact sums and ratios in front of a round
+    int *flags;     // [columns][8]
+    int *err;       // [0] a wait timed out: the pass is void  [1] the gate of the launches that redo it
+};
+bool lg_xseg(int m, int ncols, int cus);
+size_t lg_xseg_bytes(int ncols);
+LgXsegBufs lg_xseg_bufs(void *base, int ncols);
 int lg_parts();  // parts of a pass that lg_halves says is to be staggered (2; MSA_LG_PARTS: 3, 4)
-int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out, const LgSide *side = nullptr);
+int launch_similarity_lg(hipStream_t s, const LgAlign &one, int npos, const void *tab, int cus, int *launches_out, const LgSide *side = nullptr,
+                         const LgXsegBufs *xseg = nullptr);
 bool lg_halves(int m, int ncols, int cus, bool with_state);
 int lg_halves_rounds(int m);  // rounds per launch of the two halves
 bool lg_finishes(const LgAlign &one, int cus);  // launch_similarity_lg will honour one.mdk_out (else the caller runs sim_finish)

@@ -613,6 +613,8 @@ Tuning tuning_from_env() {
     t.lg_halves = num("MSA_LG_HALVES", 1);
     t.lg_pipe = num("MSA_LG_PIPE", 1);
     t.lg_pipe_k = num("MSA_LG_PIPE_K", 1);
+    t.lg_xseg = num("MSA_LG_XSEG", 1);
+    t.lg_xseg_kx = num("MSA_LG_XSEG_KX", 0);
     t.lg_parts = num("MSA_LG_PARTS", 2);
     return t;
 }

@@ -345,8 +345,11 @@ int sim_kernel_enqueue(msa_ctx *c, int npos, const SimOrder &ord, const int32_t 
                                 a.ldk = msak::bx_ldk(m), a.m = m, a.n = n, a.ldw = c->ldw, a.ncols = ord.npad;
                                 msak::LgSide side = {msak::lg_parts(), {c->stream2, c->part_stream[0], c->part_stream[1]}, c->ev_fork,
                                                      {c->ev_join, c->part_join[0], c->part_join[1]}};
+                                msak::LgXsegBufs xb = {};
+                                if (msak::lg_xseg(m, ord.npad, c->cus) && c->xsegbuf.reserve(msak::lg_xseg_bytes(ord.npad)) == hipSuccess)
+                                    xb = msak::lg_xseg_bufs(c->xsegbuf.p, ord.npad);
                                 return msak::launch_similarity_lg(c->stream, a, npos, c->tab.p, c->cus, &c->sim_launches,
-                                                                  c->sim_halves && c->stream2 ? &side : nullptr);
+                                                                  c->sim_halves && c->stream2 ? &side : nullptr, xb.dep ? &xb : nullptr);
                             }();
         if (e) return fail_hip(c, (hipError_t)e, "launch_similarity");
     }

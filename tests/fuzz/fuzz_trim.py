@@ -37,9 +37,11 @@ CONTEXTS = [dict(), dict(MSA_FLAT_MAX_M="512"), dict(MSA_FLAT_MAX_M="0", MSA_MDK
             dict(MSA_LG_HALVES="0"),
             # (round 6, late) a forced split runs as loop waves + a service wave up to twelve; the barrier scheme, and the pipelined kernel wherever a column is split
             dict(MSA_LG_SPLIT="5", MSA_LG_PIPE="0"), dict(MSA_LG_PIPE="0"), dict(MSA_LG_SPLIT="12", MSA_LG_ROUNDS="1"),
-            dict(MSA_LG_SPLIT="4", MSA_LG_PIPE_K="4")]
+            dict(MSA_LG_SPLIT="4", MSA_LG_PIPE_K="4"),
+            # the XCD-per-segment kernel of tall alignments at any size, and its pass giving up at once
+            dict(MSA_COMPACT="0", MSA_LG_XSEG="2"), dict(MSA_COMPACT="0", MSA_LG_XSEG="3", MSA_LG_ROUNDS="3")]
 SWITCHES = ("MSA_PIPELINE", "MSA_LG_BIG", "MSA_SIM_KERNEL", "MSA_MDK_HOST", "MSA_UPLOAD_DIRECT", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_COMPACT",
-            "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K")
+            "MSA_FLAT_MAX_M", "MSA_ZEROCOPY_KB", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K", "MSA_LG_XSEG", "MSA_LG_XSEG_KX")
 ctxs = []
 for env in CONTEXTS:
     for k in SWITCHES:

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 MSA_SWITCHES = ("MSA_SIM_KERNEL", "MSA_SIM_MODE", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE",
                 "MSA_UPLOAD_DIRECT", "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB",
-                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K")
+                "MSA_DEVICE_CLUSTERS", "MSA_TRACE", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD", "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K", "MSA_LG_XSEG", "MSA_LG_XSEG_KX")
 
 
 def _compute_units():
@@ -104,9 +104,10 @@ STRICT = [
     (3328, 200, dict(sim_kernel="lg_pipe", sim_waves_per_column=12, sim_launches=1)),
     (3700, 500, dict(sim_kernel="lg_pipe", sim_waves_per_column=7, sim_launches=10)),
     (3700, 1000, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=21)),   # (... as two staggered halves: 10 + 11)
-    # --- a workgroup per column with a barrier per round beyond 9000 rows: min(8 -- 12 up to 256 columns --, wave slots / columns, rows / 1024) waves
-    (9216, 64, dict(sim_kernel="lg", sim_waves_per_column=9)),
-    (9216, 300, dict(sim_kernel="lg", sim_waves_per_column=8)),
+    # --- beyond 9000 rows with up to 568 columns: wave w of every column on XCD w (round 6, late) -- eight loop waves per column, sixteen while
+    #     17 x columns waves fit the chip; with more columns a workgroup per column and a barrier per round
+    (9216, 64, dict(sim_kernel="lg_xseg", sim_waves_per_column=16)),
+    (9216, 340, dict(sim_kernel="lg_xseg", sim_waves_per_column=8)),
     # --- the columns as two staggered halves on two streams (7 + 8 launches at 2600 rows): a wave per column when the columns outnumber the
     #     wave slots (2560 ... 4608 rows)
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),

@@ -36,7 +36,7 @@ def ctx_with(monkeypatch):
     def make(**env):
         for name in ("MSA_SIM_KERNEL", "MSA_LG_R0", "MSA_LG_BIG", "MSA_LG_ROUNDS", "MSA_LG_SPLIT", "MSA_MDK_HOST", "MSA_PIPELINE", "MSA_UPLOAD_DIRECT",
                      "MSA_COMPACT", "MSA_FLAT_MAX_M", "MSA_FLAT_U", "MSA_ZEROCOPY_KB", "MSA_FRONT_CW", "MSA_FRONT_NT", "MSA_FRONT_XCD",
-                     "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K"):
+                     "MSA_FRONT_FROM_M", "MSA_PAIR_TI", "MSA_PAIR_K", "MSA_LISTS_FUSED", "MSA_LG_HALVES", "MSA_LG_PIPE", "MSA_LG_PIPE_K", "MSA_LG_XSEG", "MSA_LG_XSEG_KX"):
             monkeypatch.delenv(name, raising=False)
         for name, value in env.items():
             if value:
@@ -420,12 +420,16 @@ KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLA
            dict(MSA_LG_SPLIT="2", MSA_LG_PIPE="0"), dict(MSA_LG_SPLIT="8", MSA_LG_PIPE="0", MSA_LG_ROUNDS="2"), dict(MSA_LG_SPLIT="3", MSA_LG_ROUNDS="0"),
            dict(MSA_LG_SPLIT="7", MSA_LG_ROUNDS="2"), dict(MSA_LG_SPLIT="12", MSA_LG_BIG="1"), dict(MSA_LG_SPLIT="5", MSA_LG_PIPE_K="3"),
            dict(MSA_LG_SPLIT="2", MSA_LG_PIPE="3", MSA_LG_PIPE_K="8", MSA_LG_ROUNDS="1"),
+           # (round 6, late) the XCD-per-segment kernel of tall alignments forced at any size: 16 / 8 / 32 loop waves per column, a launch per
+           # two rounds; and the pass giving up at once (the gated barrier-scheme launches behind it do the work)
+           dict(MSA_COMPACT="0", MSA_LG_XSEG="2"), dict(MSA_COMPACT="0", MSA_LG_XSEG="2", MSA_LG_XSEG_KX="1", MSA_LG_ROUNDS="2"),
+           dict(MSA_COMPACT="0", MSA_LG_XSEG="2", MSA_LG_XSEG_KX="4", MSA_LG_BIG="1"), dict(MSA_COMPACT="0", MSA_LG_XSEG="3"),
            dict(MSA_COMPACT="0", MSA_LG_HALVES="2", MSA_LG_ROUNDS="3", MSA_LG_SPLIT="4", MSA_LG_PIPE="0"),
            dict(MSA_SIM_KERNEL="seq")]
 KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "compact-flat-512-u4", "compact-flat-512-u8", "compact-flat-512-u16", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
               "lg-split-16-big", "lg-lists-in-two-passes", "lg-round5-front-pairs", "narrow-front-32-pairs-16", "lg-halves", "lg-halves-split-4",
               "lg-barrier-split-2", "lg-barrier-split-8-rounds", "lg-pipe-3-one-launch", "lg-pipe-7-rounds", "lg-pipe-12-big", "lg-pipe-5-subrounds-3",
-              "lg-pipe-2-lockstep-subrounds-8", "lg-barrier-halves-split-4", "seq"]
+              "lg-pipe-2-lockstep-subrounds-8", "xseg-16", "xseg-8-rounds-2", "xseg-32-big", "xseg-gives-up", "lg-barrier-halves-split-4", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
@@ -482,7 +486,8 @@ def test_similarity_tall_alignments_split_columns(ctx_with, shape):
     g = ctx.gaps()
     mdk, q = ctx.similarity(vhash, dist)
     paths = ctx.last_paths()  # (the default dispatch: a workgroup of eight waves per column, row indices beyond 32768 rows)
-    assert paths["sim_waves_per_column"] == 8 and paths["sim_kernel"] == ("lg_big" if m > 32768 else "lg"), paths
+    # (round 6, late: wave w of every column on XCD w -- eight loop waves per column, sixteen while 17 x columns waves fit the chip)
+    assert paths["sim_waves_per_column"] == (16 if m > 32768 else 8) and paths["sim_kernel"] == ("lg_big_xseg" if m > 32768 else "lg_xseg"), paths
     # the CPU oracle itself on two 16-column slices of the workgroup-per-column path at the sizes it was built for (W from the
     # device's pair pass -- the oracle's own would take minutes here; the device's W against the oracle on row slices)
     assert np.array_equal(g, (a == ord("-")).sum(axis=0))
@@ -497,7 +502,7 @@ def test_similarity_tall_alignments_split_columns(ctx_with, shape):
         assert np.array_equal(bits(q[sl]), bits(oq)), f"Q of columns {c0}..{c0 + 15} differs from the oracle"
         assert np.array_equal(bits(mdk[sl]), bits(omdk)), f"MDK of columns {c0}..{c0 + 15} differs from the oracle"
     del w
-    for env in (dict(MSA_SIM_KERNEL="seq"), dict(MSA_LG_SPLIT="1")):
+    for env in (dict(MSA_SIM_KERNEL="seq"), dict(MSA_LG_SPLIT="1"), dict(MSA_LG_XSEG="0")):  # (... the sequential kernel, a wave per column, the barrier scheme)
         other = ctx_with(**env)
         other.upload(a, ord("X"))
         mdk2, q2 = other.similarity(vhash, dist)
@@ -518,7 +523,7 @@ def test_similarity_beyond_32768_rows(ctx_with):
     g = ctx.gaps()
     assert np.array_equal(g, (a == ord("-")).sum(axis=0))
     mdk, q = ctx.similarity(vhash, dist)
-    assert ctx.last_paths()["sim_kernel"] == "lg_big"
+    assert ctx.last_paths()["sim_kernel"] == "lg_big_xseg"
     seq = ctx_with(MSA_SIM_KERNEL="seq")
     seq.upload(a, ord("X"))
     mdk2, q2 = seq.similarity(vhash, dist)
