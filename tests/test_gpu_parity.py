@@ -510,6 +510,42 @@ def test_similarity_tall_alignments_split_columns(ctx_with, shape):
         assert np.array_equal(bits(q), bits(q2)) and np.array_equal(bits(mdk), bits(mdk2)), env
 
 
+def test_xseg_passes_of_several_contexts_at_once(ctx_with):
+    """The XCD-per-segment kernel admits one pass at a time per process (its 9 or 17 waves per column must all be resident): contexts
+    of other threads that ask meanwhile take the barrier scheme.  Four threads, a context each, the kernel forced at a size the
+    sequential kernel checks in a moment; every thread's Q and MDK against the sequential kernel's, bit for bit, twice over."""
+    import threading
+
+    vhash, dist = oracle.aa_matrix()
+    cases = [synth_msa(2300 + 64 * t, 40 + 7 * t, 900 + t) for t in range(4)]
+    want = []
+    for a in cases:
+        seq = ctx_with(MSA_SIM_KERNEL="seq")
+        seq.upload(a, ord("X"))
+        want.append(seq.similarity(vhash, dist))
+        seq.close()
+    ctxs = [ctx_with(MSA_LG_XSEG="2") for _ in cases]
+    bad, kinds = [], []
+
+    def run(t):
+        for _ in range(6):
+            ctxs[t].upload(cases[t], ord("X"))
+            mdk, q = ctxs[t].similarity(vhash, dist)
+            kinds.append(ctxs[t].last_paths()["sim_kernel"])
+            if not (np.array_equal(bits(q), bits(want[t][1])) and np.array_equal(bits(mdk), bits(want[t][0]))):
+                bad.append(t)
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for c in ctxs:
+        c.close()
+    assert not bad, f"threads {sorted(set(bad))} differ from the sequential kernel"
+    assert "lg_xseg" in kinds, kinds  # (at least the first pass of all runs the kernel; the others take whatever is free)
+
+
 def test_similarity_beyond_32768_rows(ctx_with):
     """40 000 sequences x 16 columns: past the 32-bit byte offsets of the W rows (m * ldw * 4 > 2^32), the lists hold row
     indices and the kernel multiplies them out.  Against the oracle -- with W taken from the device's pair pass, as in
