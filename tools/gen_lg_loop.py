@@ -44,7 +44,16 @@ def issue_rows(d, c):
     return out
 
 
+BIG = False  # (set per generated variant below)
+
+
 def load(i, o, vo):
+    if BIG:
+        # the list holds ROW INDICES (beyond 32768 rows the byte offsets of the W rows no longer fit 32 bits): the offset relative to the
+        # segment's first row, multiplied out on the scalar unit -- %[wuni] is then the address of THAT row, and the caller vouches that
+        # (last row - first row) x row bytes stays below 2^32 (round_loop_lds checks; else the C++ loop)
+        return [f"s_sub_u32 s{T0}, s{o + i}, %[k0]", f"s_mul_i32 s{T0}, s{T0}, %[rowb]", f"v_add_u32 v{vo}, s{T0}, %[joff]",
+                f"global_load_dword v{W0 + i}, v{vo}, %[wuni]"]
     return [f"v_add_u32 v{vo}, s{o + i}, %[joff]", f"global_load_dword v{W0 + i}, v{vo}, %[wuni]"]
 
 
@@ -81,44 +90,56 @@ def sload(o, c, off_bytes):
     return [f"s_load_dwordx16 s[{o}:{o + 15}], s[{OFFP}:{OFFP + 1}], {hex(off_bytes)}", f"s_load_dwordx8 s[{c}:{c + 7}], s[{TROWP}:{TROWP + 1}], {hex(off_bytes // 2)}"]
 
 
-lines = []
-L = lambda name: f".Llg_{name}_%="
-lines += [f"s_mov_b64 s[{OFFP}:{OFFP + 1}], %[offp]", f"s_mov_b64 s[{TROWP}:{TROWP + 1}], %[trowp]"]
-lines += sload(EA_O, EA_C, 0)
-lines += ["s_cmp_lt_u32 %[nblk], 2", f"s_cbranch_scc1 {L('pro')}"]
-lines += sload(EB_O, EB_C, 0x40)
-lines += [f"{L('pro')}:", "s_waitcnt lgkmcnt(0)"]
-for i in range(16):
-    lines += load(i, EA_O, DB + i)  # (block B's table-row registers are free until block A's top)
-lines += issue_rows(DA, EA_C)
-lines += [f"{L('loop')}:"]
-# ---- block A
-lines += ["s_waitcnt lgkmcnt(0)", "s_cmp_eq_u32 %[nblk], 1", f"s_cbranch_scc1 {L('lastA')}"]
-lines += issue_rows(DB, EB_C)
-lines += ["s_cmp_lt_u32 %[nblk], 3", f"s_cbranch_scc1 {L('noA')}"]
-lines += sload(EA_O, EA_C, 0x80)
-lines += [f"{L('noA')}:"]
-lines += consume_reload(DA, EB_O)
-# ---- block B
-lines += ["s_waitcnt lgkmcnt(0)", "s_cmp_eq_u32 %[nblk], 2", f"s_cbranch_scc1 {L('lastB')}"]
-lines += issue_rows(DA, EA_C)
-lines += [f"s_add_u32 s{OFFP}, s{OFFP}, 0x80", f"s_addc_u32 s{OFFP + 1}, s{OFFP + 1}, 0", f"s_add_u32 s{TROWP}, s{TROWP}, 0x40", f"s_addc_u32 s{TROWP + 1}, s{TROWP + 1}, 0"]
-lines += ["s_cmp_lt_u32 %[nblk], 4", f"s_cbranch_scc1 {L('noB')}"]
-lines += sload(EB_O, EB_C, 0x40)
-lines += [f"{L('noB')}:"]
-lines += consume_reload(DB, EA_O)
-lines += ["s_sub_u32 %[nblk], %[nblk], 2", f"s_branch {L('loop')}"]
-lines += [f"{L('lastA')}:"] + consume_last(DA) + [f"s_branch {L('done')}"]
-lines += [f"{L('lastB')}:"] + consume_last(DB)
-lines += [f"{L('done')}:"]
+def build(big):
+    global BIG
+    BIG = big
+    tag = "big_" if big else ""
+    lines = []
+    L = lambda name: f".Llg_{tag}{name}_%="
+    lines += [f"s_mov_b64 s[{OFFP}:{OFFP + 1}], %[offp]", f"s_mov_b64 s[{TROWP}:{TROWP + 1}], %[trowp]"]
+    lines += sload(EA_O, EA_C, 0)
+    lines += ["s_cmp_lt_u32 %[nblk], 2", f"s_cbranch_scc1 {L('pro')}"]
+    lines += sload(EB_O, EB_C, 0x40)
+    lines += [f"{L('pro')}:", "s_waitcnt lgkmcnt(0)"]
+    for i in range(16):
+        lines += load(i, EA_O, DB + i)  # (block B's table-row registers are free until block A's top)
+    lines += issue_rows(DA, EA_C)
+    lines += [f"{L('loop')}:"]
+    # ---- block A
+    lines += ["s_waitcnt lgkmcnt(0)", "s_cmp_eq_u32 %[nblk], 1", f"s_cbranch_scc1 {L('lastA')}"]
+    lines += issue_rows(DB, EB_C)
+    lines += ["s_cmp_lt_u32 %[nblk], 3", f"s_cbranch_scc1 {L('noA')}"]
+    lines += sload(EA_O, EA_C, 0x80)
+    lines += [f"{L('noA')}:"]
+    lines += consume_reload(DA, EB_O)
+    # ---- block B
+    lines += ["s_waitcnt lgkmcnt(0)", "s_cmp_eq_u32 %[nblk], 2", f"s_cbranch_scc1 {L('lastB')}"]
+    lines += issue_rows(DA, EA_C)
+    lines += [f"s_add_u32 s{OFFP}, s{OFFP}, 0x80", f"s_addc_u32 s{OFFP + 1}, s{OFFP + 1}, 0", f"s_add_u32 s{TROWP}, s{TROWP}, 0x40", f"s_addc_u32 s{TROWP + 1}, s{TROWP + 1}, 0"]
+    lines += ["s_cmp_lt_u32 %[nblk], 4", f"s_cbranch_scc1 {L('noB')}"]
+    lines += sload(EB_O, EB_C, 0x40)
+    lines += [f"{L('noB')}:"]
+    lines += consume_reload(DB, EA_O)
+    lines += ["s_sub_u32 %[nblk], %[nblk], 2", f"s_branch {L('loop')}"]
+    lines += [f"{L('lastA')}:"] + consume_last(DA) + [f"s_branch {L('done')}"]
+    lines += [f"{L('lastB')}:"] + consume_last(DB)
+    lines += [f"{L('done')}:"]
+
+    return lines
+
 
 clob = [f"v{r}" for r in range(48, 96)] + [f"s{r}" for r in range(36, 90)] + ["m0", "scc", "memory"]
-out = ["// GENERATED by tools/gen_lg_loop.py -- do not edit; the design is described there.", "#define LG_LOOP_ASM \\"]
-for ln in lines:
-    out.append(f'    "{ln}\\n\\t" \\')
-out.append('    ""')
+out = ["// GENERATED by tools/gen_lg_loop.py -- do not edit; the design is described there."]
+total = 0
+for big, name in ((False, "LG_LOOP_ASM"), (True, "LG_LOOP_BIG_ASM")):
+    lines = build(big)
+    total += len(lines)
+    out.append(f"#define {name} \\")
+    for ln in lines:
+        out.append(f'    "{ln}\\n\\t" \\')
+    out.append('    ""')
 out.append("#define LG_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pytrimal_amd", "csrc", "msastat_lgloop.inc")
 with open(path, "w") as f:
     f.write("\n".join(out) + "\n")
-print(path, len(lines), "instructions")
+print(path, total, "instructions")
