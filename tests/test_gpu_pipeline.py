@@ -262,6 +262,35 @@ def test_random_tall_trims_against_the_oracle():
     assert line["mismatch"] is False and line["mode"] == "tall" and line["cases"] > 30, line
 
 
+@pytest.mark.parametrize("m,n,kernel", [(8990, 20, "lg_pipe"), (9300, 24, "lg_xseg")])
+def test_whole_trims_on_both_sides_of_the_tall_boundary(m, n, kernel):
+    """Up to 9000 rows a split column's loop waves run ahead of its service wave inside one workgroup; beyond, wave w of every column
+    runs on XCD w and the increments travel through memory (round 6, late).  Whole `strict` and `automated1` trims of an alignment on
+    either side, through the DEFAULT dispatch, against the oracle: masks, cuts, the selected method."""
+    rng = np.random.default_rng(m)
+    a = synth_msa(m, n, 5150 + m)
+    a[rng.random(a.shape) < 0.02] = ord("X")
+    a[: m // 3, n // 2] = ord("-")  # (a column whose first valid row lies a hundred rounds down)
+    matrix = SimilarityMatrix.aa()
+    vhash = np.ascontiguousarray(matrix._vhash, dtype=np.int32)
+    dist = np.ascontiguousarray(matrix._dist, dtype=np.float32)
+    ctx = _lib.Context(0)
+    try:
+        for method in ("strict", "automated1"):
+            P = _lib.TrimParams(_lib.METHOD_CODES[method], -1.0, -1, -1.0, -1.0, -1, -1, -1, -1.0, -1.0, -1, -1.0, vhash.ctypes.data, dist.ctypes.data,
+                                len(matrix))
+            ctx.upload(a, ord("X"))
+            res, seq, info = ctx.trim(P)
+            if method == "strict":
+                assert ctx.last_paths()["sim_kernel"] == kernel, ctx.last_paths()
+            ores, oseq, oinfo = oracle.trim(a, method=method)
+            assert np.array_equal(res, ores) and np.array_equal(seq, oseq), f"{method}: masks differ from the oracle"
+            assert info.gap_cut == oinfo.gap_cut and info.selected_method == oinfo.selected
+            assert np.float32(info.sim_cut).view(np.uint32) == np.float32(oinfo.sim_cut).view(np.uint32)
+    finally:
+        ctx.close()
+
+
 def test_public_api_from_threads_against_the_oracle():
     """tests/fuzz/fuzz_threads.py: four threads trimming random protein / DNA / RNA alignments through the four trimmer classes
     (type detection, default matrices, per-thread contexts) against the oracle's trim at the same time."""
