@@ -424,12 +424,13 @@ KERNELS = [dict(), dict(MSA_COMPACT="0"), dict(MSA_FLAT_MAX_M="0"), dict(MSA_FLA
            # two rounds; and the pass giving up at once (the gated barrier-scheme launches behind it do the work)
            dict(MSA_COMPACT="0", MSA_LG_XSEG="2"), dict(MSA_COMPACT="0", MSA_LG_XSEG="2", MSA_LG_XSEG_KX="1", MSA_LG_ROUNDS="2"),
            dict(MSA_COMPACT="0", MSA_LG_XSEG="2", MSA_LG_XSEG_KX="4", MSA_LG_BIG="1"), dict(MSA_COMPACT="0", MSA_LG_XSEG="3"),
+           dict(MSA_COMPACT="0", MSA_LG_XSEG="2", MSA_LG_XSEG_KX="8", MSA_LG_ROUNDS="3"),  # (four segments per column: two XCDs share one)
            dict(MSA_COMPACT="0", MSA_LG_HALVES="2", MSA_LG_ROUNDS="3", MSA_LG_SPLIT="4", MSA_LG_PIPE="0"),
            dict(MSA_SIM_KERNEL="seq")]
 KERNEL_IDS = ["default", "lg", "compact-lg", "compact-flat-512", "compact-flat-512-u4", "compact-flat-512-u8", "compact-flat-512-u16", "lg-big", "lg-rounds", "lg-split-2", "lg-split-4-rounds", "lg-split-8",
               "lg-split-16-big", "lg-lists-in-two-passes", "lg-round5-front-pairs", "narrow-front-32-pairs-16", "lg-halves", "lg-halves-split-4",
               "lg-barrier-split-2", "lg-barrier-split-8-rounds", "lg-pipe-3-one-launch", "lg-pipe-7-rounds", "lg-pipe-12-big", "lg-pipe-5-subrounds-3",
-              "lg-pipe-2-lockstep-subrounds-8", "xseg-16", "xseg-8-rounds-2", "xseg-32-big", "xseg-gives-up", "lg-barrier-halves-split-4", "seq"]
+              "lg-pipe-2-lockstep-subrounds-8", "xseg-16", "xseg-8-rounds-2", "xseg-32-big", "xseg-gives-up", "xseg-4-rounds-3", "lg-barrier-halves-split-4", "seq"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
