@@ -108,7 +108,7 @@ STRICT = [
     #     17 x columns waves fit the chip; with more columns a workgroup per column and a barrier per round
     (9216, 64, dict(sim_kernel="lg_xseg", sim_waves_per_column=16)),
     (9216, 340, dict(sim_kernel="lg_xseg", sim_waves_per_column=8)),
-    (9216, 700, dict(sim_kernel="lg_xseg", sim_waves_per_column=4)),   # (569 .. 1024 columns up to 16000 rows: four segments, two XCDs share one)
+    (9216, 800, dict(sim_kernel="lg_xseg", sim_waves_per_column=4)),   # (700 .. ~970 columns up to 16000 rows: four segments, two XCDs share one)
     # --- the columns as two staggered halves on two streams (7 + 8 launches at 2600 rows): a wave per column when the columns outnumber the
     #     wave slots (2560 ... 4608 rows)
     (2048, 6000, dict(pipeline="two_streams", sim_kernel="lg", sim_waves_per_column=1, sim_launches=6)),
