@@ -226,6 +226,9 @@ int fetch_similarity_finish(msa_ctx *c, int n, float *mdk_out, float *q_out, msa
     // reference does it, from the bit-exact Q)
     const float *dm = c->h_f32.p, *dq = c->h_f32.p + n;
     for (int i = 0; i < n; ++i) {
+        // (Q is a quotient of two sums of terms >= 0 or 0: never a NaN -- unless the pipelined split-column kernel gave up on an internal
+        // wait and said so in its sums: similarity_lg_pipe_body)
+        if (dq[i] != dq[i]) return fail_hip(c, hipErrorUnknown, "similarity kernel: an internal wait between the waves of a column timed out");
         float v = dm[i];
         if (v != v) {
             v = static_cast<float>(std::exp(-static_cast<double>(dq[i])));

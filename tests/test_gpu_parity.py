@@ -473,6 +473,22 @@ def test_similarity_many_rows(ctx_with, kernel, shape):
     _sim_parity(ctx_with(**kernel), synth_msa(m, n, 77 + m))
 
 
+def test_pipelined_kernel_that_gives_up_is_an_error(ctx_with):
+    """The waits between the waves of a split column are bounded: a wait that never ends (a protocol error) raises a word in LDS, the
+    service wave writes NaN sums and the host turns them into an error -- loud, never a hang, never a silently wrong value.
+    MSA_LG_PIPE=4 makes every workgroup give up at once."""
+    a = synth_msa(2100, 40, 5)
+    vhash, dist = oracle.aa_matrix()
+    ctx = ctx_with(MSA_LG_PIPE="4")
+    ctx.upload(a, ord("X"))
+    with pytest.raises(RuntimeError):
+        ctx.similarity(vhash, dist)
+    ctx.close()
+    ok = ctx_with()
+    ok.upload(a, ord("X"))
+    _sim_parity(ok, a)  # (the next context of the process is unharmed)
+
+
 @pytest.mark.parametrize("shape", [(20000, 500), (40000, 300)])
 def test_similarity_tall_alignments_split_columns(ctx_with, shape):
     """Pfam-style shapes: far fewer columns than the chip has wave slots, so the launcher gives every column a workgroup of
