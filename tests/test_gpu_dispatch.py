@@ -106,7 +106,8 @@ STRICT = [
     (3700, 1000, dict(sim_kernel="lg_pipe", sim_waves_per_column=3, sim_launches=21)),   # (... as two staggered halves: 10 + 11)
     # --- beyond 9000 rows with up to 568 columns: wave w of every column on XCD w (round 6, late) -- eight loop waves per column, sixteen while
     #     17 x columns waves fit the chip; with more columns a workgroup per column and a barrier per round
-    (9216, 64, dict(sim_kernel="lg_xseg", sim_waves_per_column=16)),
+    (9216, 64, dict(sim_kernel="lg_pipe", sim_waves_per_column=12)),    # (a compute unit per column: the pipelined kernel up to 11000 rows)
+    (11100, 64, dict(sim_kernel="lg_xseg", sim_waves_per_column=16)),
     (9216, 340, dict(sim_kernel="lg_xseg", sim_waves_per_column=8)),
     (9216, 800, dict(sim_kernel="lg_xseg", sim_waves_per_column=4)),   # (700 .. ~970 columns up to 16000 rows: four segments, two XCDs share one)
     # --- the columns as two staggered halves on two streams (7 + 8 launches at 2600 rows): a wave per column when the columns outnumber the

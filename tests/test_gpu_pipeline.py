@@ -262,9 +262,9 @@ def test_random_tall_trims_against_the_oracle():
     assert line["mismatch"] is False and line["mode"] == "tall" and line["cases"] > 30, line
 
 
-@pytest.mark.parametrize("m,n,kernel", [(8990, 20, "lg_pipe"), (9300, 24, "lg_xseg")])
+@pytest.mark.parametrize("m,n,kernel", [(8990, 20, "lg_pipe"), (11050, 20, "lg_xseg")])
 def test_whole_trims_on_both_sides_of_the_tall_boundary(m, n, kernel):
-    """Up to 9000 rows a split column's loop waves run ahead of its service wave inside one workgroup; beyond, wave w of every column
+    """Up to 9000 rows (11000 with a compute unit per column) a split column's loop waves run ahead of its service wave inside one workgroup; beyond, wave w of every column
     runs on XCD w and the increments travel through memory (round 6, late).  Whole `strict` and `automated1` trims of an alignment on
     either side, through the DEFAULT dispatch, against the oracle: masks, cuts, the selected method."""
     rng = np.random.default_rng(m)
